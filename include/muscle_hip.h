@@ -1,0 +1,119 @@
+/* libmuscle_hip — C ABI of the MI355X (gfx950) kernels behind the MCL / MuSCLe training hot path.
+ *
+ * The reference (SCoulY/MuSCLe) is pure PyTorch and has no FFI of its own; what each entry point
+ * replaces is the ATen/cuDNN op sequence at the cited reference line (paths relative to the
+ * reference repository).  The drop-in boundary a user sees is the Python surface in muscle_amd/
+ * (same class and function names as src/__init__.py:1-6); this header is the boundary *under* it.
+ *
+ * Conventions
+ *   - every activation is NHWC fp32, viewed as a row-major matrix [rows = N*H*W, C]; C % 4 == 0 and
+ *     every pointer 16-byte aligned (the kernels use 16-byte accesses);
+ *   - weights keep the reference's state_dict layouts (conv [Cout, Cin/groups, k, k], linear [out, in]);
+ *   - the caller owns all memory; the library never allocates, never retains a pointer past return;
+ *   - calls only enqueue work on `stream` (a hipStream_t passed as void*), never synchronise;
+ *   - return 0 on success, a negative value for an argument error detected before launch, a positive
+ *     hipError_t otherwise; mx_last_error() returns a thread-local message;
+ *   - "+=" outputs accumulate (the caller zeroes them); they use fp32/fp64 hardware atomics, so their
+ *     last bits depend on arrival order.
+ *   - an operand "mode" selects the prologue applied while the operand is loaded:
+ *        0 PLAIN   v = x
+ *        1 BNACT   v = swish(scale[c]*x + shift[c]) * (gate ? gate[n,c] : 1)     n = row / rows_per_sample
+ *        2 AFFINE  v = scale[c]*x + shift[c]
+ */
+#ifndef MUSCLE_HIP_H
+#define MUSCLE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int mx_version(void);
+const char* mx_last_error(void);
+
+/* ---- pointwise (1x1) convolutions on fp32 MFMA: model.py:44,63,77,86 ------------------------------ */
+
+/* C[M,N] = A'[M,K] * W[N,K]^T (+bias[N]) (+residual[M,ldc]) (relu); stats[2N] += column (sum, sum^2) of C. */
+int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_shift, const float* a_gate,
+              int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,
+              const float* bias, const float* residual, int relu, double* stats, void* stream);
+
+/* dX[M,N] = G[M,K] * W[K,N] (+residual): data gradient of the 1x1 conv with weight W[K=Cout, N=Cin]. */
+int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, int ldg, int ldx,
+                const float* residual, void* stream);
+
+/* dW[Co,Ci] += G[R,Co]^T * X'[R,Ci]: weight gradient, reduction over the R pixel rows split across blocks. */
+int mx_pw_wgrad(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
+                const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
+                void* stream);
+
+/* batched plain GEMM for the PCM head (MuSCLe.py:213-223): layout 0: C=A*B^T (B [N,K]); 1: C=A*B (B [K,N]). */
+int mx_bgemm(int layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+             long sa, long sb, long sc, int batch, int relu, void* stream);
+
+/* ---- BatchNorm2d (train / eval), SiLU, SE gate, drop_connect + skip: model.py:45-94, utils.py:36-91 -- */
+
+/* stats[2C] += (sum x, sum x^2) per channel */
+int mx_colstats(const float* X, long rows, int C, double* stats, void* stream);
+
+/* training: batch mean / biased var from stats, running stats updated with `momentum` (unbiased var);
+ * eval: running stats.  Writes scale = gamma*rstd, shift = beta - mean*scale, and saves mean, rstd. */
+int mx_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                   float* mean, float* rstd, void* stream);
+
+/* out = (scale[c]*P + shift[c]) [swish if act] [* row_scale[n]] [+ residual]   (BN2 + drop_connect + skip) */
+int mx_bn_apply(const float* P, const float* scale, const float* shift, const float* row_scale, const float* residual,
+                float* out, long rows, int C, int rows_per_sample, int act, void* stream);
+
+/* effective upstream gradient  g = G [* row_scale[n]] ; [g = g*gate[n,c] + gate_add[n,c]] ;
+ * [g *= swish'(act_scale[c]*X + act_shift[c])] ;  sums[2C] += (sum g, sum g*X)  */
+int mx_bn_bwd_reduce(const float* G, const float* X, const float* row_scale, const float* gate, const float* gate_add,
+                     const float* act_scale, const float* act_shift, long rows, int C, int rows_per_sample,
+                     double* sums, void* stream);
+
+/* dgamma += rstd*(sum gx - mean*sum g); dbeta += sum g; (c1,c2,c3) so that dX = c1*g + c2*X + c3 */
+int mx_bn_bwd_finalize(const double* sums, int C, double count, const float* gamma, const float* mean, const float* rstd,
+                       int training, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream);
+
+/* out = c1[c]*g + c2[c]*X + c3[c] with g as in mx_bn_bwd_reduce (out may alias G) */
+int mx_bn_bwd_apply(const float* G, const float* X, const float* row_scale, const float* gate, const float* gate_add,
+                    const float* act_scale, const float* act_shift, const float* c1, const float* c2, const float* c3,
+                    float* out, long rows, int C, int rows_per_sample, void* stream);
+
+/* out[n,c] += sum_hw f(X[n,hw,c]),  f = [scale*x+shift] [swish if act] [* G]: SE squeeze (model.py:82),
+ * head GAP (MuSCLe.py:240) and the gate-gradient reduction of their backward. */
+int mx_pool_sum(const float* X, const float* G, const float* scale, const float* shift, int act, long rows, int C,
+                int rows_per_sample, float* out, void* stream);
+
+/* ---- depthwise k x k convolution, k in {3,5}, stride in {1,2}: model.py:50-52,78; utils.py:122-145 ---- */
+
+/* Y = dwconv(act(X)), act = swish(scale*x+shift) when scale != NULL; stats[2C] += (sum Y, sum Y^2) */
+int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, double* stats, int N,
+                  int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
+
+/* dX = dwconv^T(dY) (+residual): gradient w.r.t. the activated input */
+int mx_dwconv_bwd_data(const float* dY, const float* W, const float* residual, float* dX, int N, int H, int Wd, int C,
+                       int K, int S, int pad_lo, int Ho, int Wo, void* stream);
+
+/* dW[C,1,K,K] += sum dY * act(X) */
+int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, int N, int H,
+                         int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
+
+/* ---- SE excitation (model.py:83-84) and stem patches (model.py:131,175) -------------------------------- */
+
+/* s = pooled_sum*inv_hw; h = W1 s + b1; gate = sigmoid(W2 swish(h) + b2) */
+int mx_se_fwd(const float* pooled_sum, float inv_hw, const float* W1, const float* b1, const float* W2, const float* b2,
+              float* s, float* h, float* gate, int N, int C, int SQ, void* stream);
+
+/* given ggate[n,c] = dL/dgate: add[n,c] = (dL/ds)[n,c]*inv_hw; dW1,db1,dW2,db2 += */
+int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W1, const float* W2,
+              float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, int N, int C, int SQ,
+              void* stream);
+
+/* out[(n,oy,ox), ci*9+ky*3+kx] = img[n,ci,oy*2-pad+ky,ox*2-pad+kx] (NCHW image), rows of 28 floats (27 + 0) */
+int mx_stem_im2col(const float* img, float* out, int N, int H, int W, int Ho, int Wo, int pad_lo, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MUSCLE_HIP_H */

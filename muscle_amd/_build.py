@@ -1,0 +1,61 @@
+"""Build libmuscle_hip.so (gfx950) in-tree with hipcc.  Called by __graft_entry__.build()."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmuscle_hip.so")
+ARCH = "gfx950"
+FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
+
+
+def sources():
+    return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
+
+
+def _stale(out, deps):
+    if not os.path.exists(out):
+        return True
+    t = os.path.getmtime(out)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    objdir = os.path.join(HERE, "build")
+    os.makedirs(objdir, exist_ok=True)
+    jobs = []
+    for src in sources():
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        if force or _stale(obj, [src] + headers):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
+        if verbose:
+            print(f"[muscle_amd] compiled {os.path.basename(src)}", file=sys.stderr)
+
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        list(ex.map(cc, jobs))
+    objs = [os.path.join(objdir, os.path.basename(s) + ".o") for s in sources()]
+    if force or jobs or _stale(LIB, objs):
+        r = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB, *objs],
+                           capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stderr}")
+        if verbose:
+            print(f"[muscle_amd] linked {LIB}", file=sys.stderr)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,328 @@
+// BatchNorm statistics / affine / backward, SiLU and SE-gate elementwise work on NHWC
+// activation matrices [rows, C] (rows = N*H*W), HBM-bound streaming kernels.
+//
+// Reference semantics: nn.BatchNorm2d(momentum=0.01, eps=1e-3) in train and eval mode
+// (src/efficientnet_pytorch/model.py:45,53,64,132), MemoryEfficientSwish (utils.py:36-52),
+// the SE gate (model.py:81-84) and drop_connect + skip (model.py:90-93, utils.py:82-91).
+//
+// All per-channel reductions use one skeleton: a block owns a contiguous slab of rows, threads
+// are laid out (row-in-pass, float4-column) so every wave reads whole contiguous lines, partial
+// sums live in registers, are combined through LDS and leave the block as one fp64 (or fp32)
+// atomic per column.
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// column-reduction skeleton
+// ---------------------------------------------------------------------------
+struct ColGeom {
+  int rows, C, c4;        // matrix extents, C/4
+  int tcols;              // float4 columns handled by one block (<= 256)
+  int rpp;                // rows per pass = 256 / tcols (>=1)
+  int rows_per_block;
+  int rps;                // rows per sample
+};
+
+static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that one block may span at most*/) {
+  ColGeom g;
+  g.rows = (int)rows; g.C = C; g.c4 = C / 4; g.rps = rps;
+  g.tcols = g.c4 < 256 ? g.c4 : 256;
+  g.rpp = 256 / g.tcols;
+  int colchunks = cdiv(g.c4, g.tcols);
+  long target_blocks = 2048 / colchunks;
+  if (target_blocks < 1) target_blocks = 1;
+  long rpb = (rows_limit + target_blocks - 1) / target_blocks;
+  if (rpb < 4L * g.rpp) rpb = 4L * g.rpp;
+  rpb = (rpb + g.rpp - 1) / g.rpp * g.rpp;
+  if (rpb > rows_limit) rpb = rows_limit;
+  g.rows_per_block = (int)rpb;
+  return g;
+}
+
+// F::eval(r, c, v0, v1): contributes two float4 partials for element block (row r, cols c..c+3)
+template <class F, int NOUT, bool PER_SAMPLE, typename OutT>
+__global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* out0, OutT* out1) {
+  __shared__ float4 sm[2][256];
+  const int tid = threadIdx.x;
+  const int used = g.tcols * g.rpp;
+  const int tc = tid % g.tcols, tr = tid / g.tcols;
+  const int c4 = blockIdx.y * g.tcols + tc;
+  long r0, r1;
+  int sample = 0;
+  if (PER_SAMPLE) {
+    sample = blockIdx.z;
+    r0 = (long)sample * g.rps + (long)blockIdx.x * g.rows_per_block;
+    r1 = min((long)(sample + 1) * g.rps, r0 + g.rows_per_block);
+  } else {
+    r0 = (long)blockIdx.x * g.rows_per_block;
+    r1 = min((long)g.rows, r0 + g.rows_per_block);
+  }
+  float4 a0 = make_float4(0, 0, 0, 0), a1 = make_float4(0, 0, 0, 0);
+  if (tid < used && c4 < g.c4) {
+    for (long r = r0 + tr; r < r1; r += g.rpp) f.eval(r, 4 * c4, a0, a1);
+  }
+  sm[0][tid] = a0;
+  sm[1][tid] = a1;
+  __syncthreads();
+  if (tid < g.tcols && c4 < g.c4) {
+    float4 s0 = sm[0][tid], s1 = sm[1][tid];
+    for (int i = 1; i < g.rpp; ++i) {
+      float4 t0 = sm[0][tid + i * g.tcols], t1 = sm[1][tid + i * g.tcols];
+      s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w;
+      s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
+    }
+    const long o = (PER_SAMPLE ? (long)sample * g.C : 0) + 4 * c4;
+    unsafeAtomicAdd(out0 + o + 0, (OutT)s0.x); unsafeAtomicAdd(out0 + o + 1, (OutT)s0.y);
+    unsafeAtomicAdd(out0 + o + 2, (OutT)s0.z); unsafeAtomicAdd(out0 + o + 3, (OutT)s0.w);
+    if (NOUT > 1) {
+      unsafeAtomicAdd(out1 + o + 0, (OutT)s1.x); unsafeAtomicAdd(out1 + o + 1, (OutT)s1.y);
+      unsafeAtomicAdd(out1 + o + 2, (OutT)s1.z); unsafeAtomicAdd(out1 + o + 3, (OutT)s1.w);
+    }
+  }
+}
+
+template <class F, int NOUT, bool PER_SAMPLE, typename OutT>
+static void launch_colreduce(const F& f, long rows, int C, int rps, OutT* o0, OutT* o1, hipStream_t st) {
+  ColGeom g = col_geom(rows, C, rps, PER_SAMPLE ? rps : rows);
+  dim3 grid(cdiv(PER_SAMPLE ? rps : rows, g.rows_per_block), cdiv(g.c4, g.tcols), PER_SAMPLE ? (int)(rows / rps) : 1);
+  hipLaunchKernelGGL((colreduce_kernel<F, NOUT, PER_SAMPLE, OutT>), grid, dim3(256), 0, st, f, g, o0, o1);
+}
+
+// ---------------------------------------------------------------------------
+// effective upstream gradient of a BN output, shared by the reduce and the apply pass:
+//   g = G[r,c]
+//   if rs   : g *= rs[n]                       (drop_connect scale of the sample, utils.py:90)
+//   if gate : g  = g * gate[n,c] + add[n,c]    (SE gate and the pooled-path gradient, model.py:82-84)
+//   if act  : g *= swish'(a[c] * X[r,c] + b[c])  (SiLU backward recomputed from the saved pre-BN tensor)
+// ---------------------------------------------------------------------------
+struct GEff {
+  const float* G; const float* X;
+  const float* rs; const float* gate; const float* add;
+  const float* a; const float* b;
+  int C, rps;
+  __device__ __forceinline__ void get(long r, int c, float4& g, float4& x) const {
+    g = ld4(G + r * C + c);
+    x = ld4(X + r * C + c);
+    const long n = r / rps;
+    if (rs) { float s = rs[n]; g.x *= s; g.y *= s; g.z *= s; g.w *= s; }
+    if (gate) {
+      float4 gt = ld4(gate + n * C + c), ad = ld4(add + n * C + c);
+      g.x = g.x * gt.x + ad.x; g.y = g.y * gt.y + ad.y; g.z = g.z * gt.z + ad.z; g.w = g.w * gt.w + ad.w;
+    }
+    if (a) {
+      float4 aa = ld4(a + c), bb = ld4(b + c);
+      g.x *= swish_gradf_(aa.x * x.x + bb.x); g.y *= swish_gradf_(aa.y * x.y + bb.y);
+      g.z *= swish_gradf_(aa.z * x.z + bb.z); g.w *= swish_gradf_(aa.w * x.w + bb.w);
+    }
+  }
+};
+
+struct FBwdReduce {      // sum g, sum g*x
+  GEff e;
+  __device__ __forceinline__ void eval(long r, int c, float4& s0, float4& s1) const {
+    float4 g, x;
+    e.get(r, c, g, x);
+    s0.x += g.x; s0.y += g.y; s0.z += g.z; s0.w += g.w;
+    s1.x += g.x * x.x; s1.y += g.y * x.y; s1.z += g.z * x.z; s1.w += g.w * x.w;
+  }
+};
+
+struct FStats {          // sum x, sum x^2
+  const float* X; int C;
+  __device__ __forceinline__ void eval(long r, int c, float4& s0, float4& s1) const {
+    float4 x = ld4(X + r * C + c);
+    s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
+    s1.x += x.x * x.x; s1.y += x.y * x.y; s1.z += x.z * x.z; s1.w += x.w * x.w;
+  }
+};
+
+struct FPool {           // per-sample: sum act(x) ; optionally sum g*act(x)
+  const float* X; const float* G; const float* a; const float* b; int C; int act;
+  __device__ __forceinline__ void eval(long r, int c, float4& s0, float4& s1) const {
+    float4 x = ld4(X + r * C + c);
+    if (a) {
+      float4 aa = ld4(a + c), bb = ld4(b + c);
+      x.x = aa.x * x.x + bb.x; x.y = aa.y * x.y + bb.y; x.z = aa.z * x.z + bb.z; x.w = aa.w * x.w + bb.w;
+    }
+    if (act) { x.x = swishf_(x.x); x.y = swishf_(x.y); x.z = swishf_(x.z); x.w = swishf_(x.w); }
+    if (G) {
+      float4 g = ld4(G + r * C + c);
+      x.x *= g.x; x.y *= g.y; x.z *= g.z; x.w *= g.w;
+    }
+    s0.x += x.x; s0.y += x.y; s0.z += x.z; s0.w += x.w;
+  }
+};
+
+// ---------------------------------------------------------------------------
+// per-channel finalisation kernels (tiny)
+// ---------------------------------------------------------------------------
+__global__ void bn_finalize_kernel(const double* stats, int C, double count, const float* gamma, const float* beta,
+                                   float* rmean, float* rvar, float momentum, float eps, int training,
+                                   float* scale, float* shift, float* mean_out, float* rstd_out) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float mean, rstd;
+  if (training) {
+    double m = stats[c] / count;
+    double var = stats[C + c] / count - m * m;
+    if (var < 0) var = 0;
+    mean = (float)m;
+    rstd = (float)(1.0 / sqrt(var + (double)eps));
+    // running stats: unbiased variance (torch.nn.functional.batch_norm)
+    double unb = count > 1 ? var * count / (count - 1) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  } else {
+    mean = rmean[c];
+    rstd = 1.0f / sqrtf(rvar[c] + eps);
+  }
+  float sc = gamma[c] * rstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - mean * sc;
+  mean_out[c] = mean;
+  rstd_out[c] = rstd;
+}
+
+__global__ void bn_bwd_finalize_kernel(const double* sums, int C, double count, const float* gamma, const float* mean,
+                                       const float* rstd, int training, float* dgamma, float* dbeta, float* c1,
+                                       float* c2, float* c3) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double sg = sums[c], sgx = sums[C + c];
+  double m = mean[c], r = rstd[c], gm = gamma[c];
+  double dg = r * (sgx - m * sg);
+  dgamma[c] += (float)dg;
+  dbeta[c] += (float)sg;
+  if (training) {
+    double k = gm * r * r * (dg / count);
+    c1[c] = (float)(gm * r);
+    c2[c] = (float)(-k);
+    c3[c] = (float)(-gm * r * (sg / count) + k * m);
+  } else {
+    c1[c] = (float)(gm * r);
+    c2[c] = 0.f;
+    c3[c] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// streaming elementwise kernels
+// ---------------------------------------------------------------------------
+// out = (sc[c]*P + sh[c]) [swish] [* rs[n]] [+ R]
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* P, const float* sc, const float* sh, const float* rs,
+                                                       const float* R, float* out, long total4, int C, int rps, int act) {
+  const int c4n = C / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    long r = i / c4n;
+    int c = (int)(i - r * c4n) * 4;
+    float4 v = ld4(P + i * 4);
+    float4 a = ld4(sc + c), b = ld4(sh + c);
+    v.x = a.x * v.x + b.x; v.y = a.y * v.y + b.y; v.z = a.z * v.z + b.z; v.w = a.w * v.w + b.w;
+    if (act) { v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w); }
+    if (rs) { float s = rs[r / rps]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+    if (R) { float4 q = ld4(R + i * 4); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+    st4(out + i * 4, v);
+  }
+}
+
+// out = c1[c]*g_eff + c2[c]*X + c3[c]   (BatchNorm backward, data gradient)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(GEff e, const float* c1, const float* c2, const float* c3,
+                                                           float* out, long total4) {
+  const int c4n = e.C / 4;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
+    long r = i / c4n;
+    int c = (int)(i - r * c4n) * 4;
+    float4 g, x;
+    e.get(r, c, g, x);
+    float4 k1 = ld4(c1 + c), k2 = ld4(c2 + c), k3 = ld4(c3 + c);
+    float4 o;
+    o.x = k1.x * g.x + k2.x * x.x + k3.x; o.y = k1.y * g.y + k2.y * x.y + k3.y;
+    o.z = k1.z * g.z + k2.z * x.z + k3.z; o.w = k1.w * g.w + k2.w * x.w + k3.w;
+    st4(out + i * 4, o);
+  }
+}
+
+static int grid_for(long total4) {
+  long b = (total4 + 255) / 256;
+  return (int)(b < 4096 ? (b < 1 ? 1 : b) : 4096);
+}
+
+extern "C" {
+
+int mx_colstats(const float* X, long rows, int C, double* stats, void* stream) {
+  MX_CHECK_ARG(X && stats && rows > 0 && C > 0 && C % 4 == 0, "colstats: bad args rows=%ld C=%d", rows, C);
+  FStats f{X, C};
+  launch_colreduce<FStats, 2, false, double>(f, rows, C, 1, stats, stats + C, (hipStream_t)stream);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta, float* running_mean,
+                   float* running_var, float momentum, float eps, int training, float* scale, float* shift,
+                   float* mean, float* rstd, void* stream) {
+  MX_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale && shift && mean && rstd,
+               "bn_finalize: null argument");
+  MX_CHECK_ARG(!training || (stats && count > 0), "bn_finalize: training needs stats and count");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, C, count, gamma,
+                     beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_bn_apply(const float* P, const float* scale, const float* shift, const float* row_scale, const float* residual,
+                float* out, long rows, int C, int rows_per_sample, int act, void* stream) {
+  MX_CHECK_ARG(P && scale && shift && out && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bn_apply: bad args");
+  long total4 = rows * (C / 4);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, P, scale, shift,
+                     row_scale, residual, out, total4, C, rows_per_sample, act);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// sums[2C] += (sum g_eff, sum g_eff * X)
+int mx_bn_bwd_reduce(const float* G, const float* X, const float* row_scale, const float* gate, const float* gate_add,
+                     const float* act_scale, const float* act_shift, long rows, int C, int rows_per_sample,
+                     double* sums, void* stream) {
+  MX_CHECK_ARG(G && X && sums && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bn_bwd_reduce: bad args");
+  MX_CHECK_ARG((gate == nullptr) == (gate_add == nullptr), "bn_bwd_reduce: gate and gate_add come together");
+  MX_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "bn_bwd_reduce: act scale/shift come together");
+  FBwdReduce f{GEff{G, X, row_scale, gate, gate_add, act_scale, act_shift, C, rows_per_sample}};
+  launch_colreduce<FBwdReduce, 2, false, double>(f, rows, C, rows_per_sample, sums, sums + C, (hipStream_t)stream);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_bn_bwd_finalize(const double* sums, int C, double count, const float* gamma, const float* mean, const float* rstd,
+                       int training, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream) {
+  MX_CHECK_ARG(sums && gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3 && C > 0 && count > 0,
+               "bn_bwd_finalize: bad args");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C, count, gamma,
+                     mean, rstd, training, dgamma, dbeta, c1, c2, c3);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_bn_bwd_apply(const float* G, const float* X, const float* row_scale, const float* gate, const float* gate_add,
+                    const float* act_scale, const float* act_shift, const float* c1, const float* c2, const float* c3,
+                    float* out, long rows, int C, int rows_per_sample, void* stream) {
+  MX_CHECK_ARG(G && X && out && c1 && c2 && c3 && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bn_bwd_apply: bad args");
+  GEff e{G, X, row_scale, gate, gate_add, act_scale, act_shift, C, rows_per_sample};
+  long total4 = rows * (C / 4);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, e, c1, c2, c3, out,
+                     total4);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// out[n,c] += sum_hw f(X[n,hw,c]) with f = [affine a,b] [swish] [* G]; used for the SE squeeze
+// (model.py:82), the global average pool of the head (MuSCLe.py:240) and their backward reductions.
+int mx_pool_sum(const float* X, const float* G, const float* scale, const float* shift, int act, long rows, int C,
+                int rows_per_sample, float* out, void* stream) {
+  MX_CHECK_ARG(X && out && rows > 0 && C % 4 == 0 && rows_per_sample > 0 && rows % rows_per_sample == 0,
+               "pool_sum: bad args rows=%ld C=%d rps=%d", rows, C, rows_per_sample);
+  FPool f{X, G, scale, shift, C, act};
+  launch_colreduce<FPool, 1, true, float>(f, rows, C, rows_per_sample, out, out, (hipStream_t)stream);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+}  // extern "C"

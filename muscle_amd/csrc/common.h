@@ -1,0 +1,88 @@
+// Shared device/host helpers for libmuscle_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MX_OK 0
+#define MX_EARG (-1)
+
+extern "C" const char* mx_last_error(void);
+void mx_set_error(const char* fmt, ...);
+
+#define MX_CHECK_ARG(cond, ...)            \
+  do {                                     \
+    if (!(cond)) {                         \
+      mx_set_error(__VA_ARGS__);           \
+      return MX_EARG;                      \
+    }                                      \
+  } while (0)
+
+#define MX_LAUNCH_CHECK()                                     \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) {                                  \
+      mx_set_error("launch failed: %s", hipGetErrorString(e__)); \
+      return (int)e__;                                        \
+    }                                                         \
+  } while (0)
+
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// device helpers
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
+// d/dx [x*sigmoid(x)] = s * (1 + x * (1 - s))   (src/efficientnet_pytorch/utils.py:44-47)
+__device__ __forceinline__ float swish_gradf_(float x) {
+  float s = sigmoidf_(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// Operand prologue descriptor used by the GEMM and elementwise kernels.
+// A "matrix" is [rows, cols] row-major fp32 with cols == channels (NHWC activations).
+//   mode 0 PLAIN : v = p[r,c]
+//   mode 1 BNACT : v = swish(c1[c]*p[r,c] + c2[c]) * (rowp ? rowp[(r/rps)*cols + c] : 1)
+//                  (BN scale/shift + SiLU + optional SE gate folded into the consumer's load)
+//   mode 2 AFFINE: v = c1[c]*p[r,c] + c2[c]
+struct MxOperand {
+  const float* p;
+  const float* c1;
+  const float* c2;
+  const float* rowp;
+  int mode;
+  int rps;  // rows per sample
+};
+enum { MX_PLAIN = 0, MX_BNACT = 1, MX_AFFINE = 2 };
+
+__device__ __forceinline__ float4 mx_apply(const MxOperand& o, float4 v, long r, int c, int cols) {
+  if (o.mode == MX_PLAIN) return v;
+  float4 a = ld4(o.c1 + c), b = ld4(o.c2 + c);
+  v.x = a.x * v.x + b.x; v.y = a.y * v.y + b.y; v.z = a.z * v.z + b.z; v.w = a.w * v.w + b.w;
+  if (o.mode == MX_AFFINE) return v;
+  v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w);
+  if (o.rowp) {
+    float4 g = ld4(o.rowp + (r / o.rps) * (long)cols + c);
+    v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w;
+  }
+  return v;
+}

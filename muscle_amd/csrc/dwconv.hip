@@ -1,0 +1,356 @@
+// Depthwise k x k convolution (k = 3/5, stride 1/2, static TF-"same" padding) for NHWC fp32
+// activations: forward, data gradient and weight gradient.
+//
+// Reference: MBConvBlock._depthwise_conv, src/efficientnet_pytorch/model.py:50-52,78 with
+// Conv2dStaticSamePadding (utils.py:122-145): zero padding (pad_lo before, pad_hi after) is applied
+// to the *activated* tensor, then a VALID convolution.  Weight layout [C,1,k,k].
+//
+// HBM-bound: every kernel stages one spatial tile x 32 channels in LDS (128 B per pixel, so global
+// loads are whole lines), applying the producer's BatchNorm affine + SiLU while staging
+// (MxOperand BNACT) so the activated tensor never exists in HBM.  Each thread produces OX
+// neighbouring outputs for 4 channels (float4) from LDS.  The forward epilogue accumulates the
+// per-channel sum / sum-of-squares that the following train-mode BatchNorm needs.
+#include "common.h"
+
+constexpr int CB = 32;       // channels per block
+constexpr int C4B = CB / 4;  // float4 groups per pixel
+
+struct DwArgs {
+  const float* x;      // fwd: input [N,H,W,C]; bwd_data: dY [N,Ho,Wo,C]; bwd_weight: input
+  const float* sc;     // BNACT prologue on x (null = plain)
+  const float* sh;
+  const float* w;      // [C,1,K,K]
+  const float* dy;     // bwd_weight: dY
+  const float* res;    // bwd_data: optional residual added to dX
+  float* y;            // fwd: Y; bwd_data: dX; bwd_weight: dW [C,1,K,K] (+=)
+  double* stats;       // fwd: [2C] or null
+  int N, H, W, Ho, Wo, C, pad;
+  int tiles_x, tiles_y;
+  int tiles_per_block;   // bwd_weight
+};
+
+__device__ __forceinline__ float4 dw_load(const DwArgs& a, const float* p, int c) {
+  float4 v = ld4(p);
+  if (a.sc) {
+    float4 s = ld4(a.sc + c), t = ld4(a.sh + c);
+    v.x = swishf_(s.x * v.x + t.x); v.y = swishf_(s.y * v.y + t.y);
+    v.z = swishf_(s.z * v.z + t.z); v.w = swishf_(s.w * v.w + t.w);
+  }
+  return v;
+}
+
+template <int K>
+__device__ __forceinline__ void dw_stage_weights(const DwArgs& a, float* wl, int c0, int tid) {
+  // wl[tap][CB]  <-  w[c][tap]
+  for (int i = tid; i < K * K * CB; i += 256) {
+    int cc = i % CB, tap = i / CB;
+    wl[i] = (c0 + cc < a.C) ? a.w[(long)(c0 + cc) * K * K + tap] : 0.f;
+  }
+}
+
+template <int K, int S, int TH, int TW>
+__device__ __forceinline__ void dw_stage_input(const DwArgs& a, float4* tile, int n, int oy0, int ox0, int c0, int tid) {
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+  for (int i = tid; i < IH * IW * C4B; i += 256) {
+    int c4 = i % C4B, pix = i / C4B;
+    int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+    int c = c0 + 4 * c4;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.C)
+      v = dw_load(a, a.x + (((long)n * a.H + iy) * a.W + ix) * a.C + c, c);
+    tile[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// forward
+// ---------------------------------------------------------------------------
+template <int K, int S, int TH, int TW, int OX>
+__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  static_assert(TH * (TW / OX) * C4B == 256, "thread mapping");
+  __shared__ float4 tile[IH * IW * C4B];
+  __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
+  __shared__ float red[2 * CB];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+  const int c0 = blockIdx.y * CB, n = blockIdx.z;
+  const int oy0 = ty * TH, ox0 = tx * TW;
+  dw_stage_weights<K>(a, wl, c0, tid);
+  dw_stage_input<K, S, TH, TW>(a, tile, n, oy0, ox0, c0, tid);
+  if (tid < 2 * CB) red[tid] = 0.f;
+  __syncthreads();
+
+  const int c4 = tid % C4B, q = tid / C4B;
+  const int oyl = q / (TW / OX), oxl = (q % (TW / OX)) * OX;
+  float4 acc[OX];
+#pragma unroll
+  for (int o = 0; o < OX; ++o) acc[o] = make_float4(0, 0, 0, 0);
+#pragma unroll
+  for (int ky = 0; ky < K; ++ky) {
+    float4 in[(OX - 1) * S + K];
+#pragma unroll
+    for (int j = 0; j < (OX - 1) * S + K; ++j) in[j] = tile[((oyl * S + ky) * IW + oxl * S + j) * C4B + c4];
+#pragma unroll
+    for (int kx = 0; kx < K; ++kx) {
+      float4 w = ld4(wl + (ky * K + kx) * CB + 4 * c4);
+#pragma unroll
+      for (int o = 0; o < OX; ++o) {
+        float4 v = in[o * S + kx];
+        acc[o].x += w.x * v.x; acc[o].y += w.y * v.y; acc[o].z += w.z * v.z; acc[o].w += w.w * v.w;
+      }
+    }
+  }
+  const int c = c0 + 4 * c4, oy = oy0 + oyl;
+  float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
+  if (c < a.C && oy < a.Ho) {
+#pragma unroll
+    for (int o = 0; o < OX; ++o) {
+      int ox = ox0 + oxl + o;
+      if (ox < a.Wo) {
+        st4(a.y + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + c, acc[o]);
+        s.x += acc[o].x; s.y += acc[o].y; s.z += acc[o].z; s.w += acc[o].w;
+        sq.x += acc[o].x * acc[o].x; sq.y += acc[o].y * acc[o].y; sq.z += acc[o].z * acc[o].z; sq.w += acc[o].w * acc[o].w;
+      }
+    }
+  }
+  if (a.stats) {
+    // lanes with equal c4 sit 8 apart: fold the wave first, then one LDS atomic per (wave, channel)
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
+      sq.x += __shfl_xor(sq.x, o, 64); sq.y += __shfl_xor(sq.y, o, 64); sq.z += __shfl_xor(sq.z, o, 64); sq.w += __shfl_xor(sq.w, o, 64);
+    }
+    if ((tid & 63) < C4B) {
+      atomicAdd(&red[4 * c4 + 0], s.x); atomicAdd(&red[4 * c4 + 1], s.y); atomicAdd(&red[4 * c4 + 2], s.z); atomicAdd(&red[4 * c4 + 3], s.w);
+      atomicAdd(&red[CB + 4 * c4 + 0], sq.x); atomicAdd(&red[CB + 4 * c4 + 1], sq.y);
+      atomicAdd(&red[CB + 4 * c4 + 2], sq.z); atomicAdd(&red[CB + 4 * c4 + 3], sq.w);
+    }
+    __syncthreads();
+    if (tid < CB && c0 + tid < a.C) {
+      unsafeAtomicAdd(a.stats + c0 + tid, (double)red[tid]);
+      unsafeAtomicAdd(a.stats + a.C + c0 + tid, (double)red[CB + tid]);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// data gradient: dX[n,iy,ix,c] = sum_{ky,kx} dY[n,oy,ox,c] * w[c,ky,kx],  oy*S - pad + ky == iy
+// tile over input pixels; dY staged with its halo.
+// ---------------------------------------------------------------------------
+template <int K, int S, int TH, int TW>
+__global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwArgs a) {
+  // output rows that can touch input rows [iy0, iy0+TH): oy in [ceil((iy0+pad-K+1)/S), floor((iy0+TH-1+pad)/S)]
+  constexpr int OH = (TH + K - 2) / S + 2, OW = (TW + K - 2) / S + 2;
+  static_assert(TH * TW * C4B == 256 * 4, "4 input pixels per thread");
+  __shared__ float4 tile[OH * OW * C4B];
+  __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
+  const int tid = threadIdx.x;
+  const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
+  const int c0 = blockIdx.y * CB, n = blockIdx.z;
+  const int iy0 = ty * TH, ix0 = tx * TW;
+  // floor division for possibly negative numerators
+  auto fdiv = [](int p, int q) { return (p >= 0) ? p / q : -((-p + q - 1) / q); };
+  const int oy_lo = fdiv(iy0 + a.pad - K + 1 + S - 1, S), ox_lo = fdiv(ix0 + a.pad - K + 1 + S - 1, S);
+  dw_stage_weights<K>(a, wl, c0, tid);
+  for (int i = tid; i < OH * OW * C4B; i += 256) {
+    int c4 = i % C4B, pix = i / C4B;
+    int oy = oy_lo + pix / OW, ox = ox_lo + pix % OW;
+    int c = c0 + 4 * c4;
+    float4 v = make_float4(0, 0, 0, 0);
+    if (oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo && c < a.C)
+      v = ld4(a.x + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + c);
+    tile[i] = v;
+  }
+  __syncthreads();
+  const int c4 = tid % C4B, q = tid / C4B;   // q in [0,32)
+  const int c = c0 + 4 * c4;
+#pragma unroll
+  for (int rep = 0; rep < 4; ++rep) {
+    const int p = q + 32 * rep;
+    const int iyl = p / TW, ixl = p % TW;
+    const int iy = iy0 + iyl, ix = ix0 + ixl;
+    float4 acc = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      const int ny = iy + a.pad - ky;
+      if (ny % S != 0 || ny < 0) continue;
+      const int oy = ny / S - oy_lo;
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        const int nx = ix + a.pad - kx;
+        if (nx % S != 0 || nx < 0) continue;
+        const int ox = nx / S - ox_lo;
+        // (oy, ox) is inside the staged tile by construction; out-of-range outputs were staged as 0
+        float4 w = ld4(wl + (ky * K + kx) * CB + 4 * c4);
+        float4 v = tile[(oy * OW + ox) * C4B + c4];
+        acc.x += w.x * v.x; acc.y += w.y * v.y; acc.z += w.z * v.z; acc.w += w.w * v.w;
+      }
+    }
+    if (c < a.C && iy < a.H && ix < a.W) {
+      const long o = (((long)n * a.H + iy) * a.W + ix) * a.C + c;
+      if (a.res) { float4 r = ld4(a.res + o); acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w; }
+      st4(a.y + o, acc);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// weight gradient: dW[c,ky,kx] += sum_{n,oy,ox} dY[n,oy,ox,c] * act(X)[n,oy*S-pad+ky,ox*S-pad+kx,c]
+// each block walks `tiles_per_block` (n, tile) pairs of one channel chunk with its partials in
+// registers, then leaves through LDS + one round of fp32 atomics.
+// ---------------------------------------------------------------------------
+template <int K, int S, int TH, int TW, int OX>
+__global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwArgs a) {
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  static_assert(TH * (TW / OX) * C4B == 256, "thread mapping");
+  __shared__ float4 tile[IH * IW * C4B];
+  __shared__ float red[K * K * CB];
+  const int tid = threadIdx.x;
+  const int c0 = blockIdx.y * CB;
+  const int c4 = tid % C4B, q = tid / C4B;
+  const int oyl = q / (TW / OX), oxl = (q % (TW / OX)) * OX;
+  const int c = c0 + 4 * c4;
+  float4 part[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) part[t] = make_float4(0, 0, 0, 0);
+  const long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
+  const long t_beg = (long)blockIdx.x * a.tiles_per_block;
+  const long t_end = min(ntiles, t_beg + a.tiles_per_block);
+  for (long t = t_beg; t < t_end; ++t) {
+    const int n = (int)(t / (a.tiles_x * a.tiles_y));
+    const int rem = (int)(t % (a.tiles_x * a.tiles_y));
+    const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
+    __syncthreads();
+    dw_stage_input<K, S, TH, TW>(a, tile, n, oy0, ox0, c0, tid);
+    __syncthreads();
+    const int oy = oy0 + oyl;
+    float4 g[OX];
+#pragma unroll
+    for (int o = 0; o < OX; ++o) {
+      int ox = ox0 + oxl + o;
+      g[o] = (c < a.C && oy < a.Ho && ox < a.Wo) ? ld4(a.dy + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + c)
+                                                  : make_float4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      float4 in[(OX - 1) * S + K];
+#pragma unroll
+      for (int j = 0; j < (OX - 1) * S + K; ++j) in[j] = tile[((oyl * S + ky) * IW + oxl * S + j) * C4B + c4];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+        for (int o = 0; o < OX; ++o) {
+          float4 v = in[o * S + kx];
+          float4& p = part[ky * K + kx];
+          p.x += g[o].x * v.x; p.y += g[o].y * v.y; p.z += g[o].z * v.z; p.w += g[o].w * v.w;
+        }
+      }
+    }
+  }
+  for (int i = tid; i < K * K * CB; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) {
+    float4 p = part[t];
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64); p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
+    }
+    if ((tid & 63) < C4B) {
+      atomicAdd(&red[t * CB + 4 * c4 + 0], p.x); atomicAdd(&red[t * CB + 4 * c4 + 1], p.y);
+      atomicAdd(&red[t * CB + 4 * c4 + 2], p.z); atomicAdd(&red[t * CB + 4 * c4 + 3], p.w);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < K * K * CB; i += 256) {
+    int cc = i % CB, tap = i / CB;
+    if (c0 + cc < a.C) unsafeAtomicAdd(a.y + (long)(c0 + cc) * K * K + tap, red[i]);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host
+// ---------------------------------------------------------------------------
+static int dw_check(const DwArgs& a, int K, int S, const char* who) {
+  MX_CHECK_ARG(K == 3 || K == 5, "%s: kernel %d unsupported (3 or 5)", who, K);
+  MX_CHECK_ARG(S == 1 || S == 2, "%s: stride %d unsupported (1 or 2)", who, S);
+  MX_CHECK_ARG(a.N > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C % 4 == 0, "%s: bad extents N=%d H=%d W=%d C=%d", who, a.N, a.H, a.W, a.C);
+  MX_CHECK_ARG(a.Ho > 0 && a.Wo > 0 && (a.Ho - 1) * S + K - a.pad <= a.H + K && a.pad >= 0 && a.pad < K,
+               "%s: inconsistent output size Ho=%d Wo=%d pad=%d", who, a.Ho, a.Wo, a.pad);
+  MX_CHECK_ARG((a.sc == nullptr) == (a.sh == nullptr), "%s: prologue scale/shift come together", who);
+  return MX_OK;
+}
+
+#define DW_DISPATCH(KERNEL_S1, KERNEL_S2, K, S, grid, st, a)                        \
+  do {                                                                              \
+    if (K == 3 && S == 1) hipLaunchKernelGGL((KERNEL_S1(3)), grid, dim3(256), 0, st, a); \
+    else if (K == 5 && S == 1) hipLaunchKernelGGL((KERNEL_S1(5)), grid, dim3(256), 0, st, a); \
+    else if (K == 3 && S == 2) hipLaunchKernelGGL((KERNEL_S2(3)), grid, dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((KERNEL_S2(5)), grid, dim3(256), 0, st, a);             \
+  } while (0)
+
+#define FWD_S1(k) dw_fwd_kernel<k, 1, 8, 16, 4>
+#define FWD_S2(k) dw_fwd_kernel<k, 2, 8, 8, 2>
+#define BWW_S1(k) dw_bwd_weight_kernel<k, 1, 8, 16, 4>
+#define BWW_S2(k) dw_bwd_weight_kernel<k, 2, 8, 8, 2>
+#define BWD_S1(k) dw_bwd_data_kernel<k, 1, 8, 16>
+#define BWD_S2(k) dw_bwd_data_kernel<k, 2, 8, 16>
+
+extern "C" {
+
+// Y = dwconv(act(X)); act = swish(scale*x+shift) if scale != null. stats[2C] += (sum Y, sum Y^2).
+int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, double* stats, int N,
+                  int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
+  DwArgs a{};
+  a.x = X; a.sc = scale; a.sh = shift; a.w = W; a.y = Y; a.stats = stats;
+  a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
+  MX_CHECK_ARG(X && W && Y, "dwconv_fwd: null pointer");
+  if (int e = dw_check(a, K, S, "dwconv_fwd")) return e;
+  const int TH = 8, TW = (S == 1) ? 16 : 8;
+  a.tiles_x = cdiv(Wo, TW); a.tiles_y = cdiv(Ho, TH);
+  dim3 grid(a.tiles_x * a.tiles_y, cdiv(C, CB), N);
+  DW_DISPATCH(FWD_S1, FWD_S2, K, S, grid, (hipStream_t)stream, a);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// dX = dwconv^T(dY) (+ residual).  dX is the gradient w.r.t. the *activated* input.
+int mx_dwconv_bwd_data(const float* dY, const float* W, const float* residual, float* dX, int N, int H, int Wd, int C,
+                       int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
+  DwArgs a{};
+  a.x = dY; a.w = W; a.res = residual; a.y = dX;
+  a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
+  MX_CHECK_ARG(dY && W && dX, "dwconv_bwd_data: null pointer");
+  if (int e = dw_check(a, K, S, "dwconv_bwd_data")) return e;
+  a.tiles_x = cdiv(Wd, 16); a.tiles_y = cdiv(H, 8);
+  dim3 grid(a.tiles_x * a.tiles_y, cdiv(C, CB), N);
+  DW_DISPATCH(BWD_S1, BWD_S2, K, S, grid, (hipStream_t)stream, a);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// dW[C,1,K,K] += sum dY * act(X)
+int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, int N, int H,
+                         int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
+  DwArgs a{};
+  a.x = X; a.sc = scale; a.sh = shift; a.dy = dY; a.y = dW;
+  a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
+  MX_CHECK_ARG(X && dY && dW, "dwconv_bwd_weight: null pointer");
+  if (int e = dw_check(a, K, S, "dwconv_bwd_weight")) return e;
+  const int TH = 8, TW = (S == 1) ? 16 : 8;
+  a.tiles_x = cdiv(Wo, TW); a.tiles_y = cdiv(Ho, TH);
+  long ntiles = (long)N * a.tiles_x * a.tiles_y;
+  int chunks = cdiv(C, CB);
+  long groups = 2048 / chunks;
+  if (groups < 1) groups = 1;
+  if (groups > ntiles) groups = ntiles;
+  a.tiles_per_block = (int)((ntiles + groups - 1) / groups);
+  dim3 grid(cdiv(ntiles, a.tiles_per_block), chunks, 1);
+  DW_DISPATCH(BWW_S1, BWW_S2, K, S, grid, (hipStream_t)stream, a);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+}  // extern "C"

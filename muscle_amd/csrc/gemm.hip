@@ -1,0 +1,359 @@
+// Exact-fp32 pointwise-convolution GEMMs on the CDNA4 matrix cores
+// (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain, 64 cycles / SIMD).
+//
+// One kernel template covers the three contractions the 1x1 convolutions of an MBConv block need
+// (reference: src/efficientnet_pytorch/model.py:77,86 forward; autograd's conv backward):
+//   NT : C[M,N]  = A'[M,K] * W[N,K]^T          forward   (W = conv weight [Cout,Cin])
+//   NN : C[M,N]  = A'[M,K] * W[K,N]            dgrad     (W = conv weight [Cout,Cin], K=Cout, N=Cin)
+//   TN : C[M,N] += A'[R,M]^T * B'[R,N]         wgrad     (reduction over the R pixel rows, split over blocks)
+// A' / B' are activation matrices [rows, channels] (NHWC) read through an MxOperand prologue, so the
+// BN affine + SiLU + SE gate of the *producer* is applied on the consumer's load and never
+// round-trips HBM.  Epilogue: optional bias / residual / relu, and per-column sum and sum of
+// squares (train-mode BatchNorm statistics of the conv output) accumulated in fp64.
+//
+// Tiling: 256 threads = 4 waves; each wave owns TM x TN MFMA tiles of 32x32; both operand tiles are
+// staged k-major in LDS (As[BK][BM+pad]) so the per-lane MFMA operand read is a conflict-free
+// ds_read_b32 of consecutive m (the 64-cycle fp32 MFMA leaves the LDS ~10 % busy, so wide reads buy
+// nothing here).  Global->register->LDS staging is double buffered with one barrier per K step.
+#include "common.h"
+#include <type_traits>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+  MxOperand a, b;
+  float* c;
+  int M, N, K;
+  int lda, ldb, ldc;
+  long sa, sb, sc;          // batch strides (elements)
+  const float* bias;        // [N] or null
+  const float* residual;    // [M, ldc] or null
+  int relu;
+  double* stats;            // [2*N] or null
+  int ksplit;               // TN: rows of R per z-slice
+};
+
+enum { L_NT = 0, L_NN = 1, L_TN = 2 };
+constexpr int BK = 16;
+
+// load a [rows x BK] slab of a row-major [R, ld] matrix (k contiguous) and store it k-major
+template <int ROWS, int PAD>
+struct SlabK {   // matrix is [rows_total, K] with k contiguous -> transposing store
+  static constexpr int TOTAL = ROWS * (BK / 4);
+  static constexpr int PER = (TOTAL + 255) / 256;
+  float4 v[PER];
+  __device__ __forceinline__ void load(const MxOperand& o, const float* base, int ld, int r0, int rows_total,
+                                       int k0, int K, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + 256 * i;
+      int k4 = idx & 3, row = idx >> 2;
+      int r = r0 + row, k = k0 + 4 * k4;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < TOTAL && r < rows_total && k < K) {
+        x = ld4(base + (long)r * ld + k);
+        x = mx_apply(o, x, r, k, K);
+      }
+      v[i] = x;
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + 256 * i;
+      int k4 = idx & 3, row = idx >> 2;
+      if (idx < TOTAL) {
+        float* p = lds + (4 * k4) * (ROWS + PAD) + row;
+        p[0] = v[i].x; p[ROWS + PAD] = v[i].y; p[2 * (ROWS + PAD)] = v[i].z; p[3 * (ROWS + PAD)] = v[i].w;
+      }
+    }
+  }
+};
+
+// load a [BK x COLS] slab of a row-major [Kdim, ld] matrix (cols contiguous) -> direct store
+template <int COLS, int PAD>
+struct SlabN {
+  static constexpr int C4 = COLS / 4;
+  static constexpr int TOTAL = BK * C4;
+  static constexpr int PER = (TOTAL + 255) / 256;
+  float4 v[PER];
+  __device__ __forceinline__ void load(const MxOperand& o, const float* base, int ld, int c0, int cols_total,
+                                       int k0, int Kdim, int tid) {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + 256 * i;
+      int c4 = idx % C4, kk = idx / C4;
+      int k = k0 + kk, c = c0 + 4 * c4;
+      float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < TOTAL && k < Kdim && c < cols_total) {
+        x = ld4(base + (long)k * ld + c);
+        x = mx_apply(o, x, k, c, cols_total);
+      }
+      v[i] = x;
+    }
+  }
+  __device__ __forceinline__ void store(float* lds, int tid) const {
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+      int idx = tid + 256 * i;
+      int c4 = idx % C4, kk = idx / C4;
+      if (idx < TOTAL) st4(lds + kk * (COLS + PAD) + 4 * c4, v[i]);
+    }
+  }
+};
+
+template <int LAYOUT, int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  constexpr int PADA = (LAYOUT == L_TN) ? 4 : 1;
+  constexpr int PADB = (LAYOUT == L_NT) ? 1 : 4;
+  constexpr int SA = BM + PADA, SB = BN + PADB;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * SA + 2 * BK * SB];
+  float* As = smem;
+  float* Bs = smem + 2 * BK * SA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  const int z = blockIdx.z;
+
+  const float* A = g.a.p;
+  const float* B = g.b.p;
+  float* C = g.c;
+  int kbeg = 0, kend = g.K;
+  if (LAYOUT == L_TN) {
+    kbeg = z * g.ksplit;
+    kend = min(g.K, kbeg + g.ksplit);
+  } else {
+    A += z * g.sa; B += z * g.sb; C += z * g.sc;
+  }
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  typename std::conditional<LAYOUT == L_TN, SlabN<BM, PADA>, SlabK<BM, PADA>>::type sa;
+  typename std::conditional<LAYOUT == L_NT, SlabK<BN, PADB>, SlabN<BN, PADB>>::type sb;
+
+  auto load = [&](int k0) {
+    if constexpr (LAYOUT == L_TN) sa.load(g.a, A, g.lda, m0, g.M, k0, kend, tid);
+    else sa.load(g.a, A, g.lda, m0, g.M, k0, kend, tid);
+    if constexpr (LAYOUT == L_NT) sb.load(g.b, B, g.ldb, n0, g.N, k0, kend, tid);
+    else sb.load(g.b, B, g.ldb, n0, g.N, k0, kend, tid);
+  };
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk > 0) {
+    load(kbeg);
+    sa.store(As, tid);
+    sb.store(Bs, tid);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) load(kbeg + (kt + 1) * BK);
+    const float* as = As + cur * BK * SA + wm * TM * 32 + l31;
+    const float* bs = Bs + cur * BK * SB + wn * TN * 32 + l31;
+    const int kleft = min(BK, kend - (kbeg + kt * BK));
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      if (kk < kleft) {
+        float av[TM], bv[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) av[i] = as[(kk + h) * SA + i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + h) * SB + j * 32];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kt + 1 < nk) {
+      sa.store(As + (cur ^ 1) * BK * SA, tid);
+      sb.store(Bs + (cur ^ 1) * BK * SB, tid);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue ------------------------------------------------------------------
+  float csum[TN], csq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * TN * 32 + j * 32 + l31;
+    const bool cok = col < g.N;
+    const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * TM * 32 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        if (cok && row < g.M) {
+          float v = acc[i][j][r];
+          const long idx = (long)row * g.ldc + col;
+          if (LAYOUT == L_TN) {
+            unsafeAtomicAdd(C + idx, v);
+          } else {
+            v += bias;
+            if (g.residual) v += g.residual[idx];
+            if (g.relu) v = fmaxf(v, 0.f);
+            C[idx] = v;
+            csum[j] += v;
+            csq[j] += v * v;
+          }
+        }
+      }
+    }
+  }
+  if (LAYOUT != L_TN && g.stats) {
+    __syncthreads();
+    float* red = smem;   // [2][BN]
+    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = csum[j] + __shfl_xor(csum[j], 32, 64);
+      float q = csq[j] + __shfl_xor(csq[j], 32, 64);
+      if (h == 0) {
+        atomicAdd(&red[wn * TN * 32 + j * 32 + l31], s);
+        atomicAdd(&red[BN + wn * TN * 32 + j * 32 + l31], q);
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < BN; i += 256) {
+      if (n0 + i < g.N) {
+        unsafeAtomicAdd(g.stats + n0 + i, (double)red[i]);
+        unsafeAtomicAdd(g.stats + g.N + n0 + i, (double)red[BN + i]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------
+template <int LAYOUT, int WM, int WN, int TM, int TN>
+static void launch(const GemmArgs& g, int batch_or_splits, hipStream_t st) {
+  constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+  dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), batch_or_splits);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
+}
+
+template <int LAYOUT>
+static void dispatch(const GemmArgs& g, int zdim, hipStream_t st) {
+  // choose the N tile with the least padding waste; ties -> wider tile
+  const int cands[5] = {128, 96, 64, 32, 192};
+  int best = 128;
+  long bestw = -1;
+  for (int i = 0; i < 4; ++i) {
+    long padded = (long)cdiv(g.N, cands[i]) * cands[i];
+    if (bestw < 0 || padded < bestw) { bestw = padded; best = cands[i]; }
+  }
+  switch (best) {
+    case 128: launch<LAYOUT, 2, 2, 2, 2>(g, zdim, st); break;   // 128 x 128
+    case 96:  launch<LAYOUT, 4, 1, 1, 3>(g, zdim, st); break;   // 128 x 96
+    case 64:  launch<LAYOUT, 4, 1, 2, 2>(g, zdim, st); break;   // 256 x 64
+    default:  launch<LAYOUT, 4, 1, 2, 1>(g, zdim, st); break;   // 256 x 32
+  }
+}
+
+static int check_operand(const MxOperand& o, const char* nm) {
+  MX_CHECK_ARG(o.p != nullptr, "gemm: operand %s is null", nm);
+  MX_CHECK_ARG(((uintptr_t)o.p & 15) == 0, "gemm: operand %s not 16-byte aligned", nm);
+  MX_CHECK_ARG(o.mode >= 0 && o.mode <= 2, "gemm: operand %s bad mode %d", nm, o.mode);
+  if (o.mode != MX_PLAIN) {
+    MX_CHECK_ARG(o.c1 && o.c2, "gemm: operand %s needs scale/shift", nm);
+    MX_CHECK_ARG(o.rps > 0, "gemm: operand %s rows_per_sample must be > 0", nm);
+  }
+  return MX_OK;
+}
+
+static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
+  if (int e = check_operand(g.a, "A")) return e;
+  if (int e = check_operand(g.b, "B")) return e;
+  MX_CHECK_ARG(g.c != nullptr, "gemm: C is null");
+  MX_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0, "gemm: bad extents M=%d N=%d K=%d", g.M, g.N, g.K);
+  MX_CHECK_ARG(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: leading dims must be multiples of 4 (lda=%d ldb=%d)", g.lda, g.ldb);
+  MX_CHECK_ARG(batch >= 1, "gemm: batch must be >= 1");
+  if (layout == L_NT) {
+    MX_CHECK_ARG(g.K % 4 == 0, "gemm NT: K=%d must be a multiple of 4", g.K);
+    dispatch<L_NT>(g, batch, st);
+  } else if (layout == L_NN) {
+    MX_CHECK_ARG(g.K % 4 == 0 && g.N % 4 == 0, "gemm NN: K=%d and N=%d must be multiples of 4", g.K, g.N);
+    dispatch<L_NN>(g, batch, st);
+  } else {
+    MX_CHECK_ARG(g.M % 4 == 0 && g.N % 4 == 0, "gemm TN: M=%d and N=%d must be multiples of 4", g.M, g.N);
+    MX_CHECK_ARG(batch == 1, "gemm TN: not batched");
+    // split the pixel reduction so the grid fills the chip (>= ~1024 blocks), >= 512 rows per split
+    long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    int splits = (int)((2048 + tiles - 1) / tiles);
+    int maxs = cdiv(g.K, 512);
+    if (splits > maxs) splits = maxs;
+    if (splits < 1) splits = 1;
+    int ks = cdiv(cdiv(g.K, splits), BK) * BK;
+    g.ksplit = ks;
+    splits = cdiv(g.K, ks);
+    dispatch<L_TN>(g, splits, st);
+  }
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+extern "C" {
+
+// C[M,N] = A'[M,K] * W[N,K]^T (+bias) (+residual) (relu); stats[2N] += column sum / sumsq.
+// A' = prologue(A; a_mode, a_scale, a_shift, a_gate, rows_per_sample).
+int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_shift, const float* a_gate,
+              int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,
+              const float* bias, const float* residual, int relu, double* stats, void* stream) {
+  GemmArgs g{};
+  g.a = MxOperand{A, a_scale, a_shift, a_gate, a_mode, rows_per_sample};
+  g.b = MxOperand{W, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.c = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = K; g.ldc = ldc;
+  g.bias = bias; g.residual = residual; g.relu = relu; g.stats = stats;
+  return gemm_common(L_NT, g, 1, (hipStream_t)stream);
+}
+
+// dX[M,N] = G[M,K] * W[K,N] (+residual): data gradient of a 1x1 conv whose weight is W[K=Cout, N=Cin].
+int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, int ldg, int ldx,
+                const float* residual, void* stream) {
+  GemmArgs g{};
+  g.a = MxOperand{G, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.b = MxOperand{W, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.c = dX; g.M = M; g.N = N; g.K = K; g.lda = ldg; g.ldb = N; g.ldc = ldx;
+  g.residual = residual;
+  return gemm_common(L_NN, g, 1, (hipStream_t)stream);
+}
+
+// dW[Co,Ci] += G[R,Co]^T * X'[R,Ci] (dW must be zeroed or hold a running sum; fp32 atomics).
+int mx_pw_wgrad(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
+                const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
+                void* stream) {
+  GemmArgs g{};
+  g.a = MxOperand{G, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.b = MxOperand{X, x_scale, x_shift, x_gate, x_mode, rows_per_sample};
+  g.c = dW; g.M = Co; g.N = Ci; g.K = R; g.lda = ldg; g.ldb = ldx; g.ldc = Ci;
+  return gemm_common(L_TN, g, 1, (hipStream_t)stream);
+}
+
+// Batched plain GEMMs for the PCM head (MuSCLe.py:213-223): layout 0 NT, 1 NN, 2 is not batched.
+int mx_bgemm(int layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
+             long sa, long sb, long sc, int batch, int relu, void* stream) {
+  MX_CHECK_ARG(layout == L_NT || layout == L_NN, "bgemm: layout must be 0 (NT) or 1 (NN)");
+  GemmArgs g{};
+  g.a = MxOperand{A, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.b = MxOperand{B, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.c = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+  g.sa = sa; g.sb = sb; g.sc = sc; g.relu = relu;
+  return gemm_common(layout, g, batch, (hipStream_t)stream);
+}
+
+}  // extern "C"

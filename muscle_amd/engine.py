@@ -1,0 +1,205 @@
+"""Forward / backward schedule of the EfficientNet MBConv chain on the HIP kernels.
+
+This is the host-side orchestration of the path the reference runs through autograd
+(src/efficientnet_pytorch/model.py:67-94 per block, :171-188 for the chain): it decides what is
+materialised in HBM and what is recomputed in a consumer's prologue.
+
+Per block, forward (NHWC, M = N*H*W rows in, M' rows out):
+    x --pw_fwd--> e_raw (+BN0 stats) --dwconv_fwd[BN0+SiLU on load]--> d_raw (+BN1 stats)
+      --pool_sum[BN1+SiLU on load]--> squeeze --se_fwd--> gate
+    d_raw --pw_fwd[BN1+SiLU+gate on load]--> p_raw (+BN2 stats) --bn_apply[+drop_connect, +skip]--> out
+Only e_raw, d_raw, p_raw and out ever exist in HBM (the activated tensors never do); they are also
+exactly what backward needs, so nothing else is saved.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .arch import BlockCfg, NetCfg
+from .ops import BNState
+
+
+@dataclass
+class BlockTape:
+    cfg: BlockCfg
+    H: int
+    W: int
+    Ho: int
+    Wo: int
+    x: torch.Tensor                       # block input [N,H,W,Cin] (materialised) or the stem's raw output for block 0
+    x_st: Optional[BNState]               # BN+SiLU still to be applied to x (block 0 only)
+    e_raw: Optional[torch.Tensor] = None
+    bn0: Optional[BNState] = None
+    d_raw: Optional[torch.Tensor] = None
+    bn1: Optional[BNState] = None
+    s: Optional[torch.Tensor] = None
+    h: Optional[torch.Tensor] = None
+    gate: Optional[torch.Tensor] = None
+    p_raw: Optional[torch.Tensor] = None
+    bn2: Optional[BNState] = None
+    row_scale: Optional[torch.Tensor] = None
+    out: Optional[torch.Tensor] = None
+
+
+@dataclass
+class Tape:
+    training: bool
+    N: int
+    cols: Optional[torch.Tensor] = None       # stem im2col [R,28]
+    stem_raw: Optional[torch.Tensor] = None   # [N,H0,W0,C0]
+    stem_bn: Optional[BNState] = None
+    H0: int = 0
+    W0: int = 0
+    blocks: List[BlockTape] = field(default_factory=list)
+
+
+def _blk(backbone, i):
+    return backbone._blocks[i]
+
+
+def stem_weight28(backbone):
+    w = backbone._conv_stem.weight
+    w28 = torch.zeros(w.shape[0], 28, dtype=torch.float32, device=w.device)
+    w28[:, :27] = w.reshape(w.shape[0], 27)
+    return w28
+
+
+def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
+                     drop_u: Optional[Dict[int, torch.Tensor]] = None) -> Tape:
+    """img: NCHW fp32 CUDA.  Returns the tape; block outputs are tape.blocks[i].out (NHWC)."""
+    N, _, H, W = img.shape
+    dev = img.device
+    tape = Tape(training=training, N=N)
+    lo, hi = cfg.stem_pad
+    H0, W0 = (H + lo + hi - 3) // 2 + 1, (W + lo + hi - 3) // 2 + 1
+    tape.H0, tape.W0 = H0, W0
+    # stem: im2col + MFMA GEMM (K = 27 padded to 28), BN statistics in the GEMM epilogue
+    tape.cols = ops.stem_im2col(img, H0, W0, lo)
+    C0 = cfg.stem_out
+    stats = ops.new_stats(C0, dev) if training else None
+    raw = ops.pw_fwd(tape.cols, stem_weight28(backbone), C0, stats=stats)
+    tape.stem_raw = raw.view(N, H0, W0, C0)
+    tape.stem_bn = ops.bn_finalize(stats, N * H0 * W0, backbone._bn0, training)
+
+    x, x_st, h, w = tape.stem_raw, tape.stem_bn, H0, W0
+    for b in cfg.blocks:
+        m = _blk(backbone, b.index)
+        ho, wo = b.out_size(h), b.out_size(w)
+        t = BlockTape(cfg=b, H=h, W=w, Ho=ho, Wo=wo, x=x, x_st=x_st)
+        M, Mo = N * h * w, N * ho * wo
+        if b.expand:
+            assert x_st is None
+            st0 = ops.new_stats(b.cexp, dev) if training else None
+            t.e_raw = ops.pw_fwd(x.view(M, b.cin), m._expand_conv.weight.view(b.cexp, b.cin), b.cexp, stats=st0)
+            t.e_raw = t.e_raw.view(N, h, w, b.cexp)
+            t.bn0 = ops.bn_finalize(st0, M, m._bn0, training)
+            dw_in, dw_st = t.e_raw, t.bn0
+        else:
+            dw_in, dw_st = x, x_st
+        st1 = ops.new_stats(b.cexp, dev) if training else None
+        t.d_raw = ops.dwconv_fwd(dw_in, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, ho, wo, st=dw_st, stats=st1)
+        t.bn1 = ops.bn_finalize(st1, Mo, m._bn1, training)
+        d2 = t.d_raw.view(Mo, b.cexp)
+        pooled = ops.pool_sum(d2, ho * wo, st=t.bn1, act=True)
+        t.s, t.h, t.gate = ops.se_fwd(pooled, 1.0 / (ho * wo), m._se_reduce.weight.view(b.se, b.cexp), m._se_reduce.bias,
+                                      m._se_expand.weight.view(b.cexp, b.se), m._se_expand.bias)
+        st2 = ops.new_stats(b.cout, dev) if training else None
+        t.p_raw = ops.pw_fwd(d2, m._project_conv.weight.view(b.cout, b.cexp), b.cout, a_mode=ops.BNACT,
+                             a_scale=t.bn1.scale, a_shift=t.bn1.shift, a_gate=t.gate, rows_per_sample=ho * wo, stats=st2)
+        t.bn2 = ops.bn_finalize(st2, Mo, m._bn2, training)
+        if b.skip and training and b.drop_rate:
+            keep = 1.0 - b.drop_rate
+            u = drop_u[b.index].to(dev, torch.float32) if drop_u is not None else torch.rand(N, device=dev)
+            t.row_scale = torch.floor(keep + u) / keep
+        res = None
+        if b.skip:
+            # the skip input is the activated block input; for the (never skipping) block 0 it would be raw
+            assert x_st is None
+            res = x.view(M, b.cin)
+        t.out = ops.bn_apply(t.p_raw, t.bn2, row_scale=t.row_scale, residual=res, rows_per_sample=ho * wo).view(N, ho, wo, b.cout)
+        tape.blocks.append(t)
+        x, x_st, h, w = t.out, None, ho, wo
+    return tape
+
+
+class GradSink:
+    """Where parameter gradients go: maps a parameter to its (accumulating) fp32 gradient buffer."""
+
+    def __init__(self):
+        self.bufs: Dict[int, torch.Tensor] = {}
+
+    def of(self, p: torch.nn.Parameter) -> torch.Tensor:
+        g = self.bufs.get(id(p))
+        if g is None:
+            g = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            self.bufs[id(p)] = g
+        return g
+
+
+def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, torch.Tensor], sink: GradSink):
+    """tap_grads: {block index: dL/d out [N,Ho,Wo,Cout]} for the tapped features.  Parameter gradients are
+    accumulated into `sink`.  The image gets no gradient (the reference never asks for one)."""
+    N, training = tape.N, tape.training
+    g_out: Optional[torch.Tensor] = None
+    for t in reversed(tape.blocks):
+        b, m = t.cfg, _blk(backbone, t.cfg.index)
+        tg = tap_grads.get(b.index)
+        if tg is not None:
+            g_out = tg if g_out is None else g_out + tg
+        if g_out is None:
+            continue                                   # blocks after the last tap get no gradient
+        M, Mo = N * t.H * t.W, N * t.Ho * t.Wo
+        hw = t.Ho * t.Wo
+        g2 = g_out.reshape(Mo, b.cout)
+        # BN2 backward (upstream gradient carries the drop_connect scale of the sample)
+        dp = ops.bn_backward(g2, t.p_raw, m._bn2, t.bn2, sink.of(m._bn2.weight), sink.of(m._bn2.bias), training,
+                             row_scale=t.row_scale, rows_per_sample=hw)
+        # project conv: weight gradient against the recomputed activated+gated input, then data gradient
+        d2 = t.d_raw.view(Mo, b.cexp)
+        ops.pw_wgrad(dp, d2, sink.of(m._project_conv.weight).view(b.cout, b.cexp), x_mode=ops.BNACT, x_scale=t.bn1.scale,
+                     x_shift=t.bn1.shift, x_gate=t.gate, rows_per_sample=hw)
+        ga = ops.pw_dgrad(dp, m._project_conv.weight.view(b.cout, b.cexp), b.cexp)          # dL/d(act*gate) [Mo,Cexp]
+        del dp
+        # SE: gate gradient = sum_hw ga * act ; excitation backward gives the pooled-path term
+        ggate = ops.pool_sum(d2, hw, G=ga, st=t.bn1, act=True)
+        add = ops.se_bwd(ggate, t.gate, t.s, t.h, m._se_reduce.weight.view(b.se, b.cexp), m._se_expand.weight.view(b.cexp, b.se),
+                         1.0 / hw, sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
+                         sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias))
+        # BN1 backward with g = (ga*gate + add) * swish'(bn1(d_raw)), in place over ga
+        dd = ops.bn_backward(ga, d2, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training, gate=t.gate,
+                             gate_add=add, act=t.bn1, rows_per_sample=hw, out=ga).view(N, t.Ho, t.Wo, b.cexp)
+        # depthwise
+        dw_in, dw_st = (t.e_raw, t.bn0) if b.expand else (t.x, t.x_st)
+        ops.dwconv_bwd_weight(dw_in, dd, sink.of(m._depthwise_conv.weight), b.kernel, b.stride, b.pad_lo, st=dw_st)
+        skip_res = g_out if b.skip else None            # d out / d x through the identity branch
+        if b.expand:
+            ge = ops.dwconv_bwd_data(dd, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, t.H, t.W)
+            del dd, ga
+            e2 = t.e_raw.view(M, b.cexp)
+            ge2 = ge.view(M, b.cexp)
+            de = ops.bn_backward(ge2, e2, m._bn0, t.bn0, sink.of(m._bn0.weight), sink.of(m._bn0.bias), training, act=t.bn0,
+                                 out=ge2)
+            ops.pw_wgrad(de, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
+            g_in = ops.pw_dgrad(de, m._expand_conv.weight.view(b.cexp, b.cin), b.cin,
+                                residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)
+            g_out = g_in.view(N, t.H, t.W, b.cin)
+        else:
+            gx = ops.dwconv_bwd_data(dd, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, t.H, t.W,
+                                     residual=skip_res)
+            if t.x_st is not None:
+                # block 0: x is the stem's raw output, still behind BN0 + SiLU -> stem backward
+                s2 = tape.stem_raw.view(M, b.cin)
+                gx2 = gx.view(M, b.cin)
+                ds = ops.bn_backward(gx2, s2, backbone._bn0, tape.stem_bn, sink.of(backbone._bn0.weight),
+                                     sink.of(backbone._bn0.bias), training, act=tape.stem_bn, out=gx2)
+                dw28 = torch.zeros(cfg.stem_out, 28, dtype=torch.float32, device=ds.device)
+                ops.pw_wgrad(ds, tape.cols, dw28)
+                sink.of(backbone._conv_stem.weight).view(cfg.stem_out, 27).add_(dw28[:, :27])
+                g_out = None
+            else:
+                g_out = gx
+    return

@@ -1,0 +1,177 @@
+"""Thin tensor-level wrappers over the C ABI (include/muscle_hip.h).
+
+Every function takes contiguous CUDA fp32 tensors in the library's NHWC / [rows, C] convention,
+allocates outputs with torch (device memory is torch's job, arithmetic is the library's) and
+enqueues on torch's current stream.
+"""
+from __future__ import annotations
+
+from typing import NamedTuple, Optional
+
+import torch
+
+from ._lib import call, ptr, stream
+
+PLAIN, BNACT, AFFINE = 0, 1, 2
+
+
+class BNState(NamedTuple):
+    scale: torch.Tensor
+    shift: torch.Tensor
+    mean: torch.Tensor
+    rstd: torch.Tensor
+
+
+def _f32(*shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device)
+
+
+# ---- GEMMs ------------------------------------------------------------------------------------
+def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None, rows_per_sample=1,
+           bias=None, residual=None, relu=False, stats=None, out=None, ldc=None):
+    """A: [M, K]; W: [N_out, K] -> [M, N_out]."""
+    M, K = A.shape
+    ldc = ldc or N_out
+    if out is None:
+        out = _f32(M, ldc, device=A.device)
+    call("mx_pw_fwd", ptr(A), a_mode, ptr(a_scale), ptr(a_shift), ptr(a_gate), rows_per_sample, ptr(W), ptr(out),
+         M, K, N_out, A.stride(0), ldc, ptr(bias), ptr(residual), int(relu), ptr(stats), stream())
+    return out
+
+
+def pw_dgrad(G, W, N_in, *, residual=None, out=None):
+    """G: [M, K=Cout]; W: [Cout, Cin] -> dX [M, Cin]."""
+    M, K = G.shape
+    if out is None:
+        out = _f32(M, N_in, device=G.device)
+    call("mx_pw_dgrad", ptr(G), ptr(W), ptr(out), M, K, N_in, G.stride(0), N_in, ptr(residual), stream())
+    return out
+
+
+def pw_wgrad(G, X, dW, *, x_mode=PLAIN, x_scale=None, x_shift=None, x_gate=None, rows_per_sample=1):
+    """dW[Co, Ci] += G[R, Co]^T X'[R, Ci]."""
+    R, Co = G.shape
+    Ci = X.shape[1]
+    call("mx_pw_wgrad", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),
+         R, Co, Ci, G.stride(0), X.stride(0), stream())
+
+
+def bgemm(layout, A, B, *, relu=False, out=None):
+    """Batched plain GEMM.  layout 0: C = A B^T with B [b, N, K]; layout 1: C = A B with B [b, K, N]."""
+    b, M, K = A.shape
+    N = B.shape[1] if layout == 0 else B.shape[2]
+    if out is None:
+        out = _f32(b, M, N, device=A.device)
+    call("mx_bgemm", layout, ptr(A), ptr(B), ptr(out), M, N, K, A.stride(1), B.stride(1), N,
+         A.stride(0), B.stride(0), M * N, b, int(relu), stream())
+    return out
+
+
+# ---- BatchNorm / elementwise ---------------------------------------------------------------------
+def new_stats(C, device):
+    return torch.zeros(2 * C, dtype=torch.float64, device=device)
+
+
+def colstats(X2d, stats):
+    call("mx_colstats", ptr(X2d), X2d.shape[0], X2d.shape[1], ptr(stats), stream())
+
+
+def bn_finalize(stats, count, bn: torch.nn.BatchNorm2d, training: bool) -> BNState:
+    C = bn.num_features
+    dev = bn.weight.device
+    buf = _f32(4, C, device=dev)
+    mom = 0.0 if bn.momentum is None else float(bn.momentum)
+    call("mx_bn_finalize", ptr(stats), C, float(count), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+         ptr(bn.running_var), mom, float(bn.eps), int(training), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]),
+         stream())
+    if training:
+        bn.num_batches_tracked += 1
+    return BNState(buf[0], buf[1], buf[2], buf[3])
+
+
+def bn_apply(P2d, st: BNState, *, row_scale=None, residual=None, rows_per_sample=1, act=False, out=None):
+    rows, C = P2d.shape
+    if out is None:
+        out = torch.empty_like(P2d)
+    call("mx_bn_apply", ptr(P2d), ptr(st.scale), ptr(st.shift), ptr(row_scale), ptr(residual), ptr(out), rows, C,
+         rows_per_sample, int(act), stream())
+    return out
+
+
+def bn_backward(G2d, X2d, bn: torch.nn.BatchNorm2d, st: BNState, dgamma, dbeta, training: bool, *, row_scale=None,
+                gate=None, gate_add=None, act: Optional[BNState] = None, rows_per_sample=1, out=None):
+    """Full BatchNorm backward of y = BN(X) given the (lazily composed) upstream gradient; returns dX.
+    `act` is the BNState whose affine feeds a SiLU that sits between this BN's output and G (i.e. the
+    same BN: G is d/d swish(BN(X))), so the SiLU derivative is recomputed from X."""
+    rows, C = X2d.shape
+    sums = new_stats(C, X2d.device)
+    a_sc = act.scale if act is not None else None
+    a_sh = act.shift if act is not None else None
+    call("mx_bn_bwd_reduce", ptr(G2d), ptr(X2d), ptr(row_scale), ptr(gate), ptr(gate_add), ptr(a_sc), ptr(a_sh), rows, C,
+         rows_per_sample, ptr(sums), stream())
+    c = _f32(3, C, device=X2d.device)
+    call("mx_bn_bwd_finalize", ptr(sums), C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
+         ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]), stream())
+    if out is None:
+        out = torch.empty_like(X2d)
+    call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), ptr(row_scale), ptr(gate), ptr(gate_add), ptr(a_sc), ptr(a_sh),
+         ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(out), rows, C, rows_per_sample, stream())
+    return out
+
+
+def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=False):
+    rows, C = X2d.shape
+    out = torch.zeros(rows // rows_per_sample, C, dtype=torch.float32, device=X2d.device)
+    call("mx_pool_sum", ptr(X2d), ptr(G), ptr(st.scale) if st else None, ptr(st.shift) if st else None, int(act), rows, C,
+         rows_per_sample, ptr(out), stream())
+    return out
+
+
+# ---- depthwise ------------------------------------------------------------------------------------
+def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, stats=None):
+    N, H, Wd, C = X.shape
+    Y = _f32(N, Ho, Wo, C, device=X.device)
+    call("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),
+         N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
+    return Y
+
+
+def dwconv_bwd_data(dY, W, K, S, pad_lo, H, Wd, *, residual=None):
+    N, Ho, Wo, C = dY.shape
+    dX = _f32(N, H, Wd, C, device=dY.device)
+    call("mx_dwconv_bwd_data", ptr(dY), ptr(W), ptr(residual), ptr(dX), N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
+    return dX
+
+
+def dwconv_bwd_weight(X, dY, dW, K, S, pad_lo, *, st: Optional[BNState] = None):
+    N, H, Wd, C = X.shape
+    _, Ho, Wo, _ = dY.shape
+    call("mx_dwconv_bwd_weight", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(dY), ptr(dW),
+         N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
+
+
+# ---- SE / stem ------------------------------------------------------------------------------------
+def se_fwd(pooled, inv_hw, W1, b1, W2, b2):
+    N, C = pooled.shape
+    SQ = W1.shape[0]
+    s, gate = torch.empty_like(pooled), torch.empty_like(pooled)
+    h = _f32(N, SQ, device=pooled.device)
+    call("mx_se_fwd", ptr(pooled), float(inv_hw), ptr(W1), ptr(b1), ptr(W2), ptr(b2), ptr(s), ptr(h), ptr(gate), N, C, SQ,
+         stream())
+    return s, h, gate
+
+
+def se_bwd(ggate, gate, s, h, W1, W2, inv_hw, dW1, db1, dW2, db2):
+    N, C = ggate.shape
+    SQ = W1.shape[0]
+    add = torch.empty_like(ggate)
+    call("mx_se_bwd", ptr(ggate), ptr(gate), ptr(s), ptr(h), ptr(W1), ptr(W2), float(inv_hw), ptr(add), ptr(dW1), ptr(db1),
+         ptr(dW2), ptr(db2), N, C, SQ, stream())
+    return add
+
+
+def stem_im2col(img, Ho, Wo, pad_lo):
+    N, _, H, W = img.shape
+    out = _f32(N * Ho * Wo, 28, device=img.device)
+    call("mx_stem_im2col", ptr(img), ptr(out), N, H, W, Ho, Wo, pad_lo, stream())
+    return out

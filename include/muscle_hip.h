@@ -113,6 +113,65 @@ int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float
 /* out[(n,oy,ox), ci*9+ky*3+kx] = img[n,ci,oy*2-pad+ky,ox*2-pad+kx] (NCHW image), rows of 28 floats (27 + 0) */
 int mx_stem_im2col(const float* img, float* out, int N, int H, int W, int Ho, int Wo, int pad_lo, void* stream);
 
+/* ---- CAM head + PCM support: MuSCLe.py:213-223,237-279 ---------------------------------------------------- */
+
+/* dst[n,y,x,coff+c] = [relu] bilinear_align_corners(src[n,:,:,c]); NHWC -> channel slice of an NHWC tensor of width ldd */
+int mx_resize_nhwc(const float* src, float* dst, int N, int Hs, int Ws, int C, int Hd, int Wd, int ldd, int coff, int relu,
+                   void* stream);
+
+/* dst[n,k,Y,X] (NCHW) = bilinear_align_corners(src[n,:,:,k]); src NHWC with leading dimension lds (MuSCLe.py:256-257) */
+int mx_upsample_to_nchw(const float* src, float* dst, int N, int Hs, int Ws, int lds, int K, int Hd, int Wd, void* stream);
+
+/* adjoint of mx_upsample_to_nchw: gsrc (=|+=) W^T gdst */
+int mx_upsample_to_nchw_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int lds, int K, int Hd, int Wd,
+                            int accumulate, void* stream);
+
+/* y = x / (||x||_2 + eps) per row, nrm saved (MuSCLe.py:218) and its backward */
+int mx_row_l2norm(const float* x, float* y, float* nrm, long R, int C, float eps, void* stream);
+int mx_row_l2norm_bwd(const float* x, const float* nrm, const float* gy, float* gx, long R, int C, float eps, void* stream);
+
+/* PCM tail on T = aff * [cam | 1]: fwd rv = T[:, :K] / (T[:, K] + eps) (MuSCLe.py:221-222); bwd gives dL/dT */
+int mx_pcm_norm(const float* T, const float* grv, float* out, long rows, int L, int K, float eps, int bwd, void* stream);
+
+/* out[b,i,j] = (gaff[b,i,j] + gaff[b,j,i]) * (aff[b,i,j] > 0): gradient through relu(f^T f) (MuSCLe.py:220);
+ * matrices are [b, n, ld] with ld >= n (padding columns -> 0) */
+int mx_sym_relu_grad(const float* gaff, const float* aff, float* out, int B, int n, int ld, void* stream);
+
+/* flat elementwise: op 0 out = alpha*a; op 1 out = a + alpha*b; op 2 out = (y > 0) ? a (+ b) : 0 */
+int mx_ew(int op, const float* a, const float* b, const float* y, float alpha, float* out, long n, void* stream);
+
+/* X[n,hw,c] += alpha * v[n,c] (backward of the global average pool, MuSCLe.py:240) */
+int mx_bcast_add(float* X, const float* v, float alpha, long rows, int C, int rows_per_sample, void* stream);
+
+/* ---- losses of the MCL step and the optimiser ---------------------------------------------------------------- */
+
+/* [N,C] classification losses with d loss / d input for unit upstream gradient:
+ * mode 0 focal(p,y) gamma 2 alpha .5 (loss_multilabel.py:68-91) -> loss[0] += ; 1 MultiLabelSoftMargin(x,y)
+ * (train_mcl.py:146) -> loss[0] += ; 2 Log_Sum_Exp_Pairwise(p,y) (loss_multilabel.py:24-33) -> loss[n];
+ * 3 grad = sigmoid(x); 4 grad = y * x * (1 - x) (sigmoid backward, x = sigmoid output, y = upstream) */
+int mx_cls_loss(int mode, const float* x, int ldx, const float* y, int ldy, float* loss, float* grad, int ldg, int N, int C,
+                void* stream);
+
+/* image_level_contrast (loss_multilabel.py:36-66): out2 = {loss, #valid anchor rows}; gemb = d loss / d emb;
+ * workspace: N*D + N floats.  N <= 64, D <= 1024. */
+int mx_imc(const float* emb, const float* label, int N, int D, int L, float* out2, float* gemb, float* workspace, void* stream);
+
+/* cam_softmaxnorm (train_mcl.py:30-36) on NCHW [N,K,HW]; bwd != 0: out = d/dx given gy */
+int mx_softmaxnorm(const float* x, const float* gy, float* out, int N, int K, long HW, int bwd, void* stream);
+
+/* ER loss (train_mcl.py:185-188): mean over rows of the top-k of |softmaxnorm(cams)-softmaxnorm(sgcs)|*lwb, exact
+ * 3-pass radix select.  d [N*K*HW] scratch; krem/prefix/sum_gt/cnt_eq [N] and hcnt/hsum [N*2048] state
+ * (prefix and sum_gt zeroed by the caller) are kept for mx_er_bwd. */
+int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int K, long HW, long k, float* d, unsigned* krem,
+              unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss, void* stream);
+/* gsgcs = d loss / d raw_sgcs * gscale * (gup ? gup[0] : 1): gup is the upstream gradient as a device scalar */
+int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsigned* prefix, const unsigned* krem,
+              const unsigned* cnt_eq, const float* gup, float gscale, float* gsgcs, int N, int K, long HW, void* stream);
+
+/* torch.optim.Adam(weight_decay) update on flat arrays (train_mcl.py:134,199,229) */
+int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+            float weight_decay, float bias_corr1, float sqrt_bias_corr2, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

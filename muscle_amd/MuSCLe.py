@@ -1,0 +1,248 @@
+"""MuSCLe model (CAM encoder mode) — drop-in for the reference's `src.MuSCLe.MuSCLe`.
+
+Same constructor, same `forward(x, cam=...)` return tuples, same `state_dict()` keys
+(src/MuSCLe.py:156-298); the computation is the HIP path of muscle_amd.engine
+(backbone) plus the head below.  Differences a caller can see:
+  * the constructor never downloads weights (`weights=` takes a state-dict path instead of the
+    reference's unconditional `EfficientNet.from_pretrained`, src/MuSCLe.py:165);
+  * EfficientNet-B0 is accepted (taps by the same last-block-of-stage rule);
+  * it only runs on a ROCm GPU: on CPU tensors forward() raises (there is no fallback path);
+  * parameter gradients are written to `p.grad` by the module's own backward (they are views of
+    one flat fp32 arena, which is what the DP all-reduce and the fused Adam consume).
+`mode='dec'` (BiFPN decoder of train_muscle.py) is not built yet.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import engine, ops
+from ._lib import MuscleHipError
+from .arch import net_cfg
+from .efficientnet import EfficientNet
+
+_CPAD = 24      # class dimension (21) padded to a multiple of 4 for 16-byte rows
+
+
+class _HeadTape:
+    __slots__ = ("emb", "cam", "fs", "f", "fn", "nrm", "aff", "T", "hw", "hwp", "h", "w", "H", "W", "fcw", "mode")
+
+
+class _ArenaSink(engine.GradSink):
+    """Gradient sink whose buffers are consecutive views of one flat, zero-filled fp32 arena."""
+
+    def __init__(self, params: List[nn.Parameter]):
+        super().__init__()
+        total = sum((p.numel() + 3) // 4 * 4 for p in params)
+        self.arena = torch.zeros(total, dtype=torch.float32, device=params[0].device)
+        self.params = params
+        off = 0
+        for p in params:
+            self.bufs[id(p)] = self.arena[off:off + p.numel()].view(p.shape)
+            off += (p.numel() + 3) // 4 * 4
+
+    def of(self, p):
+        return self.bufs[id(p)]
+
+
+class _Forward(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, anchor, model, mode, drop_u):
+        need_grad = ctx.needs_input_grad[1]      # False under torch.no_grad(): nothing is kept then
+        outs, tape, head = model._run_forward(x, mode, drop_u)
+        if need_grad:
+            ctx.model, ctx.tape, ctx.head, ctx.mode = model, tape, head, mode
+        ctx.set_materialize_grads(False)      # unused outputs arrive as None instead of full-size zeros
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        model, tape, head, mode = ctx.model, ctx.tape, ctx.head, ctx.mode
+        ctx.tape = ctx.head = None
+        model._run_backward(tape, head, mode, gouts)
+        return None, None, None, None, None
+
+
+class MuSCLe(nn.Module):
+    def __init__(self, num_classes, pretrained="efficientnet-b1", layers=1, MemoryEfficient=True, bifpn_channels=256,
+                 last_pooling=True, mode="enc", weights: Optional[str] = None):
+        super().__init__()
+        self.classes = num_classes
+        if num_classes > _CPAD - 1:
+            raise ValueError(f"num_classes <= {_CPAD - 1} supported")
+        self.cfg = net_cfg(pretrained, last_pooling)
+        self.backbone = EfficientNet(self.cfg, num_classes)
+        tc = self.cfg.tap_channels
+        (self.p1_seq, self.p2_seq, self.p3_seq, self.p4_seq, self.p5_seq, self.p6_seq, self.p7_seq) = self.cfg.taps
+        self.mode = mode
+        if mode == "enc":
+            self.fuse = nn.Conv2d(tc[0] + tc[2] + tc[4], 128, 1, bias=True)
+            self.pool = nn.AdaptiveAvgPool2d((1, 1))
+            self.fc = nn.Linear(tc[6], num_classes, bias=False)
+        else:
+            raise NotImplementedError("mode='dec' (BiFPN decoder, src/MuSCLe.py:115-148) is not built yet")
+        self.fuse_dec = nn.Conv2d(bifpn_channels, num_classes, 1)
+        self.logits = None
+        self._anchor = torch.zeros(1, requires_grad=True)      # makes autograd call our backward; not a parameter
+        self.last_grad_sink: Optional[_ArenaSink] = None
+        if weights is not None:
+            sd = torch.load(weights, map_location="cpu")
+            self.load_state_dict(sd.get("state_dict", sd), strict=False)
+
+    # ---- which parameters receive gradients (SURVEY.md §7 "DDP with unused parameters") ----------
+    def live_parameters(self, cam_mode: str = "cam") -> List[nn.Parameter]:
+        ps: List[nn.Parameter] = [self.backbone._conv_stem.weight, self.backbone._bn0.weight, self.backbone._bn0.bias]
+        last = self.cfg.taps[6]
+        for blk in self.backbone._blocks[:last + 1]:
+            ps += list(blk.parameters())
+        ps += [self.fuse.weight, self.fuse.bias]
+        if cam_mode in ("cam", "logits"):
+            ps.append(self.fc.weight)
+        if cam_mode == "logits":
+            ps = [p for p in ps if p is not self.fuse.weight and p is not self.fuse.bias]
+        return ps
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward(self, x, cam="cam", drop_u: Optional[Dict[int, torch.Tensor]] = None):
+        if cam not in ("logits", "cam", "pix"):
+            raise NotImplementedError(f"forward(cam={cam!r}) needs the BiFPN decoder (mode='dec'), not built yet")
+        if not x.is_cuda:
+            raise MuscleHipError("MuSCLe.forward runs on the HIP kernels only: move the model and input to a ROCm GPU")
+        x = x.contiguous().float()
+        outs = _Forward.apply(x, self._anchor, self, cam, drop_u)
+        if cam == "logits":
+            self.logits = outs[1]
+            return outs[0], outs[1]
+        if cam == "cam":
+            self.logits = outs[3]
+            return outs[0], outs[1], outs[2], outs[3]
+        return outs[0], outs[1]
+
+    def _run_forward(self, x, mode, drop_u):
+        cfg, K = self.cfg, self.classes
+        N, _, H, W = x.shape
+        dev = x.device
+        tape = engine.backbone_forward(self.backbone, cfg, x, self.training, drop_u)
+        t = cfg.taps
+        p1, p3, p5, p7 = (tape.blocks[i].out for i in (t[0], t[2], t[4], t[6]))
+        _, h, w, C7 = p7.shape
+        hw, M7 = h * w, N * h * w
+        ht = _HeadTape()
+        ht.h, ht.w, ht.hw, ht.hwp, ht.H, ht.W, ht.mode = h, w, hw, (hw + 3) // 4 * 4, H, W, mode
+        fcw = torch.zeros(_CPAD, C7, dtype=torch.float32, device=dev)
+        fcw[:K] = self.fc.weight.detach()
+        ht.fcw = fcw
+        p7m = p7.view(M7, C7)
+        emb = logits = None
+        if mode in ("cam", "logits"):
+            emb = ops.ew(0, ops.pool_sum(p7m, hw), alpha=1.0 / hw)                      # GAP, MuSCLe.py:240
+            logits = ops.pw_fwd(emb, fcw, K)                                             # fc (no bias), :241
+            ht.emb = emb
+            if mode == "logits":
+                return (emb, logits), tape, ht
+        # CAM = relu(1x1 conv of p7 with the detached fc weight), :243-247.  Column K of the padded class
+        # dimension is forced to 1 through the bias so that aff @ [cam|1] also yields the affinity row sums.
+        one = torch.zeros(_CPAD, dtype=torch.float32, device=dev)
+        one[K] = 1.0
+        cam = torch.zeros(M7 + 4, _CPAD, dtype=torch.float32, device=dev)               # +4 rows: padded-K reads
+        ops.pw_fwd(p7m, fcw, _CPAD, bias=one, relu=True, out=cam, ldc=_CPAD)
+        ht.cam = cam
+        # fs = cat(relu(resize(p1)), relu(resize(p3)), relu(p5)) under no_grad, :248-252
+        c1, c3, c5 = p1.shape[3], p3.shape[3], p5.shape[3]
+        fs = torch.empty(N, h, w, c1 + c3 + c5, dtype=torch.float32, device=dev)
+        ops.resize_nhwc(p1, fs, 0)
+        ops.resize_nhwc(p3, fs, c1)
+        ops.resize_nhwc(p5, fs, c1 + c3)
+        ht.fs = fs
+        # PCM, :213-223
+        Cf = c1 + c3 + c5
+        f = ops.pw_fwd(fs.view(M7, Cf), self.fuse.weight.view(128, Cf), 128, bias=self.fuse.bias)
+        fnb = torch.zeros(M7 + 4, 128, dtype=torch.float32, device=dev)
+        fn = fnb[:M7]
+        nrm = torch.empty(M7, dtype=torch.float32, device=dev)
+        ops.call("mx_row_l2norm", ops.ptr(f), ops.ptr(fn), ops.ptr(nrm), M7, 128, 1e-5, ops.stream())
+        ht.f, ht.fn, ht.nrm = f, fnb, nrm
+        aff = torch.zeros(N, hw, ht.hwp, dtype=torch.float32, device=dev)
+        fn3 = fn.view(N, hw, 128)
+        ops.bgemm(0, fn3, fn3, aff, hw, hw, 128, relu=True)                               # relu(f^T f)
+        T = torch.empty(N, hw, _CPAD, dtype=torch.float32, device=dev)
+        ops.bgemm(1, aff, cam[:M7].view(N, hw, _CPAD), T, hw, _CPAD, ht.hwp)              # aff @ [cam | 1]
+        ht.aff, ht.T = aff, T
+        rv = ops.pcm_norm(T, torch.empty_like(T), K, 1e-5)                                # column-normalised aff applied
+        cams = ops.upsample_to_nchw(cam[:M7].view(N, h, w, _CPAD), K, H, W)               # :256
+        sgc = ops.upsample_to_nchw(rv.view(N, h, w, _CPAD), K, H, W)                      # :257
+        if mode == "pix":
+            return (cams, sgc), tape, ht
+        return (cams, sgc, emb, logits), tape, ht
+
+    # ---- backward -----------------------------------------------------------------------------------
+    def _run_backward(self, tape, ht, mode, gouts):
+        cfg, K = self.cfg, self.classes
+        N = tape.N
+        p7 = tape.blocks[cfg.taps[6]].out
+        _, h, w, C7 = p7.shape
+        hw, M7 = ht.hw, N * ht.hw
+        dev = p7.device
+        sink = _ArenaSink(self.live_parameters(mode))
+        if mode == "logits":
+            g_cams = g_sgc = None
+            g_emb, g_logits = gouts
+        elif mode == "cam":
+            g_cams, g_sgc, g_emb, g_logits = gouts
+        else:
+            (g_cams, g_sgc), g_emb, g_logits = gouts, None, None
+        g_p7 = None
+        if mode != "logits":
+            g_cam = torch.zeros(M7 + 4, _CPAD, dtype=torch.float32, device=dev)          # dL/d cam (low res), pre-relu mask
+            have = False
+            if g_cams is not None:
+                ops.upsample_to_nchw_bwd(g_cams.contiguous(), g_cam[:M7].view(N, h, w, _CPAD))
+                have = True
+            if g_sgc is not None:
+                g_rv = torch.zeros(N, hw, _CPAD, dtype=torch.float32, device=dev)
+                ops.upsample_to_nchw_bwd(g_sgc.contiguous(), g_rv.view(N, h, w, _CPAD))
+                gTb = torch.zeros(M7 + 4, _CPAD, dtype=torch.float32, device=dev)
+                gT = gTb[:M7].view(N, hw, _CPAD)
+                ops.pcm_norm(ht.T, gT, K, 1e-5, grv=g_rv)
+                cam3 = ht.cam[:M7].view(N, hw, _CPAD)
+                g_aff = torch.zeros_like(ht.aff)
+                ops.bgemm(0, gT, cam3, g_aff, hw, hw, _CPAD)                                # dT camx^T
+                g_camx = torch.empty(N, hw, _CPAD, dtype=torch.float32, device=dev)
+                ops.bgemm(1, ht.aff, gT, g_camx, hw, _CPAD, ht.hwp)                         # aff^T dT (aff symmetric)
+                ops.ew(1, g_cam[:M7], g_camx.view(M7, _CPAD), alpha=1.0, out=g_cam[:M7])
+                have = True
+                G2 = ops.sym_relu_grad(g_aff, ht.aff, hw)
+                del g_aff
+                g_fn = torch.empty(N, hw, 128, dtype=torch.float32, device=dev)
+                ops.bgemm(1, G2, ht.fn[:M7].view(N, hw, 128), g_fn, hw, 128, ht.hwp)
+                del G2
+                g_f = ops.row_l2norm_bwd(ht.f, ht.nrm, g_fn.view(M7, 128), 1e-5)
+                Cf = ht.fs.shape[3]
+                ops.pw_wgrad(g_f, ht.fs.view(M7, Cf), sink.of(self.fuse.weight).view(128, Cf))
+                sink.of(self.fuse.bias).add_(ops.pool_sum(g_f, M7).view(128))
+            if have:
+                g_cam_m = ops.ew(2, g_cam[:M7], y=ht.cam[:M7])                              # relu backward
+                g_p7 = ops.pw_dgrad(g_cam_m, ht.fcw, C7)                                    # through the detached fc weight
+        if mode in ("cam", "logits") and (g_emb is not None or g_logits is not None):
+            g_e = g_emb.contiguous() if g_emb is not None else None
+            if g_logits is not None:
+                gl = torch.zeros(N, _CPAD, dtype=torch.float32, device=dev)
+                gl[:, :K] = g_logits
+                dW = torch.zeros(_CPAD, C7, dtype=torch.float32, device=dev)
+                ops.pw_wgrad(gl, ht.emb, dW)
+                sink.of(self.fc.weight).add_(dW[:K])
+                g_e = ops.pw_dgrad(gl, ht.fcw, C7, residual=g_e)
+            if g_p7 is None:
+                g_p7 = torch.zeros(M7, C7, dtype=torch.float32, device=dev)
+            ops.bcast_add(g_p7, g_e, 1.0 / hw, hw)                                          # GAP backward
+        if g_p7 is not None:
+            engine.backbone_backward(self.backbone, cfg, tape, {cfg.taps[6]: g_p7.view(N, h, w, C7)}, sink)
+        for p in sink.params:
+            g = sink.of(p)
+            if p.grad is None:
+                p.grad = g
+            else:
+                p.grad = p.grad + g
+        self.last_grad_sink = sink

@@ -1,0 +1,14 @@
+"""muscle_amd — MI355X-native MCL / MuSCLe training hot path.
+
+Public names mirror the reference's `src/__init__.py:1-6` for the path that is built
+(MuSCLe model in CAM-encoder mode, the MCL loss callables) plus the loop body (`mcl_step`)
+and the fused optimiser.  Importing the package never needs a GPU; running anything does.
+"""
+from .MuSCLe import MuSCLe  # noqa: F401
+from .loss_multilabel import (FocalLoss, Log_Sum_Exp_Pairwise_Loss, MultiLabelSoftMarginLoss,  # noqa: F401
+                              image_level_contrast)
+from .optim import FusedAdam  # noqa: F401
+from .train_step import cam_softmaxnorm, er_loss, mcl_step  # noqa: F401
+
+__all__ = ["MuSCLe", "FocalLoss", "Log_Sum_Exp_Pairwise_Loss", "MultiLabelSoftMarginLoss", "image_level_contrast",
+           "FusedAdam", "cam_softmaxnorm", "er_loss", "mcl_step"]

@@ -1,0 +1,278 @@
+// CAM head + PCM (pixel-correlation module) support kernels.
+//
+// Reference: MuSCLe.forward(cam='cam'/'pix') src/MuSCLe.py:237-279 and MuSCLe.PCM :213-223.
+// The contractions (fc, CAM 1x1, fuse 1x1, f^T f, cam*aff) run on the MFMA GEMM (gemm.hip); this file
+// holds what sits between them: bilinear(align_corners=True) resampling, the per-pixel L2
+// normalisation, the affinity column normalisation and their adjoints.  Low-resolution head tensors
+// are NHWC with the class dimension padded to a leading dimension that is a multiple of 4.
+#include "common.h"
+
+// align_corners=True source coordinate (torch upsample_bilinear2d): src = dst * (in-1)/(out-1)
+__device__ __forceinline__ void bil_coord(int d, int in, int out, int& i0, int& i1, float& w1) {
+  float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  float s = scale * d;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  w1 = s - i0;
+}
+
+// dst[n,y,x,coff + c] = [relu] bilinear(src[n,:,:,c])   NHWC -> NHWC (channel slice of a wider tensor)
+__global__ __launch_bounds__(256) void resize_nhwc_kernel(const float* src, float* dst, int N, int Hs, int Ws, int C, int Hd,
+                                                          int Wd, int ldd, int coff, int relu) {
+  const int c4n = C / 4;
+  const long total = (long)N * Hd * Wd * c4n;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int c = (int)(i % c4n) * 4;
+    long p = i / c4n;
+    int x = (int)(p % Wd);
+    long q = p / Wd;
+    int y = (int)(q % Hd), n = (int)(q / Hd);
+    int y0, y1, x0, x1;
+    float wy, wx;
+    bil_coord(y, Hs, Hd, y0, y1, wy);
+    bil_coord(x, Ws, Wd, x0, x1, wx);
+    const float* b = src + (long)n * Hs * Ws * C + c;
+    float4 a00 = ld4(b + ((long)y0 * Ws + x0) * C), a01 = ld4(b + ((long)y0 * Ws + x1) * C);
+    float4 a10 = ld4(b + ((long)y1 * Ws + x0) * C), a11 = ld4(b + ((long)y1 * Ws + x1) * C);
+    float4 o;
+#define BIL(f) o.f = (1.f - wy) * ((1.f - wx) * a00.f + wx * a01.f) + wy * ((1.f - wx) * a10.f + wx * a11.f)
+    BIL(x); BIL(y); BIL(z); BIL(w);
+#undef BIL
+    if (relu) { o.x = fmaxf(o.x, 0.f); o.y = fmaxf(o.y, 0.f); o.z = fmaxf(o.z, 0.f); o.w = fmaxf(o.w, 0.f); }
+    st4(dst + p * ldd + coff + c, o);
+  }
+}
+
+// dst[n,k,Y,X] (NCHW, K classes) = bilinear(src[n,:,:,k]) with src NHWC of leading dimension lds
+__global__ __launch_bounds__(256) void upsample_to_nchw_kernel(const float* src, float* dst, int N, int Hs, int Ws, int lds,
+                                                               int K, int Hd, int Wd) {
+  const long total = (long)N * K * Hd * Wd;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int x = (int)(i % Wd);
+    long q = i / Wd;
+    int y = (int)(q % Hd);
+    q /= Hd;
+    int k = (int)(q % K), n = (int)(q / K);
+    int y0, y1, x0, x1;
+    float wy, wx;
+    bil_coord(y, Hs, Hd, y0, y1, wy);
+    bil_coord(x, Ws, Wd, x0, x1, wx);
+    const float* b = src + (long)n * Hs * Ws * lds + k;
+    float a00 = b[((long)y0 * Ws + x0) * lds], a01 = b[((long)y0 * Ws + x1) * lds];
+    float a10 = b[((long)y1 * Ws + x0) * lds], a11 = b[((long)y1 * Ws + x1) * lds];
+    dst[i] = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
+  }
+}
+
+// adjoint of the above: gsrc[n,sy,sx,k] (+)= sum over destination pixels of weight * gdst[n,k,Y,X].
+// One block per (n,k): separable, first along X into LDS [Hd][Ws], then along Y.
+__global__ __launch_bounds__(256) void upsample_to_nchw_bwd_kernel(const float* gdst, float* gsrc, int N, int Hs, int Ws, int lds,
+                                                                   int K, int Hd, int Wd, int accumulate) {
+  extern __shared__ float t[];   // [Hd][Ws]
+  const int nk = blockIdx.x, n = nk / K, k = nk % K;
+  const float* g = gdst + (long)nk * Hd * Wd;
+  const float sx = (Wd > 1) ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
+  const float sy = (Hd > 1) ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
+  for (int i = threadIdx.x; i < Hd * Ws; i += 256) t[i] = 0.f;
+  __syncthreads();
+  // stage 1: every destination element scatters into its two source columns (LDS atomics, row-local)
+  for (int i = threadIdx.x; i < Hd * Wd; i += 256) {
+    int x = i % Wd, y = i / Wd;
+    int x0, x1;
+    float wx;
+    bil_coord(x, Ws, Wd, x0, x1, wx);
+    float v = g[i];
+    atomicAdd(&t[y * Ws + x0], (1.f - wx) * v);
+    if (x1 != x0) atomicAdd(&t[y * Ws + x1], wx * v);
+  }
+  __syncthreads();
+  (void)sx; (void)sy;
+  // stage 2: gather along Y: source row i receives from dst rows with floor(src) == i (w 1-f) or i-1 (w f)
+  for (int o = threadIdx.x; o < Hs * Ws; o += 256) {
+    int sxi = o % Ws, syi = o / Ws;
+    float acc = 0.f;
+    for (int y = 0; y < Hd; ++y) {
+      int y0, y1;
+      float wy;
+      bil_coord(y, Hs, Hd, y0, y1, wy);
+      if (y0 == syi) acc += (1.f - wy) * t[y * Ws + sxi];
+      if (y1 == syi && y1 != y0) acc += wy * t[y * Ws + sxi];
+    }
+    float* d = gsrc + (((long)n * Hs + syi) * Ws + sxi) * lds + k;
+    *d = accumulate ? (*d + acc) : acc;
+  }
+}
+
+// rows [R, C]: y = x / (||x||_2 + eps); saves the norm.  One wave per row.
+__global__ __launch_bounds__(256) void row_l2norm_kernel(const float* x, float* y, float* nrm, long R, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < R; r += (long)gridDim.x * 4) {
+    const float* p = x + r * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += p[c] * p[c];
+    s = sqrtf(wave_sum(s));
+    float inv = 1.f / (s + eps);
+    for (int c = lane; c < C; c += 64) y[r * C + c] = p[c] * inv;
+    if (lane == 0) nrm[r] = s;
+  }
+}
+
+// backward of y = x/(n+eps): gx = gy/(n+eps) - (x/n) * (gy.x)/(n+eps)^2
+__global__ __launch_bounds__(256) void row_l2norm_bwd_kernel(const float* x, const float* nrm, const float* gy, float* gx, long R,
+                                                             int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  for (long r = blockIdx.x * 4L + (threadIdx.x >> 6); r < R; r += (long)gridDim.x * 4) {
+    const float* p = x + r * C;
+    const float* g = gy + r * C;
+    float d = 0.f;
+    for (int c = lane; c < C; c += 64) d += p[c] * g[c];
+    d = wave_sum(d);
+    float n = nrm[r], inv = 1.f / (n + eps);
+    float k = (n > 0.f) ? d * inv * inv / n : 0.f;
+    for (int c = lane; c < C; c += 64) gx[r * C + c] = g[c] * inv - p[c] * k;
+  }
+}
+
+// PCM tail.  T[b,j,0..L) = aff * camx with camx[:, :, K] == 1, so T[b,j,K] is the affinity row sum.
+//   fwd : rv[b,j,k] = T[b,j,k] / (T[b,j,K] + eps)   (k < K; padding columns -> 0)
+//   bwd : gT[b,j,k] = grv[b,j,k]*r ; gT[b,j,K] = -sum_k grv*T*r^2 ; r = 1/(T[b,j,K]+eps)
+__global__ __launch_bounds__(256) void pcm_norm_kernel(const float* T, const float* grv, float* out, long rows, int L, int K,
+                                                       float eps, int bwd) {
+  for (long r = blockIdx.x * 256L + threadIdx.x; r < rows; r += (long)gridDim.x * 256) {
+    const float* t = T + r * L;
+    float inv = 1.f / (t[K] + eps);
+    if (!bwd) {
+      for (int k = 0; k < L; ++k) out[r * L + k] = (k < K) ? t[k] * inv : 0.f;
+    } else {
+      const float* g = grv + r * L;
+      float acc = 0.f;
+      for (int k = 0; k < K; ++k) { out[r * L + k] = g[k] * inv; acc += g[k] * t[k]; }
+      out[r * L + K] = -acc * inv * inv;
+      for (int k = K + 1; k < L; ++k) out[r * L + k] = 0.f;
+    }
+  }
+}
+
+// G2[b,i,j] = (gaff[b,i,j] + gaff[b,j,i]) * (aff[b,i,j] > 0): gradient of relu(f f^T) w.r.t. the symmetric product
+__global__ __launch_bounds__(256) void sym_relu_grad_kernel(const float* gaff, const float* aff, float* out, int B, int n, int ld) {
+  const long total = (long)B * n * ld;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int j = (int)(i % ld);
+    long q = i / ld;
+    int ii = (int)(q % n);
+    long b = q / n;
+    float v = 0.f;
+    if (j < n && aff[i] > 0.f) v = gaff[i] + gaff[(b * n + j) * ld + ii];
+    out[i] = v;
+  }
+}
+
+// small elementwise helpers on flat fp32 arrays
+//  op 0: out = alpha*a                 op 1: out = a + alpha*b
+//  op 2: out = (y > 0) ? a (+ b) : 0   (relu backward; b optional, y given as third operand)
+__global__ __launch_bounds__(256) void ew_kernel(int op, const float* a, const float* b, const float* y, float alpha, float* out,
+                                                 long n) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float v;
+    if (op == 0) v = alpha * a[i];
+    else if (op == 1) v = a[i] + alpha * b[i];
+    else v = (y[i] > 0.f) ? (a[i] + (b ? b[i] : 0.f)) : 0.f;
+    out[i] = v;
+  }
+}
+
+// X[n, hw, c] += alpha * v[n, c]   (backward of the global average pool)
+__global__ __launch_bounds__(256) void bcast_add_kernel(float* X, const float* v, float alpha, long rows, int C, int rps) {
+  const int c4n = C / 4;
+  const long total = rows * c4n;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long r = i / c4n;
+    int c = (int)(i - r * c4n) * 4;
+    float4 x = ld4(X + i * 4), a = ld4(v + (r / rps) * C + c);
+    x.x += alpha * a.x; x.y += alpha * a.y; x.z += alpha * a.z; x.w += alpha * a.w;
+    st4(X + i * 4, x);
+  }
+}
+
+static int gs(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+extern "C" {
+
+int mx_resize_nhwc(const float* src, float* dst, int N, int Hs, int Ws, int C, int Hd, int Wd, int ldd, int coff, int relu,
+                   void* stream) {
+  MX_CHECK_ARG(src && dst && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C % 4 == 0 && ldd % 4 == 0 && coff % 4 == 0 &&
+                   coff + C <= ldd, "resize_nhwc: bad args C=%d ldd=%d coff=%d", C, ldd, coff);
+  hipLaunchKernelGGL(resize_nhwc_kernel, dim3(gs((long)N * Hd * Wd * (C / 4))), dim3(256), 0, (hipStream_t)stream, src, dst, N,
+                     Hs, Ws, C, Hd, Wd, ldd, coff, relu);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_upsample_to_nchw(const float* src, float* dst, int N, int Hs, int Ws, int lds, int K, int Hd, int Wd, void* stream) {
+  MX_CHECK_ARG(src && dst && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && K > 0 && K <= lds, "upsample_to_nchw: bad args");
+  hipLaunchKernelGGL(upsample_to_nchw_kernel, dim3(gs((long)N * K * Hd * Wd)), dim3(256), 0, (hipStream_t)stream, src, dst, N,
+                     Hs, Ws, lds, K, Hd, Wd);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_upsample_to_nchw_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int lds, int K, int Hd, int Wd,
+                            int accumulate, void* stream) {
+  MX_CHECK_ARG(gdst && gsrc && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && K > 0 && K <= lds, "upsample_to_nchw_bwd: bad args");
+  size_t sh = (size_t)Hd * Ws * sizeof(float);
+  MX_CHECK_ARG(sh <= 160 * 1024, "upsample_to_nchw_bwd: Hd*Ws=%d exceeds LDS", Hd * Ws);
+  if (sh > 48 * 1024)
+    hipFuncSetAttribute((const void*)upsample_to_nchw_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL(upsample_to_nchw_bwd_kernel, dim3(N * K), dim3(256), sh, (hipStream_t)stream, gdst, gsrc, N, Hs, Ws, lds,
+                     K, Hd, Wd, accumulate);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_row_l2norm(const float* x, float* y, float* nrm, long R, int C, float eps, void* stream) {
+  MX_CHECK_ARG(x && y && nrm && R > 0 && C > 0, "row_l2norm: bad args");
+  hipLaunchKernelGGL(row_l2norm_kernel, dim3(gs(R * 64)), dim3(256), 0, (hipStream_t)stream, x, y, nrm, R, C, eps);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_row_l2norm_bwd(const float* x, const float* nrm, const float* gy, float* gx, long R, int C, float eps, void* stream) {
+  MX_CHECK_ARG(x && nrm && gy && gx && R > 0 && C > 0, "row_l2norm_bwd: bad args");
+  hipLaunchKernelGGL(row_l2norm_bwd_kernel, dim3(gs(R * 64)), dim3(256), 0, (hipStream_t)stream, x, nrm, gy, gx, R, C, eps);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_pcm_norm(const float* T, const float* grv, float* out, long rows, int L, int K, float eps, int bwd, void* stream) {
+  MX_CHECK_ARG(T && out && rows > 0 && K > 0 && K < L && (!bwd || grv), "pcm_norm: bad args");
+  hipLaunchKernelGGL(pcm_norm_kernel, dim3(gs(rows)), dim3(256), 0, (hipStream_t)stream, T, grv, out, rows, L, K, eps, bwd);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_sym_relu_grad(const float* gaff, const float* aff, float* out, int B, int n, int ld, void* stream) {
+  MX_CHECK_ARG(gaff && aff && out && B > 0 && n > 0 && ld >= n, "sym_relu_grad: bad args");
+  hipLaunchKernelGGL(sym_relu_grad_kernel, dim3(gs((long)B * n * ld)), dim3(256), 0, (hipStream_t)stream, gaff, aff, out, B, n, ld);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_ew(int op, const float* a, const float* b, const float* y, float alpha, float* out, long n, void* stream) {
+  MX_CHECK_ARG(a && out && n > 0 && op >= 0 && op <= 2, "ew: bad args");
+  MX_CHECK_ARG(op != 1 || b, "ew: op 1 needs b");
+  MX_CHECK_ARG(op != 2 || y, "ew: op 2 needs y");
+  hipLaunchKernelGGL(ew_kernel, dim3(gs(n)), dim3(256), 0, (hipStream_t)stream, op, a, b, y, alpha, out, n);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_bcast_add(float* X, const float* v, float alpha, long rows, int C, int rows_per_sample, void* stream) {
+  MX_CHECK_ARG(X && v && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bcast_add: bad args");
+  hipLaunchKernelGGL(bcast_add_kernel, dim3(gs(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, X, v, alpha, rows, C,
+                     rows_per_sample);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+}  // extern "C"

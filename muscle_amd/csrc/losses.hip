@@ -1,0 +1,422 @@
+// Loss kernels of the MCL step (phase 1): classification losses, image-level contrast (IMC),
+// cam_softmaxnorm and the equivariant-regularisation (ER) top-k loss; plus the fused Adam update.
+//
+// Reference: src/loss_multilabel.py:24-33 (pairwise), :36-66 (IMC), :68-91 (focal),
+// nn.MultiLabelSoftMarginLoss (train_mcl.py:146,181), train_mcl.py:30-36 (cam_softmaxnorm),
+// train_mcl.py:178,185-188 (ER expression), torch.optim.Adam with weight_decay (train_mcl.py:134).
+#include "common.h"
+
+// ---------------------------------------------------------------------------
+// small [N, C] classification losses.  mode 0 focal(p,y); 1 soft-margin(x,y); 2 pairwise(p,y);
+// 3 sigmoid forward (out = sigmoid(x)); 4 sigmoid backward (out = g * s * (1-s), x = s, y = g)
+// loss: focal / softmargin -> scalar (atomic accumulate into loss[0]); pairwise -> loss[n]
+// grad: d loss / d input for a unit upstream gradient (pairwise: per-sample loss_n)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void cls_loss_kernel(int mode, const float* x, int ldx, const float* y, int ldy, float* loss,
+                                                      float* grad, int ldg, int N, int C) {
+  const int n = blockIdx.x, lane = threadIdx.x;
+  const float* xr = x + (long)n * ldx;
+  const float* yr = y + (long)n * ldy;
+  if (mode == 3) { for (int c = lane; c < C; c += 64) grad[(long)n * ldg + c] = sigmoidf_(xr[c]); return; }
+  if (mode == 4) { for (int c = lane; c < C; c += 64) { float s = xr[c]; grad[(long)n * ldg + c] = yr[c] * s * (1.f - s); } return; }
+  if (mode == 0) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float p = xr[c], t = yr[c];
+      float pt = t * p + (1.f - t) * (1.f - p);
+      float om = 1.f - pt, lg = logf(pt + 1e-9f);
+      acc += -0.5f * om * om * lg;
+      float dpt = -0.5f * (-2.f * om * lg + om * om / (pt + 1e-9f));
+      grad[(long)n * ldg + c] = dpt * (2.f * t - 1.f) / N;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) atomicAdd(loss, acc / N);
+  } else if (mode == 1) {
+    float acc = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float v = xr[c], t = yr[c];
+      // log sigmoid(v) = min(v,0) - log1p(exp(-|v|))
+      float ls = fminf(v, 0.f) - log1pf(__expf(-fabsf(v)));
+      float lsn = fminf(-v, 0.f) - log1pf(__expf(-fabsf(v)));
+      acc += -(t * ls + (1.f - t) * lsn);
+      grad[(long)n * ldg + c] = (sigmoidf_(v) - t) / ((float)C * N);
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) atomicAdd(loss, acc / ((float)C * N));
+  } else {
+    float sn = 0.f, sp = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      float p = xr[c], t = yr[c];
+      float pos = (t == 0.f) ? 0.f : p, neg = (t == 1.f) ? 0.f : p;
+      sn += __expf(neg);
+      sp += __expf(-pos);
+    }
+    sn = wave_sum(sn); sp = wave_sum(sp);
+    float cc = (float)C * C;
+    float S = sn * sp / cc;
+    if (lane == 0) loss[n] = logf(1.f + S);
+    float k = 1.f / (1.f + S) / cc;
+    for (int c = lane; c < C; c += 64) {
+      float p = xr[c], t = yr[c];
+      float g = 0.f;
+      if (t != 1.f) g += __expf(p) * sp;      // neg_c = p active
+      if (t != 0.f) g -= __expf(-p) * sn;     // pos_c = p active
+      grad[(long)n * ldg + c] = g * k;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// IMC (loss_multilabel.py:36-66) in one workgroup: N <= 64 samples.
+// out[0] = loss, out[1] = number of valid anchor rows; gemb = d loss / d emb.
+// ws: N*D floats (normalised embeddings) + N floats (norms)
+// ---------------------------------------------------------------------------
+constexpr int IMC_MAXN = 64;
+__global__ __launch_bounds__(256) void imc_kernel(const float* emb, const float* label, int N, int D, int L, float* out,
+                                                  float* gemb, float* ws) {
+  __shared__ float Wm[IMC_MAXN][IMC_MAXN + 1];   // first S, then the symmetric pair weights
+  __shared__ unsigned char Pm[IMC_MAXN][IMC_MAXN], Gm[IMC_MAXN][IMC_MAXN];
+  __shared__ float nrm[IMC_MAXN], rowk1[IMC_MAXN], rowk2[IMC_MAXN];
+  __shared__ float lossacc, validacc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* E = ws;
+  if (tid == 0) { lossacc = 0.f; validacc = 0.f; }
+  for (int i = wave; i < N; i += 4) {
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) { float v = emb[(long)i * D + d]; s += v * v; }
+    s = sqrtf(wave_sum(s));
+    float dn = fmaxf(s, 1e-6f);
+    for (int d = lane; d < D; d += 64) E[(long)i * D + d] = emb[(long)i * D + d] / dn;
+    if (lane == 0) nrm[i] = s;
+  }
+  __syncthreads();
+  for (int p = wave; p < N * N; p += 4) {
+    int i = p / N, j = p % N;
+    if (j <= i) { if (lane == 0) { Wm[i][j] = 0.f; Pm[i][j] = 0; Gm[i][j] = 0; } continue; }
+    float dot = 0.f;
+    for (int d = lane; d < D; d += 64) dot += E[(long)i * D + d] * E[(long)j * D + d];
+    dot = wave_sum(dot);
+    int same = 1, inter = 0;
+    for (int c = lane; c < L; c += 64) {
+      float a = label[(long)i * L + c], b = label[(long)j * L + c];
+      if (a != b) same = 0;
+      inter += ((long)a & (long)b) ? 1 : 0;
+    }
+    same = __all(same);
+    inter = (int)wave_sum((float)inter);
+    if (lane == 0) { Wm[i][j] = __expf(dot / 0.1f); Pm[i][j] = same; Gm[i][j] = (inter == 0); }
+  }
+  __syncthreads();
+  if (tid < N) {
+    int i = tid;
+    float sp = 1e-6f, sn = 1e-6f;
+    int vp = 0, vn = 0;
+    for (int j = i + 1; j < N; ++j) {
+      if (Pm[i][j]) { sp += Wm[i][j]; ++vp; }
+      if (Gm[i][j]) { sn += Wm[i][j]; ++vn; }
+    }
+    bool valid = vp >= 1 && vn >= 1 && vn > vp;
+    if (valid) {
+      atomicAdd(&lossacc, -logf(sp / (sp + sn)) / N);
+      atomicAdd(&validacc, 1.f);
+      rowk1[i] = (-1.f / sp + 1.f / (sp + sn)) / N;   // d/d sp
+      rowk2[i] = (1.f / (sp + sn)) / N;               // d/d sn
+    } else {
+      rowk1[i] = rowk2[i] = 0.f;
+    }
+  }
+  __syncthreads();
+  // pair weights dL/d(dot_ij), upper triangle
+  for (int p = tid; p < N * N; p += 256) {
+    int i = p / N, j = p % N;
+    if (j > i) {
+      float w = (Pm[i][j] ? rowk1[i] : 0.f) + (Gm[i][j] ? rowk2[i] : 0.f);
+      Wm[i][j] = w * Wm[i][j] / 0.1f;
+    }
+  }
+  __syncthreads();
+  for (int p = tid; p < N * N; p += 256) {
+    int i = p / N, j = p % N;
+    if (j < i) Wm[i][j] = Wm[j][i];
+  }
+  __syncthreads();
+  // g_e[i] = sum_j Wsym[i][j] * e_j ; then back through the normalisation
+  for (int i = wave; i < N; i += 4) {
+    float dotge = 0.f;
+    float gloc[16];   // D <= 1024
+    int cnt = 0;
+    for (int d = lane; d < D; d += 64, ++cnt) {
+      float g = 0.f;
+      for (int j = 0; j < N; ++j) g += Wm[i][j] * E[(long)j * D + d];
+      gloc[cnt] = g;
+      dotge += g * E[(long)i * D + d];
+    }
+    dotge = wave_sum(dotge);
+    float s = nrm[i];
+    cnt = 0;
+    for (int d = lane; d < D; d += 64, ++cnt) {
+      float g = gloc[cnt];
+      float v = (s > 1e-6f) ? (g - E[(long)i * D + d] * dotge) / s : g / 1e-6f;
+      gemb[(long)i * D + d] = v;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) { out[0] = lossacc; out[1] = validacc; }
+}
+
+// ---------------------------------------------------------------------------
+// cam_softmaxnorm (train_mcl.py:30-36) on NCHW [N, K, H, W]: fg = softmax over channels 1..K-1,
+// bg = 1 - max fg.  One thread per pixel; channel reads are plane-strided, x-contiguous.
+// ---------------------------------------------------------------------------
+constexpr int KMAX = 32;
+
+__device__ __forceinline__ void softmaxnorm_px(const float* x, long plane, int K, float* o, int* amax) {
+  float mx = -INFINITY;
+  for (int k = 1; k < K; ++k) { o[k] = x[k * plane]; mx = fmaxf(mx, o[k]); }
+  float s = 0.f;
+  for (int k = 1; k < K; ++k) { o[k] = __expf(o[k] - mx); s += o[k]; }
+  float inv = 1.f / s, best = -1.f;
+  int bi = 1;
+  for (int k = 1; k < K; ++k) { o[k] *= inv; if (o[k] > best) { best = o[k]; bi = k; } }
+  o[0] = 1.f - best;
+  *amax = bi;
+}
+
+__global__ __launch_bounds__(256) void softmaxnorm_kernel(const float* x, const float* gy, float* out, int N, int K, long HW,
+                                                          int bwd) {
+  const long total = (long)N * HW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long n = i / HW, p = i - n * HW;
+    const float* xb = x + n * K * HW + p;
+    float o[KMAX];
+    int am;
+    softmaxnorm_px(xb, HW, K, o, &am);
+    float* ob = out + n * K * HW + p;
+    if (!bwd) {
+      for (int k = 0; k < K; ++k) ob[k * HW] = o[k];
+    } else {
+      const float* gb = gy + n * K * HW + p;
+      float g[KMAX];
+      float dot = 0.f;
+      for (int k = 1; k < K; ++k) g[k] = gb[k * HW];
+      g[am] -= gb[0];
+      for (int k = 1; k < K; ++k) dot += g[k] * o[k];
+      ob[0] = 0.f;
+      for (int k = 1; k < K; ++k) ob[k * HW] = o[k] * (g[k] - dot);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// ER loss: d[n, k, p] = | sm(cams)[k] - sm(sgcs)[k] | * m[n,k]; top-k mean per row by exact radix select.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void er_diff_kernel(const float* cams, const float* sgcs, const float* lwb, float* d, int N,
+                                                      int K, long HW) {
+  const long total = (long)N * HW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long n = i / HW, p = i - n * HW;
+    float a[KMAX], b[KMAX];
+    int t0, t1;
+    softmaxnorm_px(cams + n * K * HW + p, HW, K, a, &t0);
+    softmaxnorm_px(sgcs + n * K * HW + p, HW, K, b, &t1);
+    for (int k = 0; k < K; ++k) d[n * K * HW + k * HW + p] = fabsf(a[k] - b[k]) * lwb[n * K + k];
+  }
+}
+
+constexpr int RBINS = 2048;
+// histogram of one radix digit over the elements whose higher digits equal prefix[n]
+__global__ __launch_bounds__(256) void er_hist_kernel(const float* d, long row_len, int shift, int nbits, unsigned himask,
+                                                      const unsigned* prefix, unsigned* hcnt, float* hsum) {
+  __shared__ unsigned lc[RBINS];
+  __shared__ float ls[RBINS];
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < RBINS; i += 256) { lc[i] = 0; ls[i] = 0.f; }
+  __syncthreads();
+  const unsigned pf = prefix[n], dm = (1u << nbits) - 1u;
+  const float* row = d + n * row_len;
+  const long per = (row_len + gridDim.x - 1) / gridDim.x;
+  const long beg = blockIdx.x * per, end = min(row_len, beg + per);
+  for (long i = beg + threadIdx.x; i < end; i += 256) {
+    float v = row[i];
+    unsigned key = __float_as_uint(v);
+    if ((key & himask) == pf) {
+      unsigned b = (key >> shift) & dm;
+      atomicAdd(&lc[b], 1u);
+      atomicAdd(&ls[b], v);
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RBINS; i += 256)
+    if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); unsafeAtomicAdd(&hsum[n * RBINS + i], ls[i]); }
+}
+
+// per row: pick the digit of the k-th largest; state = {krem (still to take), prefix, sum_gt, cnt_eq}
+__global__ void er_scan_kernel(const unsigned* hcnt, const float* hsum, int shift, int nbits, unsigned* krem, unsigned* prefix,
+                               float* sum_gt, unsigned* cnt_eq, int N) {
+  int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  unsigned k = krem[n];
+  float s = sum_gt[n];
+  int nb = 1 << nbits;
+  int b = nb - 1;
+  for (; b > 0; --b) {
+    unsigned c = hcnt[n * RBINS + b];
+    if (c >= k) break;
+    k -= c;
+    s += hsum[n * RBINS + b];
+  }
+  krem[n] = k;
+  sum_gt[n] = s;
+  prefix[n] |= ((unsigned)b) << shift;
+  cnt_eq[n] = hcnt[n * RBINS + b];
+}
+
+// loss = sum_n (sum_gt[n] + krem[n] * tau[n]) / (N * k)
+__global__ void er_final_kernel(const unsigned* krem, const unsigned* prefix, const float* sum_gt, int N, float inv_nk, float* loss) {
+  float acc = 0.f;
+  for (int n = threadIdx.x; n < N; n += 64) acc += sum_gt[n] + (float)krem[n] * __uint_as_float(prefix[n]);
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) loss[0] = acc * inv_nk;
+}
+
+// gradient w.r.t. raw sgcs: selected elements get -sign(c - s) * m / (N k) (ties at tau share krem/cnt_eq),
+// pulled back through cam_softmaxnorm.
+__global__ __launch_bounds__(256) void er_bwd_kernel(const float* cams, const float* sgcs, const float* lwb, const unsigned* prefix,
+                                                     const unsigned* krem, const unsigned* cnt_eq, const float* gup, float gscale,
+                                                     float* gsg, int N, int K, long HW) {
+  const long total = (long)N * HW;
+  if (gup) gscale *= gup[0];
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long n = i / HW, p = i - n * HW;
+    float a[KMAX], b[KMAX], g[KMAX];
+    int t0, am;
+    softmaxnorm_px(cams + n * K * HW + p, HW, K, a, &t0);
+    softmaxnorm_px(sgcs + n * K * HW + p, HW, K, b, &am);
+    const unsigned tk = prefix[n];
+    const float tiew = cnt_eq[n] ? (float)krem[n] / (float)cnt_eq[n] : 0.f;
+    for (int k = 0; k < K; ++k) {
+      float m = lwb[n * K + k];
+      float df = a[k] - b[k];
+      unsigned key = __float_as_uint(fabsf(df) * m);
+      float w = (key > tk) ? 1.f : ((key == tk) ? tiew : 0.f);
+      float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+      g[k] = -sg * m * w * gscale;
+    }
+    float dot = 0.f;
+    g[am] -= g[0];
+    for (int k = 1; k < K; ++k) dot += g[k] * b[k];
+    float* ob = gsg + n * K * HW + p;
+    ob[0] = 0.f;
+    for (int k = 1; k < K; ++k) ob[k * HW] = b[k] * (g[k] - dot);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Adam, L2 weight decay folded into the gradient (torch.optim.Adam, not AdamW), flat arrays
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1,
+                                                   float b2, float eps, float wd, float bc1, float bc2s) {
+  for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      float4 pp = ld4(p + i), gg = ld4(g + i), mm = ld4(m + i), vv = ld4(v + i);
+#define ADAM1(f)                                            \
+  {                                                         \
+    float gr = gg.f + wd * pp.f;                            \
+    mm.f = b1 * mm.f + (1.f - b1) * gr;                     \
+    vv.f = b2 * vv.f + (1.f - b2) * gr * gr;                \
+    pp.f -= (lr / bc1) * mm.f / (sqrtf(vv.f) / bc2s + eps); \
+  }
+      ADAM1(x) ADAM1(y) ADAM1(z) ADAM1(w)
+#undef ADAM1
+      st4(p + i, pp); st4(m + i, mm); st4(v + i, vv);
+    } else {
+      for (long j = i; j < n; ++j) {
+        float gr = g[j] + wd * p[j];
+        m[j] = b1 * m[j] + (1.f - b1) * gr;
+        v[j] = b2 * v[j] + (1.f - b2) * gr * gr;
+        p[j] -= (lr / bc1) * m[j] / (sqrtf(v[j]) / bc2s + eps);
+      }
+    }
+  }
+}
+
+static int gs(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+extern "C" {
+
+int mx_cls_loss(int mode, const float* x, int ldx, const float* y, int ldy, float* loss, float* grad, int ldg, int N, int C,
+                void* stream) {
+  MX_CHECK_ARG(mode >= 0 && mode <= 4 && x && y && grad && N > 0 && C > 0, "cls_loss: bad args");
+  MX_CHECK_ARG(mode >= 3 || loss, "cls_loss: loss output required");
+  hipLaunchKernelGGL(cls_loss_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mode, x, ldx, y, ldy, loss, grad, ldg, N, C);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_imc(const float* emb, const float* label, int N, int D, int L, float* out2, float* gemb, float* workspace, void* stream) {
+  MX_CHECK_ARG(emb && label && out2 && gemb && workspace, "imc: null pointer");
+  MX_CHECK_ARG(N > 0 && N <= IMC_MAXN && D > 0 && D <= 1024 && L > 0, "imc: N=%d (<=64) D=%d (<=1024) L=%d", N, D, L);
+  hipLaunchKernelGGL(imc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, label, N, D, L, out2, gemb, workspace);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_softmaxnorm(const float* x, const float* gy, float* out, int N, int K, long HW, int bwd, void* stream) {
+  MX_CHECK_ARG(x && out && N > 0 && K >= 2 && K <= KMAX && HW > 0 && (!bwd || gy), "softmaxnorm: bad args K=%d", K);
+  hipLaunchKernelGGL(softmaxnorm_kernel, dim3(gs((long)N * HW)), dim3(256), 0, (hipStream_t)stream, x, gy, out, N, K, HW, bwd);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// ER forward.  workspace layout (caller-allocated, zero-filled): d [N*K*HW] floats, then
+//   state: krem[N] u32, prefix[N] u32, sum_gt[N] f32, cnt_eq[N] u32, hcnt[N*2048] u32, hsum[N*2048] f32
+int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int K, long HW, long k, float* d, unsigned* krem,
+              unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss, void* stream) {
+  MX_CHECK_ARG(cams && sgcs && lwb && d && krem && prefix && sum_gt && cnt_eq && hcnt && hsum && loss, "er_fwd: null pointer");
+  MX_CHECK_ARG(N > 0 && K >= 2 && K <= KMAX && HW > 0, "er_fwd: bad extents");
+  MX_CHECK_ARG(k >= 1 && k <= (long)K * HW, "er_fwd: k=%ld out of range for rows of %ld (torch.topk would raise)", k, (long)K * HW);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(er_diff_kernel, dim3(gs((long)N * HW)), dim3(256), 0, st, cams, sgcs, lwb, d, N, K, HW);
+  // krem <- k  (prefix, sum_gt zeroed by the caller)
+  {
+    unsigned kk = (unsigned)k;
+    hipMemsetD32Async((hipDeviceptr_t)krem, (int)kk, N, st);
+  }
+  const long row_len = (long)K * HW;
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  const unsigned himask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
+  int chunks = (int)((row_len + 16383) / 16384);
+  if (chunks > 512) chunks = 512;
+  for (int ps = 0; ps < 3; ++ps) {
+    hipMemsetAsync(hcnt, 0, sizeof(unsigned) * N * RBINS, st);
+    hipMemsetAsync(hsum, 0, sizeof(float) * N * RBINS, st);
+    hipLaunchKernelGGL(er_hist_kernel, dim3(chunks, N), dim3(256), 0, st, d, row_len, shifts[ps], bits[ps], himask[ps], prefix,
+                       hcnt, hsum);
+    hipLaunchKernelGGL(er_scan_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
+                       cnt_eq, N);
+  }
+  hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)k), loss);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsigned* prefix, const unsigned* krem,
+              const unsigned* cnt_eq, const float* gup, float gscale, float* gsgcs, int N, int K, long HW, void* stream) {
+  MX_CHECK_ARG(cams && sgcs && lwb && prefix && krem && cnt_eq && gsgcs && N > 0 && K >= 2 && K <= KMAX && HW > 0, "er_bwd: bad args");
+  hipLaunchKernelGGL(er_bwd_kernel, dim3(gs((long)N * HW)), dim3(256), 0, (hipStream_t)stream, cams, sgcs, lwb, prefix, krem,
+                     cnt_eq, gup, gscale, gsgcs, N, K, HW);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
+            float weight_decay, float bias_corr1, float sqrt_bias_corr2, void* stream) {
+  MX_CHECK_ARG(p && g && m && v && n > 0, "adam: bad args");
+  MX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam: pointers must be 16-byte aligned");
+  hipLaunchKernelGGL(adam_kernel, dim3(gs((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
+                     weight_decay, bias_corr1, sqrt_bias_corr2);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+}  // extern "C"

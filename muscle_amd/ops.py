@@ -56,14 +56,12 @@ def pw_wgrad(G, X, dW, *, x_mode=PLAIN, x_scale=None, x_shift=None, x_gate=None,
          R, Co, Ci, G.stride(0), X.stride(0), stream())
 
 
-def bgemm(layout, A, B, *, relu=False, out=None):
-    """Batched plain GEMM.  layout 0: C = A B^T with B [b, N, K]; layout 1: C = A B with B [b, K, N]."""
-    b, M, K = A.shape
-    N = B.shape[1] if layout == 0 else B.shape[2]
-    if out is None:
-        out = _f32(b, M, N, device=A.device)
-    call("mx_bgemm", layout, ptr(A), ptr(B), ptr(out), M, N, K, A.stride(1), B.stride(1), N,
-         A.stride(0), B.stride(0), M * N, b, int(relu), stream())
+def bgemm(layout, A, B, out, M, N, K, *, relu=False):
+    """Batched plain GEMM on 3-D views [b, rows, ld]; extents explicit because operands may be padded.
+    layout 0: C[M,N] = A[M,K] B[N,K]^T; layout 1: C[M,N] = A[M,K] B[K,N]."""
+    b = A.shape[0]
+    call("mx_bgemm", layout, ptr(A), ptr(B), ptr(out), M, N, K, A.stride(1), B.stride(1), out.stride(1),
+         A.stride(0), B.stride(0), out.stride(0), b, int(relu), stream())
     return out
 
 
@@ -175,3 +173,61 @@ def stem_im2col(img, Ho, Wo, pad_lo):
     out = _f32(N * Ho * Wo, 28, device=img.device)
     call("mx_stem_im2col", ptr(img), ptr(out), N, H, W, Ho, Wo, pad_lo, stream())
     return out
+
+
+# ---- head -----------------------------------------------------------------------------------------
+def resize_nhwc(src, dst, coff, relu=True):
+    N, Hs, Ws, C = src.shape
+    _, Hd, Wd, ldd = dst.shape
+    call("mx_resize_nhwc", ptr(src), ptr(dst), N, Hs, Ws, C, Hd, Wd, ldd, coff, int(relu), stream())
+
+
+def upsample_to_nchw(src, K, Hd, Wd):
+    N, Hs, Ws, lds = src.shape
+    dst = _f32(N, K, Hd, Wd, device=src.device)
+    call("mx_upsample_to_nchw", ptr(src), ptr(dst), N, Hs, Ws, lds, K, Hd, Wd, stream())
+    return dst
+
+
+def upsample_to_nchw_bwd(gdst, gsrc, accumulate=False):
+    N, K, Hd, Wd = gdst.shape
+    _, Hs, Ws, lds = gsrc.shape
+    call("mx_upsample_to_nchw_bwd", ptr(gdst), ptr(gsrc), N, Hs, Ws, lds, K, Hd, Wd, int(accumulate), stream())
+
+
+def row_l2norm(x, eps):
+    R, C = x.shape
+    y, nrm = torch.empty_like(x), _f32(R, device=x.device)
+    call("mx_row_l2norm", ptr(x), ptr(y), ptr(nrm), R, C, float(eps), stream())
+    return y, nrm
+
+
+def row_l2norm_bwd(x, nrm, gy, eps):
+    R, C = x.shape
+    gx = torch.empty_like(x)
+    call("mx_row_l2norm_bwd", ptr(x), ptr(nrm), ptr(gy), ptr(gx), R, C, float(eps), stream())
+    return gx
+
+
+def pcm_norm(T, out, K, eps, grv=None):
+    rows, L = T.shape[0] * T.shape[1], T.shape[2]
+    call("mx_pcm_norm", ptr(T), ptr(grv), ptr(out), rows, L, K, float(eps), int(grv is not None), stream())
+    return out
+
+
+def sym_relu_grad(gaff, aff, n):
+    out = torch.empty_like(gaff)
+    call("mx_sym_relu_grad", ptr(gaff), ptr(aff), ptr(out), gaff.shape[0], n, gaff.shape[2], stream())
+    return out
+
+
+def ew(op, a, b=None, y=None, alpha=1.0, out=None):
+    if out is None:
+        out = torch.empty_like(a)
+    call("mx_ew", op, ptr(a), ptr(b), ptr(y), float(alpha), ptr(out), a.numel(), stream())
+    return out
+
+
+def bcast_add(X2d, v, alpha, rows_per_sample):
+    rows, C = X2d.shape
+    call("mx_bcast_add", ptr(X2d), ptr(v), float(alpha), rows, C, rows_per_sample, stream())

@@ -1,0 +1,132 @@
+"""The MCL loop body — the build's counterpart of train_mcl.py:153-229 — and the
+script-level helpers it uses (cam_maxnorm / cam_softmaxnorm, train_mcl.py:21-36; the ER expression, :185-188).
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional
+
+import torch
+
+from . import loss_multilabel as L
+from ._lib import call, ptr, stream
+
+_RBINS = 2048
+
+
+class _SoftmaxNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous().float()
+        N, K, H, W = x.shape
+        out = torch.empty_like(x)
+        call("mx_softmaxnorm", ptr(x), None, ptr(out), N, K, H * W, 0, stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, K, H, W = x.shape
+        out = torch.empty_like(x)
+        call("mx_softmaxnorm", ptr(x), ptr(g.contiguous()), ptr(out), N, K, H * W, 1, stream())
+        return out
+
+
+def cam_softmaxnorm(cams):
+    """train_mcl.py:30-36."""
+    return _SoftmaxNorm.apply(cams)
+
+
+class _ERLoss(torch.autograd.Function):
+    """mean(topk(flatten(|softmaxnorm(cams).detach()*m - softmaxnorm(sgcs)*m|), k)) fused (train_mcl.py:175-188);
+    the gradient goes to raw_sgcs only, as in the reference (cams is detached at :175)."""
+
+    @staticmethod
+    def forward(ctx, raw_cams, raw_sgcs, lwb, k):
+        raw_cams, raw_sgcs, lwb = raw_cams.contiguous().float(), raw_sgcs.contiguous().float(), lwb.contiguous().float()
+        N, K, H, W = raw_cams.shape
+        HW = H * W
+        if k > K * HW:
+            raise RuntimeError(f"selected index k={k} out of range for rows of {K * HW} (torch.topk raises the same)")
+        dev = raw_cams.device
+        d = torch.empty(N * K * HW, dtype=torch.float32, device=dev)
+        st_u = torch.zeros(3, N, dtype=torch.int32, device=dev)          # krem, prefix, cnt_eq
+        sum_gt = torch.zeros(N, dtype=torch.float32, device=dev)
+        hcnt = torch.empty(N * _RBINS, dtype=torch.int32, device=dev)
+        hsum = torch.empty(N * _RBINS, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        call("mx_er_fwd", ptr(raw_cams), ptr(raw_sgcs), ptr(lwb), N, K, HW, int(k), ptr(d), ptr(st_u[0]), ptr(st_u[1]),
+             ptr(sum_gt), ptr(st_u[2]), ptr(hcnt), ptr(hsum), ptr(loss), stream())
+        ctx.save_for_backward(raw_cams, raw_sgcs, lwb, st_u)
+        ctx.k = int(k)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        raw_cams, raw_sgcs, lwb, st_u = ctx.saved_tensors
+        N, K, H, W = raw_cams.shape
+        out = torch.empty_like(raw_sgcs)
+        gup = g.contiguous().float().reshape(1)
+        call("mx_er_bwd", ptr(raw_cams), ptr(raw_sgcs), ptr(lwb), ptr(st_u[1]), ptr(st_u[0]), ptr(st_u[2]), ptr(gup),
+             1.0 / (N * ctx.k), ptr(out), N, K, H * W, stream())
+        return None, out, None, None
+
+
+def er_loss(raw_cams, raw_sgcs, label_with_bg, valid_channel: int):
+    n, c, h, w = raw_cams.shape
+    return _ERLoss.apply(raw_cams, raw_sgcs, label_with_bg, int(0.2 * valid_channel * h * w))
+
+
+# ---------------------------------------------------------------------------
+# loop body
+# ---------------------------------------------------------------------------
+def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_u=None, crop_geom=None,
+             valid_channel: Optional[int] = None, grad_hook=None, imc_sync: bool = False):
+    """One iteration of train_mcl.py:153-229 on the HIP path: same order, same epoch gates (4/8/12), same
+    loss composition, two optimizer steps once ep >= 8.
+
+    batch: {"img" [N,3,S,S], "label" [N,20], "view1","view2" [N,3,V,V], "coord1","coord2" [N,4] int64}, CUDA.
+    valid_channel: int(label.sum()) if the caller already has it on the host (train_mcl.py:178 reads it
+    back from the device every iteration; passing it avoids that synchronisation).
+    grad_hook(model, phase): called after each backward and before the optimizer step — the data-parallel
+    gradient all-reduce plugs in here (muscle_amd.dist).
+    imc_sync: reproduce the reference's Python-float fall-through for IMC with a device->host read
+    (default: add the device-side loss, which is exactly 0 with zero gradient in that case).
+    Returns the dict of the seven loss terms train_mcl.py:243-249 prints.
+    """
+    img, label = batch["img"], batch["label"].float()
+    out: Dict[str, object] = {}
+    optimizer.zero_grad()
+    model.train()
+    n = label.shape[0]
+    label_with_bg = torch.cat((torch.ones((n, 1), dtype=label.dtype, device=label.device), label), dim=1)
+    raw_cams, raw_sgcs, emb, logits = model(img, cam="cam", drop_u=drop_u)
+    if valid_channel is None:
+        valid_channel = int(label.sum().cpu())
+    p = L.sigmoid(logits[:, 1:])
+    out["loss_focal"] = L.FocalLoss()(p, label)
+    out["loss_softmargin"] = L.MultiLabelSoftMarginLoss()(logits[:, 1:], label)
+    out["loss_pair"] = L.Log_Sum_Exp_Pairwise_Loss(p, label).mean()
+    loss_cls = out["loss_pair"] + out["loss_softmargin"] + out["loss_focal"]
+    out["loss_er"] = er_loss(raw_cams, raw_sgcs, label_with_bg, valid_channel)
+    loss = loss_cls + out["loss_er"]
+    out["loss_imc"] = 0
+    if ep >= 4:
+        if imc_sync:
+            out["loss_imc"] = L.image_level_contrast(emb, label)
+            if torch.is_tensor(out["loss_imc"]):
+                loss = loss_cls + out["loss_imc"] + out["loss_er"]
+        else:
+            out["loss_imc"], _ = L.image_level_contrast_nosync(emb, label)
+            loss = loss_cls + out["loss_imc"] + out["loss_er"]
+    optimizer.zero_grad()
+    loss.backward()
+    if grad_hook is not None:
+        grad_hook(model, 1)
+    optimizer.step()
+    out["loss_pixpro"] = 0
+    out["loss_emd"] = 0
+    if ep >= 8:
+        from . import phase2
+        phase2.run(model, optimizer, batch, ep, label_with_bg, out, crop_geom=crop_geom, grad_hook=grad_hook)
+    return out

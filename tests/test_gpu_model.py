@@ -1,0 +1,217 @@
+"""GPU parity of the full model (backbone + CAM/PCM head), the phase-1 loss kernels and the loop body, through the
+public muscle_amd API, against (a) the CPU oracle on the same seeded inputs and (b) the fixtures produced by the
+reference itself (tests/golden).  fp32 tolerances as stated per assert (losses rel <= 1e-4,
+CAM/SGC max-abs <= 1e-3 max|ref|, gradients max-abs <= 2e-3 of the tensor scale, cosine >= 0.9999)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from muscle_amd import synth
+from muscle_amd.arch import net_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.asarray(a))  # noqa: E731
+
+
+def build(name, seed):
+    import muscle_amd
+    cfg = net_cfg(name, False)
+    sd = synth.synth_state_dict(cfg, seed)
+    m = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)
+    m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    return cfg, sd, m.to(DEV)
+
+
+def close(a, b, tol):
+    a = a.detach().cpu() if torch.is_tensor(a) else a
+    e = gu.rel_err(a, b)
+    assert e <= tol, e
+
+
+def check_grads(model, net32, net64, keys_live, tol=2e-3):
+    worst = 0.0
+    named = dict(model.named_parameters())
+    for k, p64 in net64.named_parameters():
+        g64 = p64.grad
+        p = named[k]
+        if g64 is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        a, b64 = p.grad.cpu().double().flatten(), g64.flatten()
+        b32 = dict(net32.named_parameters())[k].grad.double().flatten()
+        scale = max(float(b64.abs().max()), 1e-30)
+        noise = float((b32 - b64).abs().max())
+        err = float((a - b64).abs().max())
+        assert err <= tol * scale + 20 * noise, (k, err / scale, noise / scale)
+        if noise <= 1e-4 * scale:
+            cos = float(a @ b64 / (a.norm() * b64.norm() + 1e-30))
+            assert cos >= 0.9999, (k, cos)
+            worst = max(worst, err / scale)
+    return worst
+
+
+@pytest.mark.parametrize("name,n,size,mode,training", [
+    ("efficientnet-b0", 3, 64, "cam", True), ("efficientnet-b0", 2, 96, "pix", False),
+    ("efficientnet-b3", 2, 72, "cam", True), ("efficientnet-b7", 2, 64, "cam", True)])
+def test_model_forward_backward(name, n, size, mode, training):
+    from oracle import mcl_oracle as O
+    seed = 23
+    cfg, sd, model = build(name, seed)
+    x = T(synth.normal(seed, "x", (n, 3, size, size)).astype(np.float32))
+    du = gu.drop_draws(cfg, n, 5)
+    nets = []
+    for dt in (torch.float32, torch.float64):
+        net = O.OracleNet(name, sd, dtype=dt)
+        net.train() if training else net.eval()
+        outs = net.forward(x.to(dt), mode, du)
+        probes = [T(synth.normal(seed, f"probe{i}", tuple(o.shape)).astype(np.float32)).to(dt) for i, o in enumerate(outs)]
+        sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+        nets.append((net, outs))
+    (net32, outs32), (net64, outs64) = nets
+    model.train() if training else model.eval()
+    got = model(x.to(DEV), cam=mode, drop_u={k: v.to(DEV) for k, v in du.items()})
+    assert len(got) == len(outs32)
+    for g, o in zip(got, outs32):
+        assert tuple(g.shape) == tuple(o.shape)
+        close(g, o.detach(), 5e-4)
+    loss = sum((g * T(synth.normal(seed, f"probe{i}", tuple(g.shape)).astype(np.float32)).to(DEV)).sum()
+               for i, g in enumerate(got))
+    loss.backward()
+    print("worst grad rel err", check_grads(model, net32, net64, None))
+
+
+def test_cpu_input_raises():
+    import muscle_amd
+    _, _, model = build("efficientnet-b0", 1)
+    with pytest.raises(muscle_amd._lib.MuscleHipError):
+        model(torch.zeros(1, 3, 32, 32))
+
+
+# ---- loss kernels against the reference's own outputs (tests/golden/units.npz) ---------------------------
+U = gu.load("units.npz")
+SEED = 3
+
+
+def test_cls_losses_golden():
+    import muscle_amd as M
+    lab = T(synth.synth_labels(6, SEED)).to(DEV)
+    logit = (T(synth.normal(SEED, "logit", (6, 20)).astype(np.float32)) * 2).to(DEV).requires_grad_()
+    p = M.loss_multilabel.sigmoid(logit)
+    l1, l2 = M.FocalLoss()(p, lab), M.MultiLabelSoftMarginLoss()(logit, lab)
+    l3 = M.Log_Sum_Exp_Pairwise_Loss(p, lab)
+    (l1 + l2 + l3.mean()).backward()
+    close(torch.stack([l1, l2]), U["cls_losses"], 1e-5); close(l3, U["cls_pair"], 1e-5); close(logit.grad, U["cls_dlogit"], 2e-5)
+
+
+def test_imc_golden():
+    import muscle_amd as M
+    emb = T(synth.normal(SEED, "imc.emb", (8, 48)).astype(np.float32)).to(DEV).requires_grad_()
+    li = M.image_level_contrast(emb, T(synth.synth_labels(8, SEED + 1)).to(DEV))
+    assert torch.is_tensor(li) == bool(U["imc_is_tensor"])
+    li.backward()
+    close(li, U["imc"], 2e-5); close(emb.grad, U["imc_demb"], 5e-5)
+    l0 = M.image_level_contrast(T(synth.normal(SEED, "imc.emb0", (4, 48)).astype(np.float32)).to(DEV), torch.ones(4, 20, device=DEV))
+    assert not torch.is_tensor(l0) and l0 == 0.0
+    ln, info = M.loss_multilabel.image_level_contrast_nosync(emb, torch.ones(8, 20, device=DEV))
+    assert float(ln) == 0.0 and float(info[1]) == 0.0
+
+
+def test_softmaxnorm_golden():
+    import muscle_amd as M
+    cam = T(synth.normal(SEED, "cam", (2, 21, 9, 11)).astype(np.float32)).to(DEV).requires_grad_()
+    o = M.cam_softmaxnorm(cam)
+    close(o, U["cam_softmaxnorm"], 1e-5)
+    # backward against torch autograd of the oracle's restatement
+    from oracle import mcl_oracle as O
+    g = T(synth.normal(SEED, "cam.g", (2, 21, 9, 11)).astype(np.float32))
+    o.backward(g.to(DEV))
+    c2 = cam.detach().cpu().requires_grad_()
+    O.cam_softmaxnorm(c2).backward(g)
+    close(cam.grad, c2.grad, 2e-5)
+
+
+def test_er_golden():
+    # the golden ER case feeds *already normalised* maps through the reference expression; reproduce it through
+    # the fused kernel by inverting the softmaxnorm: raw = log(fg) gives softmax(raw[1:]) = fg / sum fg, so instead
+    # compare the fused kernel with the oracle on raw maps, and the top-k machinery with torch.topk directly.
+    import muscle_amd as M
+    from oracle import mcl_oracle as O
+    n, h, w = 3, 8, 8
+    rc = T(synth.normal(SEED, "er.rc", (n, 21, h, w)).astype(np.float32))
+    rs = T(synth.normal(SEED, "er.rs", (n, 21, h, w)).astype(np.float32)).requires_grad_()
+    lab = T(synth.synth_labels(n, SEED + 2))
+    lwb = torch.cat((torch.ones(n, 1), lab), 1)
+    vc = int(lab.sum())
+    ref = O.er_loss(O.cam_softmaxnorm(rc).detach(), O.cam_softmaxnorm(rs), lwb, vc)
+    ref.backward()
+    rsg = rs.detach().to(DEV).requires_grad_()
+    got = M.er_loss(rc.to(DEV), rsg, lwb.to(DEV), vc)
+    got.backward()
+    close(got, float(ref), 1e-5); close(rsg.grad, rs.grad, 2e-5)
+    # k larger than the number of non-zero entries (the production regime) and k > row length (must raise)
+    big = M.er_loss(rc.to(DEV), rsg, lwb.to(DEV), 40)
+    refbig = O.er_loss(O.cam_softmaxnorm(rc), O.cam_softmaxnorm(rs), lwb, 40)
+    close(big, float(refbig), 1e-5)
+    with pytest.raises(RuntimeError):
+        M.er_loss(rc.to(DEV), rsg, lwb.to(DEV), 200)
+
+
+def test_adam_golden():
+    import muscle_amd as M
+    w = torch.nn.Parameter(T(synth.normal(SEED, "adam.w", (33,)).astype(np.float32)).to(DEV))
+    w2 = torch.nn.Parameter(T(synth.normal(SEED, "adam.w2", (5,)).astype(np.float32)).to(DEV))
+    o = M.FusedAdam([w, w2], lr=1e-4, weight_decay=5e-5)
+    for stp in range(3):
+        w.grad = T(synth.normal(SEED, f"adam.g{stp}", (33,)).astype(np.float32)).to(DEV)
+        w2.grad = None if stp == 1 else T(synth.normal(SEED, f"adam.h{stp}", (5,)).astype(np.float32)).to(DEV)
+        o.step()
+        close(torch.cat([w.detach(), w2.detach()]), U["adam_traj"][stp], 1e-6)
+
+
+# ---- the loop body against the reference's own step outputs ---------------------------------------------
+PHASE1 = ["step_b0_ep0.npz", "step_b0_ep4.npz", "step_b0_ep4_imc0.npz", "step_b7_ep4.npz"]
+
+
+@pytest.mark.parametrize("fname", PHASE1)
+@pytest.mark.parametrize("imc_sync", [False, True])
+def test_mcl_step_phase1_golden(fname, imc_sync):
+    import muscle_amd as M
+    G = gu.load(fname)
+    name = str(G["name"]); n, size, view, ep, seed, tseed = (int(v) for v in G["meta"])
+    cfg, sd, model = build(name, seed)
+    opt = M.FusedAdam(model.parameters(), lr=float(G["lr"]), weight_decay=5e-5)
+    b = {k: T(v).to(DEV) for k, v in synth.synth_batch(n, size, view, seed).items()}
+    du = {int(i): T(u).to(DEV) for i, u in zip(G["drop_idx"], G["drop_u"])}
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    out = M.mcl_step(model, opt, b, ep, drop_u=du, imc_sync=imc_sync)
+    names = ("loss_focal", "loss_softmargin", "loss_pair", "loss_er", "loss_imc", "loss_pixpro", "loss_emd")
+    got = np.array([float(out[k]) for k in names])
+    assert np.all(np.abs(got - G["losses"]) <= 1e-4 * np.maximum(np.abs(G["losses"]), 1e-3)), (got, G["losses"])
+    if imc_sync:
+        assert torch.is_tensor(out["loss_imc"]) == bool(G["loss_is_tensor"][0]) or ep < 4
+    keys = [str(k) for k in G["param_keys"]]
+    named = dict(model.named_parameters())
+    assert keys == list(named.keys())
+    g = gu.tensor_summary([(k, named[k].grad) for k in keys])
+    ref = G["grad1"]
+    assert np.array_equal(np.isnan(g[:, 0]), np.isnan(ref[:, 0]))          # same set of parameters without gradient
+    live = ~np.isnan(ref[:, 0])
+    scale = np.maximum(ref[live, :1], 1e-3 * ref[live, 0].max())
+    assert np.all(np.abs(g[live] - ref[live]) <= 3e-3 * scale), np.abs((g[live] - ref[live]) / scale).max()
+    # Adam: parameters without gradient untouched; the others moved by ~lr (first step = lr * sign(g))
+    for k in keys:
+        d = (named[k].detach() - before[k]).abs().max().item()
+        if np.isnan(ref[keys.index(k), 0]):
+            assert d == 0.0, k
+        else:
+            assert d <= 1.01 * float(G["lr"]) + 1e-9, (k, d)
+    dl = gu.tensor_summary([(k, named[k].detach() - before[k]) for k in keys])
+    refd = G["delta1"]
+    big = live & (ref[:, 0] > 1e-2 * ref[live, 0].max())                    # well-conditioned tensors: same update
+    assert np.all(np.abs(dl[big, 0] - refd[big, 0]) <= 2e-2 * refd[big, 0])
+    bn = np.array([[float(v.double().sum()), float(model.state_dict()[k.replace("running_mean", "running_var")].double().sum())]
+                   for k, v in model.state_dict().items() if k.endswith("running_mean")])
+    close(bn, G["bn_after"], 1e-4)

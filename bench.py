@@ -1,0 +1,211 @@
+#!/usr/bin/env python
+"""bench.py — images/sec of the MCL training step on MI355X (contract: see the task's bench section).
+
+    python bench.py [--gpus N --steps K --warmup W] [--model efficientnet-b7 --batch 32 --size 448 --epoch 4]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One "step" = one iteration of the train_mcl.py loop body (muscle_amd.mcl_step) on a synthetic batch that is
+already resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects:
+  roofline     — dominant kernel family (fp32-MFMA pointwise GEMMs), timed live with HIP events on the launch stream
+  cpu_baseline — the CPU oracle (oracle/mcl_oracle.py, a port of the reference) timed on this host, N=1 only
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from muscle_amd import arch, synth  # noqa: E402
+
+GEMM_CALLS = ("mx_pw_fwd", "mx_pw_dgrad", "mx_pw_wgrad")
+MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+
+
+def make_batch(n, size, view, seed, dev):
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    c1, c2, _ = synth.synth_coords(n, view, 2 * view, seed)
+    return {
+        "img": torch.randn(n, 3, size, size, device=dev, generator=g),
+        "view1": torch.randn(n, 3, view, view, device=dev, generator=g),
+        "view2": torch.randn(n, 3, view, view, device=dev, generator=g),
+        "label": torch.from_numpy(synth.synth_labels(n, seed)).to(dev),
+        "coord1": torch.from_numpy(c1).to(dev),
+        "coord2": torch.from_numpy(c2).to(dev),
+    }
+
+
+class GemmTimer:
+    """HIP events around every pointwise-GEMM launch, recorded on the stream the kernel is enqueued on."""
+
+    def __init__(self):
+        self.pairs = []
+        self.on = False
+
+    def install(self):
+        from muscle_amd import _lib
+        inner = _lib.call
+        me = self
+
+        def timed(name, *a):
+            if me.on and name in GEMM_CALLS:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                inner(name, *a)
+                e1.record()
+                me.pairs.append((e0, e1))
+            else:
+                inner(name, *a)
+
+        from muscle_amd import ops, loss_multilabel, train_step
+        for mod in (_lib, ops, loss_multilabel, train_step):
+            if hasattr(mod, "call"):
+                mod.call = timed
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs), len(self.pairs)
+
+
+def pointwise_flops_per_image(cfg, size):
+    m = arch.forward_macs(cfg, size)
+    stem_h = cfg.stem_out_size(size)
+    stem = 28 * cfg.stem_out * stem_h * stem_h          # stem runs as a K=28 GEMM (27 taps + pad)
+    # forward + data gradient + weight gradient, 2 flop per MAC; the stem has no data gradient
+    return 6 * m["pointwise"] + 4 * stem
+
+
+def cpu_baseline(model_name, size, view, ep, seconds_budget=25.0):
+    """The oracle (a CPU port of the reference's loop body) on this host's cores; bounded sample."""
+    from oracle import mcl_oracle as O
+    n = 2
+    cfg = arch.net_cfg(model_name, False)
+    torch.manual_seed(0)
+    net = O.OracleNet(model_name, synth.synth_state_dict(cfg, 0))
+    opt = O.OracleAdam(net.parameters())
+    b = {k: torch.from_numpy(v) for k, v in synth.synth_batch(n, size, view, 0).items()}
+    b["label"][1] = b["label"][0]
+    times = []
+    t_start = time.time()
+    for i in range(4):
+        t0 = time.time()
+        O.mcl_step(net, opt, b, ep)
+        times.append(time.time() - t0)
+        if i >= 1 and time.time() - t_start > seconds_budget:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    sec = sum(timed) / len(timed)
+    return {"value": n / sec, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(timed)} timed steps (1 warm-up) of the same loop body, {model_name} {size}x{size}, batch {n}, "
+                      f"epoch-{ep} semantics, oracle/mcl_oracle.py on torch-CPU fp32, {sec:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--model", default="efficientnet-b7")
+    ap.add_argument("--batch", type=int, default=32, help="per-GPU batch")
+    ap.add_argument("--size", type=int, default=448)
+    ap.add_argument("--epoch", type=int, default=4, help="epoch gate semantics of train_mcl.py (4: cls+ER+IMC)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    import muscle_amd
+    from muscle_amd.dist import GradAverager, broadcast_parameters
+    cfg = arch.net_cfg(a.model, False)
+    torch.manual_seed(0)
+    model = muscle_amd.MuSCLe(21, a.model, layers=3, last_pooling=False).to(dev)
+    broadcast_parameters(model)
+    opt = muscle_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=5e-5)
+    view = a.size // 2
+    batch = make_batch(a.batch, a.size, view, 1000 + rank, dev)
+    vc = int(batch["label"].sum().item())
+    hook = GradAverager() if world > 1 else None
+    timer = GemmTimer()
+    timer.install()
+
+    def step():
+        return muscle_amd.mcl_step(model, opt, batch, a.epoch, valid_channel=vc, grad_hook=hook)
+
+    for _ in range(a.warmup):
+        step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    timer.on = (rank == 0)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        out = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    timer.on = False
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    imgs = a.batch * world * a.steps
+    gemm_ms, gemm_launches = timer.total_ms()
+    flops = pointwise_flops_per_image(cfg, a.size) * a.batch * a.steps
+    achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
+    res = {
+        "metric": "images/sec (whole node), MCL EfficientNet-B7 448x448 bs=32/GPU" if (a.model, a.size, a.batch) == ("efficientnet-b7", 448, 32)
+        else f"images/sec (whole node), MCL {a.model} {a.size}x{a.size} bs={a.batch}/GPU",
+        "value": imgs / dt, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"train_mcl.py loop body, step-A (epoch-{a.epoch} gates: focal+softmargin+pairwise+ER"
+                               f"{'+IMC' if a.epoch >= 4 else ''}, one backward, one Adam step), MuSCLe({a.model}, "
+                               f"last_pooling=False, 21 classes), random-init weights",
+                   "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
+                   "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused"},
+        "losses": {k: (float(v) if torch.is_tensor(v) else v) for k, v in out.items()},
+        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 pointwise convs: fwd+dgrad+wgrad, stem)",
+                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
+                     "launches_per_step": gemm_launches // max(a.steps, 1),
+                     "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
+                     "time_share_of_step": gemm_ms * 1e-3 / dt,
+                     "algorithmic_gflop_per_image": pointwise_flops_per_image(cfg, a.size) / 1e9},
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        res["cpu_baseline"] = cpu_baseline(a.model, a.size, view, a.epoch)
+    print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -105,10 +105,10 @@ int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift,
 int mx_se_fwd(const float* pooled_sum, float inv_hw, const float* W1, const float* b1, const float* W2, const float* b2,
               float* s, float* h, float* gate, int N, int C, int SQ, void* stream);
 
-/* given ggate[n,c] = dL/dgate: add[n,c] = (dL/ds)[n,c]*inv_hw; dW1,db1,dW2,db2 += */
+/* given ggate[n,c] = dL/dgate: add[n,c] = (dL/ds)[n,c]*inv_hw; dW1,db1,dW2,db2 +=; gh_scratch: N*SQ floats */
 int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W1, const float* W2,
-              float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, int N, int C, int SQ,
-              void* stream);
+              float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, float* gh_scratch, int N, int C,
+              int SQ, void* stream);
 
 /* out[(n,oy,ox), ci*9+ky*3+kx] = img[n,ci,oy*2-pad+ky,ox*2-pad+kx] (NCHW image), rows of 28 floats (27 + 0) */
 int mx_stem_im2col(const float* img, float* out, int N, int H, int W, int Ho, int Wo, int pad_lo, void* stream);

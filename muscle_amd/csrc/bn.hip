@@ -22,13 +22,14 @@ struct ColGeom {
   int rps;                // rows per sample
 };
 
-static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that one block may span at most*/) {
+static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that one block may span at most*/,
+                        int groups = 1 /*independent row ranges (samples) sharing the grid*/) {
   ColGeom g;
   g.rows = (int)rows; g.C = C; g.c4 = C / 4; g.rps = rps;
   g.tcols = g.c4 < 256 ? g.c4 : 256;
   g.rpp = 256 / g.tcols;
   int colchunks = cdiv(g.c4, g.tcols);
-  long target_blocks = 2048 / colchunks;
+  long target_blocks = 2048 / ((long)colchunks * groups);
   if (target_blocks < 1) target_blocks = 1;
   long rpb = (rows_limit + target_blocks - 1) / target_blocks;
   if (rpb < 4L * g.rpp) rpb = 4L * g.rpp;
@@ -58,7 +59,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
   }
   float4 a0 = make_float4(0, 0, 0, 0), a1 = make_float4(0, 0, 0, 0);
   if (tid < used && c4 < g.c4) {
-    for (long r = r0 + tr; r < r1; r += g.rpp) f.eval(r, 4 * c4, a0, a1);
+    long r = r0 + tr;
+    const long st = g.rpp;
+    float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, c0 = b0, c1 = b0, d0 = b0, d1 = b0;
+    for (; r + 3 * st < r1; r += 4 * st) {       // four independent rows in flight
+      f.eval(r, 4 * c4, a0, a1);
+      f.eval(r + st, 4 * c4, b0, b1);
+      f.eval(r + 2 * st, 4 * c4, c0, c1);
+      f.eval(r + 3 * st, 4 * c4, d0, d1);
+    }
+    for (; r < r1; r += st) f.eval(r, 4 * c4, a0, a1);
+    a0.x += b0.x + c0.x + d0.x; a0.y += b0.y + c0.y + d0.y; a0.z += b0.z + c0.z + d0.z; a0.w += b0.w + c0.w + d0.w;
+    a1.x += b1.x + c1.x + d1.x; a1.y += b1.y + c1.y + d1.y; a1.z += b1.z + c1.z + d1.z; a1.w += b1.w + c1.w + d1.w;
   }
   sm[0][tid] = a0;
   sm[1][tid] = a1;
@@ -82,7 +94,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
 
 template <class F, int NOUT, bool PER_SAMPLE, typename OutT>
 static void launch_colreduce(const F& f, long rows, int C, int rps, OutT* o0, OutT* o1, hipStream_t st) {
-  ColGeom g = col_geom(rows, C, rps, PER_SAMPLE ? rps : rows);
+  ColGeom g = col_geom(rows, C, rps, PER_SAMPLE ? rps : rows, PER_SAMPLE ? (int)(rows / rps) : 1);
   dim3 grid(cdiv(PER_SAMPLE ? rps : rows, g.rows_per_block), cdiv(g.c4, g.tcols), PER_SAMPLE ? (int)(rows / rps) : 1);
   hipLaunchKernelGGL((colreduce_kernel<F, NOUT, PER_SAMPLE, OutT>), grid, dim3(256), 0, st, f, g, o0, o1);
 }

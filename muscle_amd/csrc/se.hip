@@ -4,82 +4,98 @@
 // Reference: MBConvBlock.forward, src/efficientnet_pytorch/model.py:81-84:
 //   s = avgpool(x); h = se_reduce(s) (+bias); r = swish(h); e = se_expand(r) (+bias); x = sigmoid(e) * x
 // The pooling itself is mx_pool_sum (bn.hip); here the pooled sums arrive as [N,C] and are scaled by
-// 1/HW.  One workgroup per sample: the matrices are tiny (C <= 3840, squeeze <= 160), the job is
-// latency-bound, so wave-shuffle dot products straight from L2 are enough.
+// 1/HW.  The matrices are tiny (C <= 3840, squeeze <= 160) and the job is latency-bound, so the work is cut
+// into (sample, output) pieces that fill the chip, with wave-shuffle dot products straight from L2; weight
+// gradients are owned per channel (no atomics).
 #include "common.h"
 
 constexpr int SQ_MAX = 256;
 
-// gate[n,c] = sigmoid(W2[c,:] . swish(W1 s + b1) + b2[c]);  saves s (mean) and h (pre-activation)
-__global__ __launch_bounds__(256) void se_fwd_kernel(const float* pooled, float inv_hw, const float* W1, const float* b1,
-                                                     const float* W2, const float* b2, float* s_out, float* h_out,
-                                                     float* gate, int C, int SQ) {
-  __shared__ float r[SQ_MAX];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ---- forward: two launches so the grid has >> 256 workgroups even for N = 32 ------------------------
+// h[n,j] = W1[j,:] . s[n,:] + b1[j]   (one wave per (n,j); s = pooled_sum * inv_hw, also written out)
+__global__ __launch_bounds__(256) void se_fwd_reduce_kernel(const float* pooled, float inv_hw, const float* W1, const float* b1,
+                                                            float* s_out, float* h_out, int C, int SQ) {
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.y * 4 + wave;
   const float* ps = pooled + (long)n * C;
-  for (int c = tid; c < C; c += 256) s_out[(long)n * C + c] = ps[c] * inv_hw;
-  for (int j = wave; j < SQ; j += 4) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) acc += W1[(long)j * C + c] * (ps[c] * inv_hw);
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float h = acc + b1[j];
-      h_out[(long)n * SQ + j] = h;
-      r[j] = swishf_(h);
-    }
-  }
+  if (blockIdx.y == 0)
+    for (int c = threadIdx.x; c < C; c += 256) s_out[(long)n * C + c] = ps[c] * inv_hw;
+  if (j >= SQ) return;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) acc += W1[(long)j * C + c] * ps[c];
+  acc = wave_sum(acc) * inv_hw;
+  if (lane == 0) h_out[(long)n * SQ + j] = acc + b1[j];
+}
+
+// gate[n,c] = sigmoid(W2[c,:] . swish(h[n,:]) + b2[c])
+__global__ __launch_bounds__(256) void se_fwd_expand_kernel(const float* h, const float* W2, const float* b2, float* gate, int C,
+                                                            int SQ) {
+  __shared__ float r[SQ_MAX];
+  const int n = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
+  for (int j = threadIdx.x; j < SQ; j += 256) r[j] = swishf_(h[(long)n * SQ + j]);
   __syncthreads();
-  for (int c = tid; c < C; c += 256) {
-    float acc = b2[c];
-    for (int j = 0; j < SQ; ++j) acc += W2[(long)c * SQ + j] * r[j];
-    gate[(long)n * C + c] = sigmoidf_(acc);
+  if (c >= C) return;
+  float acc = b2[c];
+  const float* w = W2 + (long)c * SQ;
+  for (int j = 0; j < SQ; ++j) acc += w[j] * r[j];
+  gate[(long)n * C + c] = sigmoidf_(acc);
+}
+
+// ---- backward --------------------------------------------------------------------------------------
+// (A) ge[n,c] = ggate*gate*(1-gate) (written to `add` as scratch); g_r[n,j] = sum_c ge[n,c] W2[c,j];
+//     gh[n,j] = g_r * swish'(h); db1[j] += gh.   One wave per (n,j).
+__global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* ggate, const float* gate, const float* h, const float* W2,
+                                                       float* gh, float* db1, int C, int SQ) {
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = blockIdx.y * 4 + wave;
+  if (j >= SQ) return;
+  const float* gg = ggate + (long)n * C;
+  const float* gt = gate + (long)n * C;
+  float acc = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    float g = gt[c];
+    acc += gg[c] * g * (1.f - g) * W2[(long)c * SQ + j];
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    float v = acc * swish_gradf_(h[(long)n * SQ + j]);
+    gh[(long)n * SQ + j] = v;
+    unsafeAtomicAdd(db1 + j, v);
   }
 }
 
-// backward of the excitation path for one sample.
-//   in : ggate[n,c] = sum_hw dA[n,hw,c] * act[n,hw,c]   (gradient w.r.t. the gate)
-//   out: add[n,c]   = (dL/ds)[n,c] / HW                 (pooled-path gradient, broadcast over hw)
-//        dW1,db1,dW2,db2 += ...
-__global__ __launch_bounds__(256) void se_bwd_kernel(const float* ggate, const float* gate, const float* s, const float* h,
-                                                     const float* W1, const float* W2, float inv_hw, float* add,
-                                                     float* dW1, float* db1, float* dW2, float* db2, int C, int SQ) {
-  __shared__ float r[SQ_MAX], gh[SQ_MAX];
-  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* gg = ggate + (long)n * C;
-  const float* gt = gate + (long)n * C;
-  const float* sn = s + (long)n * C;
-  for (int j = tid; j < SQ; j += 256) r[j] = swishf_(h[(long)n * SQ + j]);
+// (B) per channel c (one thread): db2[c] += sum_n ge; dW2[c,j] += sum_n ge[n,c] r[n,j];
+//     dW1[j,c] += sum_n gh[n,j] s[n,c];  add[n,c] = inv_hw * sum_j gh[n,j] W1[j,c].   No atomics: c is owned.
+__global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* ggate, const float* gate, const float* s, const float* h,
+                                                       const float* gh, const float* W1, float inv_hw, float* add, float* dW1,
+                                                       float* dW2, float* db2, int N, int C, int SQ) {
+  extern __shared__ float sh[];          // r[N][SQ], ghs[N][SQ]
+  float* r = sh;
+  float* ghs = sh + (long)N * SQ;
+  for (int i = threadIdx.x; i < N * SQ; i += 256) { r[i] = swishf_(h[i]); ghs[i] = gh[i]; }
   __syncthreads();
-  // g_e[c] = ggate*gate*(1-gate); dW2[c,j] += g_e[c]*r[j]; db2[c] += g_e[c]
-  for (int c = tid; c < C; c += 256) {
-    float g = gt[c];
-    float ge = gg[c] * g * (1.f - g);
-    unsafeAtomicAdd(db2 + c, ge);
-    for (int j = 0; j < SQ; ++j) unsafeAtomicAdd(dW2 + (long)c * SQ + j, ge * r[j]);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    float g = gate[(long)n * C + c];
+    sb += ggate[(long)n * C + c] * g * (1.f - g);
   }
-  // g_r[j] = sum_c g_e[c] * W2[c,j];  g_h = g_r * swish'(h)
-  for (int j = wave; j < SQ; j += 4) {
+  db2[c] += sb;
+  for (int j = 0; j < SQ; ++j) {
+    float a2 = 0.f, a1 = 0.f;
+    for (int n = 0; n < N; ++n) {
+      float g = gate[(long)n * C + c];
+      float ge = ggate[(long)n * C + c] * g * (1.f - g);
+      a2 += ge * r[n * SQ + j];
+      a1 += ghs[n * SQ + j] * s[(long)n * C + c];
+    }
+    dW2[(long)c * SQ + j] += a2;
+    dW1[(long)j * C + c] += a1;
+  }
+  for (int n = 0; n < N; ++n) {
     float acc = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      float g = gt[c];
-      acc += gg[c] * g * (1.f - g) * W2[(long)c * SQ + j];
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) {
-      float v = acc * swish_gradf_(h[(long)n * SQ + j]);
-      gh[j] = v;
-      unsafeAtomicAdd(db1 + j, v);
-    }
-  }
-  __syncthreads();
-  // dW1[j,c] += g_h[j]*s[c];  g_s[c] = sum_j g_h[j]*W1[j,c]
-  for (int c = tid; c < C; c += 256) {
-    float sc = sn[c], acc = 0.f;
-    for (int j = 0; j < SQ; ++j) {
-      float v = gh[j];
-      acc += v * W1[(long)j * C + c];
-      unsafeAtomicAdd(dW1 + (long)j * C + c, v * sc);
-    }
+    for (int j = 0; j < SQ; ++j) acc += ghs[n * SQ + j] * W1[(long)j * C + c];
     add[(long)n * C + c] = acc * inv_hw;
   }
 }
@@ -118,19 +134,27 @@ int mx_se_fwd(const float* pooled_sum, float inv_hw, const float* W1, const floa
               float* s, float* h, float* gate, int N, int C, int SQ, void* stream) {
   MX_CHECK_ARG(pooled_sum && W1 && b1 && W2 && b2 && s && h && gate, "se_fwd: null pointer");
   MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_fwd: bad extents N=%d C=%d SQ=%d", N, C, SQ);
-  hipLaunchKernelGGL(se_fwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, pooled_sum, inv_hw, W1, b1, W2, b2, s, h,
-                     gate, C, SQ);
+  hipLaunchKernelGGL(se_fwd_reduce_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, pooled_sum, inv_hw, W1, b1,
+                     s, h, C, SQ);
+  hipLaunchKernelGGL(se_fwd_expand_kernel, dim3(N, cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, h, W2, b2, gate, C, SQ);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
 int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W1, const float* W2,
-              float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, int N, int C, int SQ,
-              void* stream) {
+              float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, float* gh_scratch, int N, int C,
+              int SQ, void* stream) {
   MX_CHECK_ARG(ggate && gate && s && h && W1 && W2 && add && dW1 && db1 && dW2 && db2, "se_bwd: null pointer");
   MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd: bad extents N=%d C=%d SQ=%d", N, C, SQ);
-  hipLaunchKernelGGL(se_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, ggate, gate, s, h, W1, W2, inv_hw, add,
-                     dW1, db1, dW2, db2, C, SQ);
+  MX_CHECK_ARG(gh_scratch != nullptr, "se_bwd: gh_scratch [N*SQ] required");
+  size_t shb = (size_t)2 * N * SQ * sizeof(float);
+  MX_CHECK_ARG(shb <= 160 * 1024, "se_bwd: N*SQ=%d too large for LDS staging", N * SQ);
+  if (shb > 48 * 1024)
+    hipFuncSetAttribute((const void*)se_bwd_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb);
+  hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
+                     C, SQ);
+  hipLaunchKernelGGL(se_bwd_b_kernel, dim3(cdiv(C, 256)), dim3(256), shb, (hipStream_t)stream, ggate, gate, s, h, gh_scratch, W1,
+                     inv_hw, add, dW1, dW2, db2, N, C, SQ);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

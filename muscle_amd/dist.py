@@ -1,0 +1,40 @@
+"""Data parallelism for the MCL step: one process per GPU, gradient averaging with RCCL over xGMI.
+
+The reference is single-GPU; the semantics fixed in SURVEY.md §8(e) are: replica-local
+BatchNorm statistics, replica-local losses (IMC pairs, ER k, EMD matching), one gradient average per
+optimizer step.  MuSCLe's backward leaves all live gradients in ONE flat fp32 arena
+(`model.last_grad_sink.arena`), so the exchange is a single large all-reduce (248.8 MB for B7) with no
+bucketing logic and no unused-parameter bookkeeping: dead parameters are simply not in the arena.
+"""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+class GradAverager:
+    """grad_hook for muscle_amd.mcl_step: averages the flat gradient arena across ranks."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bytes_reduced = 0
+
+    def __call__(self, model, phase: int):
+        if self.world == 1:
+            return
+        arena = model.last_grad_sink.arena
+        if arena.is_cuda:
+            dist.all_reduce(arena, op=dist.ReduceOp.AVG, group=self.group)
+        else:                                      # gloo (CPU tests) has no AVG
+            dist.all_reduce(arena, op=dist.ReduceOp.SUM, group=self.group)
+            arena.div_(self.world)
+        self.bytes_reduced += arena.numel() * 4
+
+
+def broadcast_parameters(model, src: int = 0, group=None):
+    """Make every replica start from rank `src`'s parameters and buffers."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(model.parameters()) + list(model.buffers()):
+        dist.broadcast(t.data, src=src, group=group)

@@ -163,8 +163,9 @@ def se_bwd(ggate, gate, s, h, W1, W2, inv_hw, dW1, db1, dW2, db2):
     N, C = ggate.shape
     SQ = W1.shape[0]
     add = torch.empty_like(ggate)
+    gh = torch.empty_like(h)
     call("mx_se_bwd", ptr(ggate), ptr(gate), ptr(s), ptr(h), ptr(W1), ptr(W2), float(inv_hw), ptr(add), ptr(dW1), ptr(db1),
-         ptr(dW2), ptr(db2), N, C, SQ, stream())
+         ptr(dW2), ptr(db2), ptr(gh), N, C, SQ, stream())
     return add
 
 

@@ -172,6 +172,36 @@ int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsi
 int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
             float weight_decay, float bias_corr1, float sqrt_bias_corr2, void* stream);
 
+/* ---- phase 2 (epochs >= 8 / >= 12): cam_maxnorm, PixPro, crops, Sinkhorn EMD ------------------------------------ */
+
+/* cam_maxnorm (train_mcl.py:21-28) per (n,k) plane of HW elements; stats[nk] = {min, max, argmin, argmax};
+ * bwd != 0: out = d/dx given gy (gradient also flows through the min / max elements, as torch's does) */
+int mx_maxnorm(const float* x, const float* gy, float* out, float* stats, int NK, long HW, int bwd, void* stream);
+
+/* PixPro (loss_multilabel.py:93-105) on NCHW maps (optionally multiplied by mask[n,k], train_mcl.py:209); coords are
+ * int64 [N,4] = (h0,w0,hl,wl).  loss must hold 1.0 and g1 zeros on entry; g1 = d loss / d f1. */
+int mx_pixpro(const float* f1, const float* f2, const float* mask, const long* coord1, const long* coord2, float* loss, float* g1,
+              int N, int K, int H, int W, void* stream);
+
+/* F.normalize(x, dim=1) on NCHW (train_mcl.py:218-219) and its backward */
+int mx_chan_l2norm(const float* x, const float* gy, float* out, int N, int K, long HW, int bwd, void* stream);
+
+/* torchutils.get_dynamic_crops (torchutils.py:217-291) pieces.  table rows of 8 ints {sample,y0,x0,lh,lw,rh,rw,out_off}:
+ * out[out_off + r*rw + c, 0..23] = bilinear_align_corners(src[sample,:,y0:y0+lh,x0:x0+lw] -> (rh,rw)), 21 classes + 0 pad */
+int mx_crop_resize(const float* src, const int* table, int ncrops, float* out, int K, int H, int W, void* stream);
+int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* gsrc, int K, int H, int W, void* stream);
+/* 4x4/stride-4 average pool over packed crops; table rows of 4 ints {in_off,h,w,out_off}; bwd: in = pooled grad */
+int mx_avgpool4(const float* in, const int* table, int ncrops, float* out, int bwd, void* stream);
+
+/* EMD.dynamic_matching (loss_multilabel.py:287-326).  pairs rows of 6 ints {x_off,n1,y_off,n2,sample,0};
+ * scores: Sinkhorn distance of every pair; best: first minimal pair per sample, loss += mean of their scores;
+ * grad: gx[crop-1 pixels of each best pair] = d loss / d x (through the 10 iterations), scaled by gscale*(gup?gup[0]:1);
+ * traj: nsamples*(11*(maxn1+maxn2)) floats scratch */
+int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, int maxn2, float* score, void* stream);
+int mx_emd_best(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss, void* stream);
+int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsamples, int maxn1, int maxn2, float* traj,
+                const float* gup, float gscale, float* gx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,549 @@
+// Phase-2 kernels of the MCL step (epochs >= 8 / >= 12): cam_maxnorm, PixPro, channel L2 normalisation,
+// dynamic crop extraction and the Sinkhorn-EMD matching.
+//
+// Reference: train_mcl.py:21-28 (cam_maxnorm), src/loss_multilabel.py:93-105 (PixPro),
+// F.normalize(dim=1) at train_mcl.py:218-219, src/torchutils.py:217-291 (get_dynamic_crops: window crop,
+// bilinear(align_corners=True) resize, 4x4 average pool), src/loss_multilabel.py:201-257,287-326 (EMD.dynamic_matching:
+// cost 1 - x.y, weights, 10 log-domain Sinkhorn iterations, min-score pair re-evaluated with gradient).
+// Crop features are packed as [pixels, 24] fp32 rows (21 classes + 3 zeros) so a cost entry is six float4 FMAs;
+// the cost matrix itself is never stored.
+#include "common.h"
+
+constexpr int FP = 24;   // padded feature width
+
+// ---------------------------------------------------------------------------
+// cam_maxnorm: y = relu((relu(x) - mn - 1e-6) / (mx - mn + 1e-6)), mn/mx over HW per (n,k)
+// stats[nk] = {mn, mx, argmin, argmax} (indices stored as float bit patterns of ints)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxnorm_fwd_kernel(const float* x, float* y, float* stats, long HW) {
+  __shared__ float smn[4], smx[4];
+  __shared__ int simn[4], simx[4];
+  const long nk = blockIdx.x;
+  const float* xp = x + nk * HW;
+  float mn = INFINITY, mx = -INFINITY;
+  int imn = 0x7fffffff, imx = 0x7fffffff;
+  for (long i = threadIdx.x; i < HW; i += 256) {
+    float v = fmaxf(xp[i], 0.f);
+    if (v < mn) { mn = v; imn = (int)i; }
+    if (v > mx) { mx = v; imx = (int)i; }
+  }
+  // wave reduce keeping the lowest index on ties
+  for (int o = 32; o > 0; o >>= 1) {
+    float omn = __shfl_xor(mn, o, 64), omx = __shfl_xor(mx, o, 64);
+    int oimn = __shfl_xor(imn, o, 64), oimx = __shfl_xor(imx, o, 64);
+    if (omn < mn || (omn == mn && oimn < imn)) { mn = omn; imn = oimn; }
+    if (omx > mx || (omx == mx && oimx < imx)) { mx = omx; imx = oimx; }
+  }
+  const int wave = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { smn[wave] = mn; smx[wave] = mx; simn[wave] = imn; simx[wave] = imx; }
+  __syncthreads();
+  mn = smn[0]; mx = smx[0]; imn = simn[0]; imx = simx[0];
+  for (int w = 1; w < 4; ++w) {
+    if (smn[w] < mn || (smn[w] == mn && simn[w] < imn)) { mn = smn[w]; imn = simn[w]; }
+    if (smx[w] > mx || (smx[w] == mx && simx[w] < imx)) { mx = smx[w]; imx = simx[w]; }
+  }
+  const float inv = 1.f / (mx - mn + 1e-6f);
+  for (long i = threadIdx.x; i < HW; i += 256) y[nk * HW + i] = fmaxf((fmaxf(xp[i], 0.f) - mn - 1e-6f) * inv, 0.f);
+  if (threadIdx.x == 0) {
+    stats[nk * 4 + 0] = mn; stats[nk * 4 + 1] = mx;
+    stats[nk * 4 + 2] = __int_as_float(imn); stats[nk * 4 + 3] = __int_as_float(imx);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxnorm_bwd_kernel(const float* x, const float* stats, const float* gy, float* gx, long HW) {
+  __shared__ float red[2][4];
+  const long nk = blockIdx.x;
+  const float* xp = x + nk * HW;
+  const float* gp = gy + nk * HW;
+  const float mn = stats[nk * 4], mx = stats[nk * 4 + 1];
+  const int imn = __float_as_int(stats[nk * 4 + 2]), imx = __float_as_int(stats[nk * 4 + 3]);
+  const float d = mx - mn + 1e-6f, inv = 1.f / d;
+  float s1 = 0.f, s2 = 0.f;   // sum g_u/d , sum g_u*(r-mn-1e-6)/d^2
+  for (long i = threadIdx.x; i < HW; i += 256) {
+    float r = fmaxf(xp[i], 0.f);
+    float num = r - mn - 1e-6f;
+    float gu = (num > 0.f) ? gp[i] : 0.f;
+    s1 += gu * inv;
+    s2 += gu * num * inv * inv;
+    gx[nk * HW + i] = (xp[i] > 0.f) ? gu * inv : 0.f;
+  }
+  s1 = wave_sum(s1); s2 = wave_sum(s2);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s1; red[1][threadIdx.x >> 6] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s1 = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    s2 = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    float gmn = -s1 + s2, gmx = -s2;     // d/d mn, d/d mx
+    if (xp[imn] > 0.f) gx[nk * HW + imn] += gmn;
+    if (xp[imx] > 0.f) gx[nk * HW + imx] += gmx;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// PixPro: loss = 1 - mean_n mean_window cos(m*f1, m*f2) over the channel dim; g1 = d loss / d f1
+// loss buffer must hold 1.0 on entry; g1 must be zero-filled.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pixpro_kernel(const float* f1, const float* f2, const float* mask, const long* c1,
+                                                     const long* c2, float* loss, float* g1, int N, int K, int H, int W) {
+  const int n = blockIdx.y;
+  const long h1 = c1[n * 4], w1 = c1[n * 4 + 1], hl = c1[n * 4 + 2], wl = c1[n * 4 + 3];
+  const long h2 = c2[n * 4], w2 = c2[n * 4 + 1];
+  const long HW = (long)H * W, cnt = hl * wl;
+  const float scale = 1.f / ((float)N * (float)cnt);
+  float acc = 0.f;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < cnt; p += (long)gridDim.x * 256) {
+    long i = p / wl, j = p % wl;
+    const float* a = f1 + (long)n * K * HW + (h1 + i) * W + (w1 + j);
+    const float* b = f2 + (long)n * K * HW + (h2 + i) * W + (w2 + j);
+    float av[32], bv[32];
+    float dot = 0.f, na = 0.f, nb = 0.f;
+    for (int k = 0; k < K; ++k) {
+      float m = mask ? mask[n * K + k] : 1.f;
+      av[k] = a[k * HW] * m; bv[k] = b[k * HW] * m;
+      dot += av[k] * bv[k]; na += av[k] * av[k]; nb += bv[k] * bv[k];
+    }
+    na = sqrtf(na); nb = sqrtf(nb);
+    float nac = fmaxf(na, 1e-8f), nbc = fmaxf(nb, 1e-8f);
+    float cs = dot / (nac * nbc);
+    acc += cs;
+    float* g = g1 + (long)n * K * HW + (h1 + i) * W + (w1 + j);
+    for (int k = 0; k < K; ++k) {
+      float m = mask ? mask[n * K + k] : 1.f;
+      float gv = bv[k] / (nac * nbc);
+      if (na > 1e-8f) gv -= cs * av[k] / (na * na);
+      g[k * HW] = -gv * scale * m;
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) atomicAdd(loss, -acc * scale);
+}
+
+// ---------------------------------------------------------------------------
+// F.normalize(x, dim=1) on NCHW: y = x / max(||x||_2, 1e-12); bwd: gx = (gy - y (y.gy)) / max(||x||, eps)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void chan_l2norm_kernel(const float* x, const float* gy, float* out, int N, int K, long HW, int bwd) {
+  const long total = (long)N * HW;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    long n = i / HW, p = i - n * HW;
+    const float* xb = x + n * K * HW + p;
+    float v[32];
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) { v[k] = xb[k * HW]; s += v[k] * v[k]; }
+    float nr = fmaxf(sqrtf(s), 1e-12f), inv = 1.f / nr;
+    float* ob = out + n * K * HW + p;
+    if (!bwd) {
+      for (int k = 0; k < K; ++k) ob[k * HW] = v[k] * inv;
+    } else {
+      const float* gb = gy + n * K * HW + p;
+      float g[32], dot = 0.f;
+      for (int k = 0; k < K; ++k) { g[k] = gb[k * HW]; dot += g[k] * v[k] * inv; }
+      for (int k = 0; k < K; ++k) ob[k * HW] = (g[k] - v[k] * inv * dot) * inv;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// crops.  One table row (8 ints) per crop: {sample, y0, x0, lh, lw, rh, rw, out_offset(pixels)}:
+// out[off + (r*rw + c), k] = bilinear_align_corners(src[sample, k, y0:y0+lh, x0:x0+lw] -> (rh, rw))
+// (rh == lh and rw == lw is the identity crop used for the second view)
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bil_coord2(int d, int in, int out, int& i0, int& i1, float& w1) {
+  float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  float s = scale * d;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  w1 = s - i0;
+}
+
+__global__ __launch_bounds__(256) void crop_resize_kernel(const float* src, const int* table, float* out, int K, int H, int W) {
+  const int* t = table + blockIdx.x * 8;
+  const int n = t[0], y0 = t[1], x0 = t[2], lh = t[3], lw = t[4], rh = t[5], rw = t[6], off = t[7];
+  const long HW = (long)H * W;
+  for (int p = threadIdx.x; p < rh * rw; p += 256) {
+    int r = p / rw, c = p % rw;
+    int ya, yb, xa, xb;
+    float wy, wx;
+    bil_coord2(r, lh, rh, ya, yb, wy);
+    bil_coord2(c, lw, rw, xa, xb, wx);
+    const float* b = src + (long)n * K * HW;
+    float* o = out + ((long)off + p) * FP;
+    for (int k = 0; k < FP; ++k) {
+      float v = 0.f;
+      if (k < K) {
+        const float* q = b + k * HW;
+        float a00 = q[(long)(y0 + ya) * W + x0 + xa], a01 = q[(long)(y0 + ya) * W + x0 + xb];
+        float a10 = q[(long)(y0 + yb) * W + x0 + xa], a11 = q[(long)(y0 + yb) * W + x0 + xb];
+        v = (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
+      }
+      o[k] = v;
+    }
+  }
+}
+
+// adjoint, one block per crop of the table: gsrc[n,k,...] += W^T gout[off ...]
+__global__ __launch_bounds__(256) void crop_resize_bwd_kernel(const float* gout_all, const int* table, float* gsrc, int K, int H, int W) {
+  const int* trow = table + blockIdx.x * 8;
+  const int n = trow[0], y0 = trow[1], x0 = trow[2], lh = trow[3], lw = trow[4], rh = trow[5], rw = trow[6];
+  const float* gout = gout_all + (long)trow[7] * FP;
+  const long HW = (long)H * W;
+  for (int p = threadIdx.x; p < rh * rw; p += 256) {
+    int r = p / rw, c = p % rw;
+    int ya, yb, xa, xb;
+    float wy, wx;
+    bil_coord2(r, lh, rh, ya, yb, wy);
+    bil_coord2(c, lw, rw, xa, xb, wx);
+    for (int k = 0; k < K; ++k) {
+      float g = gout[(long)p * FP + k];
+      if (g == 0.f) continue;
+      float* q = gsrc + (long)n * K * HW + k * HW;
+      unsafeAtomicAdd(q + (long)(y0 + ya) * W + x0 + xa, (1.f - wy) * (1.f - wx) * g);
+      unsafeAtomicAdd(q + (long)(y0 + ya) * W + x0 + xb, (1.f - wy) * wx * g);
+      unsafeAtomicAdd(q + (long)(y0 + yb) * W + x0 + xa, wy * (1.f - wx) * g);
+      unsafeAtomicAdd(q + (long)(y0 + yb) * W + x0 + xb, wy * wx * g);
+    }
+  }
+}
+
+// 4x4 average pool (stride 4, floor) over packed crops.  table row (4 ints): {in_off, h, w, out_off}
+__global__ __launch_bounds__(256) void avgpool4_kernel(const float* in, const int* table, float* out, int bwd) {
+  const int* t = table + blockIdx.x * 4;
+  const int ioff = t[0], h = t[1], w = t[2], ooff = t[3];
+  const int ph = h / 4, pw = w / 4;
+  if (!bwd) {
+    for (int i = threadIdx.x; i < ph * pw * FP; i += 256) {
+      int k = i % FP, p = i / FP;
+      int r = p / pw, c = p % pw;
+      float s = 0.f;
+      for (int a = 0; a < 4; ++a)
+        for (int b = 0; b < 4; ++b) s += in[((long)ioff + (4 * r + a) * w + 4 * c + b) * FP + k];
+      out[((long)ooff + p) * FP + k] = s * (1.f / 16.f);
+    }
+  } else {   // reads the pooled crop's gradient (at out_off), writes the unpooled crop's gradient (at in_off)
+    for (int i = threadIdx.x; i < h * w * FP; i += 256) {
+      int k = i % FP, p = i / FP;
+      int r = p / w, c = p % w;
+      float v = 0.f;
+      if (r / 4 < ph && c / 4 < pw) v = in[((long)ooff + (r / 4) * pw + c / 4) * FP + k] * (1.f / 16.f);
+      out[((long)ioff + p) * FP + k] = v;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Sinkhorn EMD.  pair table row (6 ints): {x_off, n1, y_off, n2, sample, reserved}
+// ---------------------------------------------------------------------------
+constexpr int EMD_MAXP = 1024;   // max pixels per crop
+constexpr float EMD_REG = 0.1f;
+constexpr int EMD_ITERS = 10;
+
+struct F24 { float4 a, b, c, d, e, f; };
+__device__ __forceinline__ F24 ld24(const float* p) {
+  F24 r; r.a = ld4(p); r.b = ld4(p + 4); r.c = ld4(p + 8); r.d = ld4(p + 12); r.e = ld4(p + 16); r.f = ld4(p + 20); return r;
+}
+__device__ __forceinline__ float dot4(float4 x, float4 y) { return x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w; }
+__device__ __forceinline__ float dot24(const F24& x, const float* y) {
+  return dot4(x.a, ld4(y)) + dot4(x.b, ld4(y + 4)) + dot4(x.c, ld4(y + 8)) + dot4(x.d, ld4(y + 12)) + dot4(x.e, ld4(y + 16)) +
+         dot4(x.f, ld4(y + 20));
+}
+
+// shared layout: xs[n1*24], ys[n2*24], u[n1], v[n2], lmu[n1], lnu[n2], tmp[max(n1,n2)]
+// One Jacobi iteration: both updates use the same (u, v) (loss_multilabel.py:215-217).
+__device__ void emd_iterate(const float* xs, const float* ys, float* u, float* v, const float* lmu, const float* lnu, float* tmp,
+                            int n1, int n2) {
+  const float ir = 1.f / EMD_REG;
+  // rows: tmp_i = reg*(lmu_i - LSE_j M_ij) + u_i
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+    F24 xi = ld24(xs + i * FP);
+    float ui = u[i], m = -INFINITY, s = 0.f;
+    for (int j = 0; j < n2; ++j) {
+      float M = (dot24(xi, ys + j * FP) - 1.f + ui + v[j]) * ir;
+      if (M > m) { s = s * __expf(m - M) + 1.f; m = M; } else s += __expf(M - m);
+    }
+    tmp[i] = EMD_REG * (lmu[i] - (m + __logf(s))) + ui;
+  }
+  __syncthreads();
+  // columns (use OLD u): v_j' = reg*(lnu_j - LSE_i M_ij) + v_j, written in place after the sweep
+  float vn[(EMD_MAXP + 255) / 256];
+  int cnt = 0;
+  for (int j = threadIdx.x; j < n2; j += blockDim.x, ++cnt) {
+    F24 yj = ld24(ys + j * FP);
+    float vj = v[j], m = -INFINITY, s = 0.f;
+    for (int i = 0; i < n1; ++i) {
+      float M = (dot24(yj, xs + i * FP) - 1.f + u[i] + vj) * ir;
+      if (M > m) { s = s * __expf(m - M) + 1.f; m = M; } else s += __expf(M - m);
+    }
+    vn[cnt] = EMD_REG * (lnu[j] - (m + __logf(s))) + vj;
+  }
+  __syncthreads();
+  cnt = 0;
+  for (int j = threadIdx.x; j < n2; j += blockDim.x, ++cnt) v[j] = vn[cnt];
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) u[i] = tmp[i];
+  __syncthreads();
+}
+
+__device__ void emd_setup(const float* X, const float* Y, float* xs, float* ys, float* u, float* v, float* lmu, float* lnu,
+                          float* tmp, int n1, int n2) {
+  for (int i = threadIdx.x; i < n1 * FP; i += blockDim.x) xs[i] = X[i];
+  for (int i = threadIdx.x; i < n2 * FP; i += blockDim.x) ys[i] = Y[i];
+  __syncthreads();
+  // weights (get_weight_vector, :250-257): mu_i = x_i . mean(y), nu_j = y_j . mean(x); tmp[0..23], tmp[24..47] hold the means
+  if (threadIdx.x < 2 * FP) {
+    int k = threadIdx.x % FP;
+    const float* src = (threadIdx.x < FP) ? ys : xs;
+    int n = (threadIdx.x < FP) ? n2 : n1;
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += src[i * FP + k];
+    tmp[threadIdx.x] = s / n;
+  }
+  __syncthreads();
+  float my[FP], mx[FP];
+  for (int k = 0; k < FP; ++k) { my[k] = tmp[k]; mx[k] = tmp[FP + k]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < FP; ++k) s += xs[i * FP + k] * my[k];
+    lmu[i] = __logf(s + 1e-6f);
+    u[i] = 0.f;
+  }
+  for (int j = threadIdx.x; j < n2; j += blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < FP; ++k) s += ys[j * FP + k] * mx[k];
+    lnu[j] = __logf(s + 1e-6f);
+    v[j] = 0.f;
+  }
+  __syncthreads();
+}
+
+// sum_ij exp(M_ij) * C_ij / (n1*n2)
+__device__ float emd_distance(const float* xs, const float* ys, const float* u, const float* v, float* tmp, int n1, int n2) {
+  const float ir = 1.f / EMD_REG;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+    F24 xi = ld24(xs + i * FP);
+    for (int j = 0; j < n2; ++j) {
+      float c = 1.f - dot24(xi, ys + j * FP);
+      acc += __expf((-c + u[i] + v[j]) * ir) * c;
+    }
+  }
+  acc = wave_sum(acc);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  float t = 0.f;
+  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += tmp[w];
+  return t / ((float)n1 * (float)n2);
+}
+
+__global__ __launch_bounds__(256) void emd_score_kernel(const float* feat, const int* pairs, float* score) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int* t = pairs + blockIdx.x * 6;
+  const int n1 = t[1], n2 = t[3];
+  float* xs = sh; float* ys = xs + n1 * FP; float* u = ys + n2 * FP; float* v = u + n1; float* lmu = v + n2;
+  float* lnu = lmu + n1; float* tmp = lnu + n2;
+  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, xs, ys, u, v, lmu, lnu, tmp, n1, n2);
+  for (int it = 0; it < EMD_ITERS; ++it) emd_iterate(xs, ys, u, v, lmu, lnu, tmp, n1, n2);
+  float d = emd_distance(xs, ys, u, v, tmp, n1, n2);
+  if (threadIdx.x == 0) score[blockIdx.x] = d;
+}
+
+// best[s] = index of the first minimal-score pair of sample s (stable sort semantics, :318); loss += score/ns
+__global__ void emd_best_kernel(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nsamples) return;
+  int bi = -1;
+  float bs = INFINITY;
+  for (int p = 0; p < npairs; ++p)
+    if (pairs[p * 6 + 4] == s && score[p] < bs) { bs = score[p]; bi = p; }
+  best[s] = bi;
+  if (bi >= 0) atomicAdd(loss, bs / nsamples);
+}
+
+// backward through the 10 iterations for the best pair of each sample: gx[best crop1 pixels, 24] = d dist / d x * gscale
+// traj: per block (EMD_ITERS+1) * (n1 + n2) floats of (u_t, v_t), in global scratch
+__global__ __launch_bounds__(256) void emd_grad_kernel(const float* feat, const int* pairs, const int* best, float* traj,
+                                                       long traj_stride, const float* gup, float gscale, float* gx) {
+  extern __shared__ __attribute__((aligned(16))) float sh[];
+  const int bi = best[blockIdx.x];
+  if (bi < 0) return;
+  if (gup) gscale *= gup[0];
+  const int* t = pairs + bi * 6;
+  const int n1 = t[1], n2 = t[3];
+  float* xs = sh; float* ys = xs + n1 * FP; float* u = ys + n2 * FP; float* v = u + n1; float* lmu = v + n2;
+  float* lnu = lmu + n1; float* tmp = lnu + n2;
+  float* ub = tmp + (n1 > n2 ? n1 : n2);   // adjoint of u  [n1]
+  float* vb = ub + n1;                      // adjoint of v  [n2]
+  float* tr = traj + blockIdx.x * traj_stride;
+  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, xs, ys, u, v, lmu, lnu, tmp, n1, n2);
+  const int nn = n1 + n2;
+  for (int it = 0; it <= EMD_ITERS; ++it) {
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) tr[it * nn + i] = u[i];
+    for (int j = threadIdx.x; j < n2; j += blockDim.x) tr[it * nn + n1 + j] = v[j];
+    if (it < EMD_ITERS) emd_iterate(xs, ys, u, v, lmu, lnu, tmp, n1, n2);
+  }
+  __syncthreads();
+  const float ir = 1.f / EMD_REG, inv12 = 1.f / ((float)n1 * (float)n2);
+  // per-thread gradient accumulators for the rows it owns
+  float gxl[(EMD_MAXP + 255) / 256][FP];
+  for (int q = 0; q < (EMD_MAXP + 255) / 256; ++q)
+    for (int k = 0; k < FP; ++k) gxl[q][k] = 0.f;
+  // final stage: Mbar_ij = pi_ij * Cd_ij / (n1 n2); Cbar += -Mbar/reg (the explicit Cd factor is detached); ubar_i = sum_j Mbar/reg ...
+  {
+    int q = 0;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x, ++q) {
+      F24 xi = ld24(xs + i * FP);
+      float us = 0.f;
+      for (int j = 0; j < n2; ++j) {
+        float c = 1.f - dot24(xi, ys + j * FP);
+        float mb = __expf((-c + u[i] + v[j]) * ir) * c * inv12 * ir;   // Mbar / reg
+        us += mb;
+        // Cbar_ij = -mb ; dC/dx_i = -y_j  ->  gx_i += mb * y_j
+        for (int k = 0; k < FP; ++k) gxl[q][k] += mb * ys[j * FP + k];
+      }
+      ub[i] = us;
+    }
+    for (int j = threadIdx.x; j < n2; j += blockDim.x) {
+      F24 yj = ld24(ys + j * FP);
+      float vs = 0.f;
+      for (int i = 0; i < n1; ++i) {
+        float c = 1.f - dot24(yj, xs + i * FP);
+        vs += __expf((-c + u[i] + v[j]) * ir) * c * inv12 * ir;
+      }
+      vb[j] = vs;
+    }
+    __syncthreads();
+  }
+  for (int it = EMD_ITERS - 1; it >= 0; --it) {
+    const float* ut = tr + it * nn;
+    const float* vt = ut + n1;
+    const float* un = tr + (it + 1) * nn;
+    const float* vn = un + n1;
+    // P_ij = exp(M_ij - rowLSE_i), rowLSE_i = lmu_i - (u'_i - u_i)/reg ; Q_ij = exp(M_ij - colLSE_j)
+    // Cbar_ij += ub'_i P_ij + vb'_j Q_ij  ->  gx_i -= (...) y_j ; ub_i = -sum_j vb'_j Q_ij ; vb_j = -sum_i ub'_i P_ij
+    int q = 0;
+    for (int i = threadIdx.x; i < n1; i += blockDim.x, ++q) {
+      F24 xi = ld24(xs + i * FP);
+      const float rl = lmu[i] - (un[i] - ut[i]) * ir, ubi = ub[i];
+      float nu_ = 0.f;
+      for (int j = 0; j < n2; ++j) {
+        float M = (dot24(xi, ys + j * FP) - 1.f + ut[i] + vt[j]) * ir;
+        float P = __expf(M - rl);
+        float Q = __expf(M - (lnu[j] - (vn[j] - vt[j]) * ir));
+        float cb = ubi * P + vb[j] * Q;
+        nu_ -= vb[j] * Q;
+        for (int k = 0; k < FP; ++k) gxl[q][k] -= cb * ys[j * FP + k];
+      }
+      tmp[i] = nu_;
+    }
+    float vnew[(EMD_MAXP + 255) / 256];
+    int c2 = 0;
+    for (int j = threadIdx.x; j < n2; j += blockDim.x, ++c2) {
+      F24 yj = ld24(ys + j * FP);
+      float acc = 0.f;
+      for (int i = 0; i < n1; ++i) {
+        float M = (dot24(yj, xs + i * FP) - 1.f + ut[i] + vt[j]) * ir;
+        acc -= ub[i] * __expf(M - (lmu[i] - (un[i] - ut[i]) * ir));
+      }
+      vnew[c2] = acc;
+    }
+    __syncthreads();
+    c2 = 0;
+    for (int j = threadIdx.x; j < n2; j += blockDim.x, ++c2) vb[j] = vnew[c2];
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) ub[i] = tmp[i];
+    __syncthreads();
+  }
+  int q = 0;
+  for (int i = threadIdx.x; i < n1; i += blockDim.x, ++q)
+    for (int k = 0; k < FP; ++k) gx[((long)t[0] + i) * FP + k] = gxl[q][k] * gscale;
+}
+
+static int gs(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
+
+extern "C" {
+
+int mx_maxnorm(const float* x, const float* gy, float* out, float* stats, int NK, long HW, int bwd, void* stream) {
+  MX_CHECK_ARG(x && out && stats && NK > 0 && HW > 0 && HW < 0x7fffffff && (!bwd || gy), "maxnorm: bad args");
+  if (!bwd) hipLaunchKernelGGL(maxnorm_fwd_kernel, dim3(NK), dim3(256), 0, (hipStream_t)stream, x, out, stats, HW);
+  else hipLaunchKernelGGL(maxnorm_bwd_kernel, dim3(NK), dim3(256), 0, (hipStream_t)stream, x, stats, gy, out, HW);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_pixpro(const float* f1, const float* f2, const float* mask, const long* coord1, const long* coord2, float* loss, float* g1,
+              int N, int K, int H, int W, void* stream) {
+  MX_CHECK_ARG(f1 && f2 && coord1 && coord2 && loss && g1 && N > 0 && K > 0 && K <= 32 && H > 0 && W > 0, "pixpro: bad args");
+  hipLaunchKernelGGL(pixpro_kernel, dim3(cdiv((long)H * W, 256), N), dim3(256), 0, (hipStream_t)stream, f1, f2, mask, coord1, coord2,
+                     loss, g1, N, K, H, W);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_chan_l2norm(const float* x, const float* gy, float* out, int N, int K, long HW, int bwd, void* stream) {
+  MX_CHECK_ARG(x && out && N > 0 && K > 0 && K <= 32 && HW > 0 && (!bwd || gy), "chan_l2norm: bad args");
+  hipLaunchKernelGGL(chan_l2norm_kernel, dim3(gs((long)N * HW)), dim3(256), 0, (hipStream_t)stream, x, gy, out, N, K, HW, bwd);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_crop_resize(const float* src, const int* table, int ncrops, float* out, int K, int H, int W, void* stream) {
+  MX_CHECK_ARG(src && table && out && ncrops > 0 && K > 0 && K <= FP, "crop_resize: bad args");
+  hipLaunchKernelGGL(crop_resize_kernel, dim3(ncrops), dim3(256), 0, (hipStream_t)stream, src, table, out, K, H, W);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* gsrc, int K, int H, int W, void* stream) {
+  MX_CHECK_ARG(gout && table && gsrc && ncrops > 0 && K > 0 && K <= FP, "crop_resize_bwd: bad args");
+  hipLaunchKernelGGL(crop_resize_bwd_kernel, dim3(ncrops), dim3(256), 0, (hipStream_t)stream, gout, table, gsrc, K, H, W);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_avgpool4(const float* in, const int* table, int ncrops, float* out, int bwd, void* stream) {
+  MX_CHECK_ARG(in && table && out && ncrops > 0, "avgpool4: bad args");
+  hipLaunchKernelGGL(avgpool4_kernel, dim3(ncrops), dim3(256), 0, (hipStream_t)stream, in, table, out, bwd);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+static size_t emd_lds(int maxn1, int maxn2, int grad) {
+  size_t f = (size_t)(maxn1 + maxn2) * FP + 2 * (size_t)(maxn1 + maxn2) + (size_t)(maxn1 > maxn2 ? maxn1 : maxn2);
+  if (f < (size_t)(maxn1 + maxn2) * FP + 2 * (size_t)(maxn1 + maxn2) + 2 * FP) f += 2 * FP;
+  if (grad) f += (size_t)(maxn1 + maxn2);
+  return f * sizeof(float);
+}
+
+int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, int maxn2, float* score, void* stream) {
+  MX_CHECK_ARG(feat && pairs && score && npairs > 0, "emd_scores: bad args");
+  MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_scores: crop larger than %d pixels", EMD_MAXP);
+  size_t sh = emd_lds(maxn1 < 2 * FP ? 2 * FP : maxn1, maxn2 < 2 * FP ? 2 * FP : maxn2, 0);
+  MX_CHECK_ARG(sh <= 160 * 1024, "emd_scores: LDS need %zu exceeds 160 KiB", sh);
+  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  hipLaunchKernelGGL(emd_score_kernel, dim3(npairs), dim3(256), sh, (hipStream_t)stream, feat, pairs, score);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_emd_best(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss, void* stream) {
+  MX_CHECK_ARG(score && pairs && best && loss && npairs > 0 && nsamples > 0, "emd_best: bad args");
+  hipLaunchKernelGGL(emd_best_kernel, dim3(cdiv(nsamples, 64)), dim3(64), 0, (hipStream_t)stream, score, pairs, npairs, nsamples, best,
+                     loss);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsamples, int maxn1, int maxn2, float* traj,
+                const float* gup, float gscale, float* gx, void* stream) {
+  MX_CHECK_ARG(feat && pairs && best && traj && gx && nsamples > 0, "emd_grad: bad args");
+  MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_grad: crop larger than %d pixels", EMD_MAXP);
+  size_t sh = emd_lds(maxn1 < 2 * FP ? 2 * FP : maxn1, maxn2 < 2 * FP ? 2 * FP : maxn2, 1);
+  MX_CHECK_ARG(sh <= 160 * 1024, "emd_grad: LDS need %zu exceeds 160 KiB", sh);
+  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
+  hipLaunchKernelGGL(emd_grad_kernel, dim3(nsamples), dim3(256), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
+                     gx);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,106 @@
+"""GPU parity of phase 2 (PixPro, cam_maxnorm, dynamic crops, Sinkhorn EMD, second optimizer step) against the
+reference's own fixtures (tests/golden) and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from muscle_amd import synth
+from muscle_amd.arch import net_cfg
+from test_gpu_model import build, close, DEV, T, U, SEED
+
+pytestmark = pytest.mark.gpu
+
+
+def test_maxnorm_golden_and_backward():
+    import muscle_amd as M
+    from oracle import mcl_oracle as O
+    cam = T(synth.normal(SEED, "cam", (2, 21, 9, 11)).astype(np.float32))
+    x = cam.to(DEV).requires_grad_()
+    y = M.cam_maxnorm(x)
+    close(y, U["cam_maxnorm"], 1e-5)
+    g = T(synth.normal(SEED, "mn.g", (2, 21, 9, 11)).astype(np.float32))
+    y.backward(g.to(DEV))
+    c2 = cam.clone().requires_grad_()
+    O.cam_maxnorm(c2).backward(g)
+    close(x.grad, c2.grad, 5e-5)
+    # strictly positive maps: the gradient through the min / max elements matters
+    pos = (cam.abs() + 0.1)
+    x2 = pos.to(DEV).requires_grad_()
+    M.cam_maxnorm(x2).backward(g.to(DEV))
+    p2 = pos.clone().requires_grad_()
+    O.cam_maxnorm(p2).backward(g)
+    close(x2.grad, p2.grad, 5e-5)
+
+
+def test_pixpro_golden():
+    import muscle_amd as M
+    f1 = T(synth.uniform(SEED, "pp.1", (3, 21, 20, 20)).astype(np.float32)).to(DEV).requires_grad_()
+    f2 = T(synth.uniform(SEED, "pp.2", (3, 21, 20, 20)).astype(np.float32))
+    f2[0, :, 3:5, 3:5] = 0
+    c1, c2, _ = synth.synth_coords(3, 20, 40, SEED)
+    l = M.PixPro(f1, f2.to(DEV), T(c1), T(c2))
+    l.backward()
+    close(l, U["pixpro"], 1e-5); close(f1.grad, U["pixpro_d1"], 2e-5)
+
+
+def test_dynamic_crops_and_emd_golden():
+    import muscle_amd as M
+    v = 64
+    x1 = torch.nn.functional.normalize(T(synth.uniform(SEED, "dc.1", (3, 21, v, v)).astype(np.float32)), dim=1).to(DEV).requires_grad_()
+    x2 = torch.nn.functional.normalize(T(synth.uniform(SEED, "dc.2", (3, 21, v, v)).astype(np.float32)), dim=1).to(DEV)
+    c1, c2 = T(U["dc_coord1"]), T(U["dc_coord2"])
+    for replay in ("recorded", "np.random"):
+        if replay == "recorded":
+            cr1, cr2, bidx = M.get_dynamic_crops(x1, c1, x2, c2, gu.geometry_from_draws(U["dc_coord1"], U["dc_draws"]))
+        else:
+            np.random.seed(9)
+            cr1, cr2, bidx = M.get_dynamic_crops(x1, c1, x2, c2)
+        assert bidx == U["dc_bidx"].tolist()
+        assert [[i, *c.shape[2:]] for i in range(len(cr1)) for c in cr1[i]] == U["dc_shapes1"].tolist()
+        assert [[i, *c.shape[2:]] for i in range(len(cr2)) for c in cr2[i]] == U["dc_shapes2"].tolist()
+        close(np.array([float(c.double().sum()) for i in range(len(cr1)) for c in cr1[i]]), U["dc_sums1"], 2e-5)
+        close(np.array([float(c.double().sum()) for i in range(len(cr2)) for c in cr2[i]]), U["dc_sums2"], 2e-5)
+    l = M.EMD()(cr1, cr2, mode="dynamic")
+    l.backward()
+    close(l, U["emd"], 1e-4); close(x1.grad, U["emd_dx1"], 2e-3)
+
+
+PHASE2 = [("step_b0_ep12_lr0.npz", 1e-4), ("step_b3_ep12_lr0.npz", 1e-4), ("step_b0_ep12.npz", 5e-3), ("step_b3_ep12.npz", 5e-3)]
+
+
+@pytest.mark.parametrize("fname,ptol", PHASE2)
+def test_mcl_step_full_golden(fname, ptol):
+    import muscle_amd as M
+    G = gu.load(fname)
+    name = str(G["name"]); n, size, view, ep, seed, tseed = (int(v) for v in G["meta"])
+    cfg, sd, model = build(name, seed)
+    lr = float(G["lr"])
+    b = {k: T(v).to(DEV) for k, v in synth.synth_batch(n, size, view, seed).items()}
+    # BN calibration pass (oracle/gen_golden.py calibrate_bn): train mode, momentum 1.0, drop draws of torch seed 7
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(b["view1"], cam="pix", drop_u={k: v.to(DEV) for k, v in gu.drop_draws(cfg, n, 7).items()})
+    for m in bns:
+        m.momentum = 0.01
+    opt = M.FusedAdam(model.parameters(), lr=lr, weight_decay=5e-5)
+    du = {int(i): T(u).to(DEV) for i, u in zip(G["drop_idx"], G["drop_u"])}
+    geo = gu.geometry_from_draws(b["coord1"].cpu().numpy(), G["crop_draws"])
+    out = M.mcl_step(model, opt, b, ep, drop_u=du, crop_geom=geo, imc_sync=True)
+    names = ("loss_focal", "loss_softmargin", "loss_pair", "loss_er", "loss_imc", "loss_pixpro", "loss_emd")
+    got = np.array([float(out[k]) for k in names])
+    tol = np.array([1e-4] * 5 + [ptol, max(ptol, 2e-4)])
+    assert np.all(np.abs(got - G["losses"]) <= tol * np.maximum(np.abs(G["losses"]), 1e-3)), (got, G["losses"])
+    assert [torch.is_tensor(out[k]) for k in names[4:]] == G["loss_is_tensor"].tolist()
+    keys = [str(k) for k in G["param_keys"]]
+    named = dict(model.named_parameters())
+    g = gu.tensor_summary([(k, named[k].grad) for k in keys])      # gradients of the second backward
+    ref = G["grad2"]
+    assert np.array_equal(np.isnan(g[:, 0]), np.isnan(ref[:, 0]))  # fc.weight has no gradient in 'pix' mode
+    live = ~np.isnan(ref[:, 0])
+    scale = np.maximum(ref[live, :1], 1e-3 * ref[live, 0].max())
+    gtol = 3e-3 if lr == 0 else 5e-2
+    assert np.all(np.abs(g[live] - ref[live]) <= gtol * scale), np.abs((g[live] - ref[live]) / scale).max()

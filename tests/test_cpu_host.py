@@ -1,0 +1,143 @@
+"""CPU-only checks: the C ABI library loads and exports every symbol of include/muscle_hip.h, the module's
+state_dict matches the reference key contract, host-side logic (arch tables, crop planning, gating) and the
+data-parallel hook over gloo with two ranks.  No kernel is launched here."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from muscle_amd import _lib, arch, synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    sigs = _lib.parse_header()
+    assert len(sigs) >= 40
+    if not os.path.exists(_lib.LIB_PATH):
+        from muscle_amd import _build
+        _build.build(verbose=False)
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    for name in list(sigs) + ["mx_last_error"]:
+        assert hasattr(L, name), name
+    L.mx_version.restype = ctypes.c_int
+    assert L.mx_version() >= 100
+    # argument errors are reported before any launch (no GPU needed)
+    LL = _lib.lib()
+    rc = LL.mx_colstats(None, 0, 0, None, None)
+    assert rc < 0 and b"colstats" in LL.mx_last_error()
+
+
+def test_header_cites_reference_lines():
+    text = open(_lib.HEADER_PATH).read()
+    for cite in ("model.py", "utils.py", "MuSCLe.py", "loss_multilabel.py", "train_mcl.py", "torchutils.py"):
+        assert cite in text
+
+
+@pytest.mark.parametrize("name", ["efficientnet-b0", "efficientnet-b3", "efficientnet-b7"])
+def test_state_dict_contract(name):
+    import muscle_amd
+    cfg = arch.net_cfg(name, False)
+    m = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)
+    spec = synth.state_dict_spec(cfg)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(spec.keys())
+    for k, shp in spec.items():
+        assert tuple(sd[k].shape) == tuple(shp), k
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state_dict(cfg, 1).items()}, strict=True)
+    live = {id(p) for p in m.live_parameters("cam")}
+    dead = [k for k, p in m.named_parameters() if id(p) not in live]
+    assert dead == ["backbone._conv_head.weight", "backbone._bn1.weight", "backbone._bn1.bias", "backbone._fc.weight",
+                    "backbone._fc.bias", "fuse_dec.weight", "fuse_dec.bias"]
+    assert all(id(p) in live for p in m.live_parameters("pix"))
+    assert id(m.fc.weight) not in {id(p) for p in m.live_parameters("pix")}
+
+
+def test_no_cpu_fallback():
+    import muscle_amd
+    m = muscle_amd.MuSCLe(21, "efficientnet-b0", last_pooling=False)
+    with pytest.raises(_lib.MuscleHipError):
+        m(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(_lib.MuscleHipError):
+        muscle_amd.FocalLoss()(torch.rand(2, 20), torch.zeros(2, 20))
+    with pytest.raises(NotImplementedError):
+        muscle_amd.MuSCLe(21, "efficientnet-b0", mode="dec")
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "muscle_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src = open(os.path.join(pkg, f)).read()
+            assert "import oracle" not in src and "from oracle" not in src and "oracle." not in src, f
+
+
+def test_arch_tables_match_reference_fixture():
+    # shapes of every block output as the reference produced them (forward_b0/b3 fixtures)
+    for fname, size in (("forward_b0.npz", 64), ("forward_b3.npz", 64)):
+        G = gu.load(fname)
+        cfg = arch.net_cfg(str(G["name"]), False)
+        h = cfg.stem_out_size(size)
+        for b, shp in zip(cfg.blocks, G["feat_shapes"]):
+            h = b.out_size(h)
+            assert [b.cout, h, h] == list(shp[1:]), b.index
+    cfg7 = arch.net_cfg("efficientnet-b7", False)
+    assert abs(arch.forward_macs(cfg7, 448)["total"] / 1e9 - 43.66) < 0.01
+    assert abs(arch.min_materialisation_bytes(cfg7, 448) / 1e9 - 2.152) < 0.001
+
+
+def test_crop_planning_matches_reference_draws():
+    from muscle_amd import phase2
+    U = gu.load("units.npz")
+    c1, c2 = torch.from_numpy(U["dc_coord1"]), torch.from_numpy(U["dc_coord2"])
+    np.random.seed(9)
+    plan = phase2._plan_crops(c1, c2, None)
+    assert plan.bidx == U["dc_bidx"].tolist()
+    assert [[i, h, w] for i, s in enumerate(plan.per1) for (_, h, w) in s] == U["dc_shapes1"].tolist()
+    assert [[i, h, w] for i, s in enumerate(plan.per2) for (_, h, w) in s] == U["dc_shapes2"].tolist()
+    plan2 = phase2._plan_crops(c1, c2, gu.geometry_from_draws(U["dc_coord1"], U["dc_draws"]))
+    assert plan2.pairs == plan.pairs and len(plan.pairs) == sum(len(a) * len(b) for a, b in zip(plan.per1, plan.per2))
+
+
+def test_synth_is_deterministic():
+    a = synth.synth_batch(4, 16, 8, 3)
+    b = synth.synth_batch(4, 16, 8, 3)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    lab = synth.synth_labels(32, 0)
+    assert lab.sum() <= 105 and (lab.sum(1) >= 1).all() and np.array_equal(lab[0], lab[1])
+
+
+_DP_WORKER = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, sys.argv[1])
+from muscle_amd.dist import GradAverager, broadcast_parameters
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+r = dist.get_rank()
+class Sink: pass
+class Model(torch.nn.Module):
+    def __init__(self):
+        super().__init__(); self.w = torch.nn.Parameter(torch.full((5,), float(r + 1))); self.register_buffer("b", torch.full((2,), float(r)))
+m = Model(); broadcast_parameters(m)
+assert torch.equal(m.w.data, torch.full((5,), 1.0)) and torch.equal(m.b, torch.zeros(2))
+m.last_grad_sink = Sink(); m.last_grad_sink.arena = torch.arange(8, dtype=torch.float32) * (r + 1)
+h = GradAverager(); h(m, 1)
+assert torch.allclose(m.last_grad_sink.arena, torch.arange(8, dtype=torch.float32) * 1.5), m.last_grad_sink.arena
+assert h.bytes_reduced == 32
+dist.destroy_process_group(); print("ok", r)
+'''
+
+
+def test_dp_hook_two_ranks_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_DP_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT) for r in range(2)]
+    outs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs

@@ -13,8 +13,11 @@
  *   - calls only enqueue work on `stream` (a hipStream_t passed as void*), never synchronise;
  *   - return 0 on success, a negative value for an argument error detected before launch, a positive
  *     hipError_t otherwise; mx_last_error() returns a thread-local message;
- *   - "+=" outputs accumulate (the caller zeroes them); they use fp32/fp64 hardware atomics, so their
- *     last bits depend on arrival order.
+ *   - "+=" outputs accumulate (the caller zeroes them); they use fp32 hardware atomics, so their last bits
+ *     depend on arrival order.  Per-channel BatchNorm statistics do NOT use atomics: producers write one
+ *     partial row per workgroup row into `part[P][2][C]` (P from the matching mx_*_parts() helper, no zeroing
+ *     needed) and the finalise entry points sum the P rows in fp64 (two levels: <= 64 row slices per channel chunk,
+ *     combined with fp64 atomics into the caller's acc[2C] scratch, then one thread per channel).
  *   - an operand "mode" selects the prologue applied while the operand is loaded:
  *        0 PLAIN   v = x
  *        1 BNACT   v = swish(scale[c]*x + shift[c]) * (gate ? gate[n,c] : 1)     n = row / rows_per_sample
@@ -32,10 +35,12 @@ const char* mx_last_error(void);
 
 /* ---- pointwise (1x1) convolutions on fp32 MFMA: model.py:44,63,77,86 ------------------------------ */
 
-/* C[M,N] = A'[M,K] * W[N,K]^T (+bias[N]) (+residual[M,ldc]) (relu); stats[2N] += column (sum, sum^2) of C. */
+/* C[M,N] = A'[M,K] * W[N,K]^T (+bias[N]) (+residual[M,ldc]) (relu); stats (optional) = partial column
+ * (sum, sum^2) rows part[mx_pw_fwd_parts(M,N,K)][2][N] of C. */
+int mx_pw_fwd_parts(int M, int N, int K);
 int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_shift, const float* a_gate,
               int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,
-              const float* bias, const float* residual, int relu, double* stats, void* stream);
+              const float* bias, const float* residual, int relu, float* stats, void* stream);
 
 /* dX[M,N] = G[M,K] * W[K,N] (+residual): data gradient of the 1x1 conv with weight W[K=Cout, N=Cin]. */
 int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, int ldg, int ldx,
@@ -52,28 +57,30 @@ int mx_bgemm(int layout, const float* A, const float* B, float* C, int M, int N,
 
 /* ---- BatchNorm2d (train / eval), SiLU, SE gate, drop_connect + skip: model.py:45-94, utils.py:36-91 -- */
 
-/* stats[2C] += (sum x, sum x^2) per channel */
-int mx_colstats(const float* X, long rows, int C, double* stats, void* stream);
+/* part[mx_colreduce_parts(rows,C)][2][C] = partial (sum x, sum x^2) per channel */
+int mx_colreduce_parts(long rows, int C);
+int mx_colstats(const float* X, long rows, int C, float* part, void* stream);
 
-/* training: batch mean / biased var from stats, running stats updated with `momentum` (unbiased var);
- * eval: running stats.  Writes scale = gamma*rstd, shift = beta - mean*scale, and saves mean, rstd. */
-int mx_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta, float* running_mean,
+/* training: batch mean / biased var from the P partial rows (summed in fp64), running stats updated with
+ * `momentum` (unbiased var); eval: running stats.  Writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd. */
+int mx_bn_finalize(const float* part, int P, int C, double count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
-                   float* mean, float* rstd, void* stream);
+                   float* mean, float* rstd, double* acc, void* stream);
 
 /* out = (scale[c]*P + shift[c]) [swish if act] [* row_scale[n]] [+ residual]   (BN2 + drop_connect + skip) */
 int mx_bn_apply(const float* P, const float* scale, const float* shift, const float* row_scale, const float* residual,
                 float* out, long rows, int C, int rows_per_sample, int act, void* stream);
 
 /* effective upstream gradient  g = G [* row_scale[n]] ; [g = g*gate[n,c] + gate_add[n,c]] ;
- * [g *= swish'(act_scale[c]*X + act_shift[c])] ;  sums[2C] += (sum g, sum g*X)  */
+ * [g *= swish'(act_scale[c]*X + act_shift[c])] ;  part[mx_colreduce_parts(rows,C)][2][C] = partial (sum g, sum g*X) */
 int mx_bn_bwd_reduce(const float* G, const float* X, const float* row_scale, const float* gate, const float* gate_add,
                      const float* act_scale, const float* act_shift, long rows, int C, int rows_per_sample,
-                     double* sums, void* stream);
+                     float* part, void* stream);
 
 /* dgamma += rstd*(sum gx - mean*sum g); dbeta += sum g; (c1,c2,c3) so that dX = c1*g + c2*X + c3 */
-int mx_bn_bwd_finalize(const double* sums, int C, double count, const float* gamma, const float* mean, const float* rstd,
-                       int training, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream);
+int mx_bn_bwd_finalize(const float* part, int P, int C, double count, const float* gamma, const float* mean, const float* rstd,
+                       int training, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, double* acc,
+                       void* stream);
 
 /* out = c1[c]*g + c2[c]*X + c3[c] with g as in mx_bn_bwd_reduce (out may alias G) */
 int mx_bn_bwd_apply(const float* G, const float* X, const float* row_scale, const float* gate, const float* gate_add,
@@ -87,8 +94,10 @@ int mx_pool_sum(const float* X, const float* G, const float* scale, const float*
 
 /* ---- depthwise k x k convolution, k in {3,5}, stride in {1,2}: model.py:50-52,78; utils.py:122-145 ---- */
 
-/* Y = dwconv(act(X)), act = swish(scale*x+shift) when scale != NULL; stats[2C] += (sum Y, sum Y^2) */
-int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, double* stats, int N,
+/* Y = dwconv(act(X)), act = swish(scale*x+shift) when scale != NULL; stats (optional) = partial (sum Y, sum Y^2)
+ * rows part[mx_dwconv_fwd_parts(N,Ho,Wo,S)][2][C] */
+int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S);
+int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats, int N,
                   int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
 
 /* dX = dwconv^T(dY) (+residual): gradient w.r.t. the activated input */

@@ -60,7 +60,7 @@ def lib() -> ctypes.CDLL:
         for name, codes in parse_header().items():
             fn = getattr(L, name)
             fn.restype = ctypes.c_int
-            fn.argtypes = [_C[c] for c in codes]
+            fn.argtypes = [_C[c] for c in codes]      # incl. the pure-host mx_*_parts() helpers
         _lib = L
     return _lib
 

@@ -82,14 +82,23 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
       s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w;
       s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
     }
-    const long o = (PER_SAMPLE ? (long)sample * g.C : 0) + 4 * c4;
-    unsafeAtomicAdd(out0 + o + 0, (OutT)s0.x); unsafeAtomicAdd(out0 + o + 1, (OutT)s0.y);
-    unsafeAtomicAdd(out0 + o + 2, (OutT)s0.z); unsafeAtomicAdd(out0 + o + 3, (OutT)s0.w);
-    if (NOUT > 1) {
-      unsafeAtomicAdd(out1 + o + 0, (OutT)s1.x); unsafeAtomicAdd(out1 + o + 1, (OutT)s1.y);
-      unsafeAtomicAdd(out1 + o + 2, (OutT)s1.z); unsafeAtomicAdd(out1 + o + 3, (OutT)s1.w);
+    if (PER_SAMPLE) {
+      const long o = (long)sample * g.C + 4 * c4;
+      unsafeAtomicAdd(out0 + o + 0, (OutT)s0.x); unsafeAtomicAdd(out0 + o + 1, (OutT)s0.y);
+      unsafeAtomicAdd(out0 + o + 2, (OutT)s0.z); unsafeAtomicAdd(out0 + o + 3, (OutT)s0.w);
+    } else {
+      // one partial row per row-block: part[blockIdx.x][2][C]; summed in fp64 by the finalise kernel.
+      // (contended fp64 atomics on 2C addresses ran at ~1/14 of the atomic rate and were not reproducible)
+      OutT* p0 = out0 + (long)blockIdx.x * 2 * g.C + 4 * c4;
+      p0[0] = s0.x; p0[1] = s0.y; p0[2] = s0.z; p0[3] = s0.w;
+      if (NOUT > 1) { OutT* p1 = p0 + g.C; p1[0] = s1.x; p1[1] = s1.y; p1[2] = s1.z; p1[3] = s1.w; }
     }
   }
+}
+
+static int colreduce_parts(long rows, int C) {
+  ColGeom g = col_geom(rows, C, 1, rows, 1);
+  return cdiv(rows, g.rows_per_block);
 }
 
 template <class F, int NOUT, bool PER_SAMPLE, typename OutT>
@@ -167,15 +176,56 @@ struct FPool {           // per-sample: sum act(x) ; optionally sum g*act(x)
 // ---------------------------------------------------------------------------
 // per-channel finalisation kernels (tiny)
 // ---------------------------------------------------------------------------
-__global__ void bn_finalize_kernel(const double* stats, int C, double count, const float* gamma, const float* beta,
-                                   float* rmean, float* rvar, float momentum, float eps, int training,
+// Two-level reduction of the partial rows part[P][2][C]: level 1 (this kernel, grid = channel chunks x row slices)
+// sums a slice of rows in fp64 and adds it into acc[2C] (fp64 atomics, <= 64 adders per address); level 2 is the
+// finalise kernel.  One block = 32 channels x 8 row lanes.
+__global__ __launch_bounds__(256) void bn_parts_reduce_kernel(const float* part, int P, int C, int rows_per_slice, double* acc) {
+  __shared__ double sh[2][8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  const int p0 = blockIdx.y * rows_per_slice, p1 = min(P, p0 + rows_per_slice);
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    int p = p0 + rl;
+    for (; p + 24 < p1; p += 32) {     // four rows in flight per thread
+      float a0 = part[(long)p * 2 * C + c], b0 = part[(long)p * 2 * C + C + c];
+      float a1 = part[(long)(p + 8) * 2 * C + c], b1 = part[(long)(p + 8) * 2 * C + C + c];
+      float a2 = part[(long)(p + 16) * 2 * C + c], b2 = part[(long)(p + 16) * 2 * C + C + c];
+      float a3 = part[(long)(p + 24) * 2 * C + c], b3 = part[(long)(p + 24) * 2 * C + C + c];
+      a += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      b += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; p < p1; p += 8) { a += (double)part[(long)p * 2 * C + c]; b += (double)part[(long)p * 2 * C + C + c]; }
+  }
+  sh[0][rl][cl] = a; sh[1][rl][cl] = b;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  for (int i = 1; i < 8; ++i) { a += sh[0][i][cl]; b += sh[1][i][cl]; }
+  unsafeAtomicAdd(acc + c, a);
+  unsafeAtomicAdd(acc + C + c, b);
+}
+
+static void launch_parts_reduce(const float* part, int P, int C, double* acc, hipStream_t st) {
+  int slices = P / 32;
+  if (slices < 1) slices = 1;
+  if (slices > 64) slices = 64;
+  int rps = (P + slices - 1) / slices;
+  slices = (P + rps - 1) / rps;
+  hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st);
+  hipLaunchKernelGGL(bn_parts_reduce_kernel, dim3(cdiv(C, 32), slices), dim3(256), 0, st, part, P, C, rps, acc);
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int C, double count, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
                                    float* scale, float* shift, float* mean_out, float* rstd_out) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
+  double st0 = 0.0, st1 = 0.0;
+  if (training) { st0 = acc[c]; st1 = acc[C + c]; }
   float mean, rstd;
   if (training) {
-    double m = stats[c] / count;
-    double var = stats[C + c] / count - m * m;
+    double m = st0 / count;
+    double var = st1 / count - m * m;
     if (var < 0) var = 0;
     mean = (float)m;
     rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -194,12 +244,12 @@ __global__ void bn_finalize_kernel(const double* stats, int C, double count, con
   rstd_out[c] = rstd;
 }
 
-__global__ void bn_bwd_finalize_kernel(const double* sums, int C, double count, const float* gamma, const float* mean,
-                                       const float* rstd, int training, float* dgamma, float* dbeta, float* c1,
-                                       float* c2, float* c3) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc, int C, double count, const float* gamma,
+                                       const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
+                                       float* c1, float* c2, float* c3) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  double sg = sums[c], sgx = sums[C + c];
+  const double sg = acc[c], sgx = acc[C + c];
   double m = mean[c], r = rstd[c], gm = gamma[c];
   double dg = r * (sgx - m * sg);
   dgamma[c] += (float)dg;
@@ -260,21 +310,27 @@ static int grid_for(long total4) {
 
 extern "C" {
 
-int mx_colstats(const float* X, long rows, int C, double* stats, void* stream) {
-  MX_CHECK_ARG(X && stats && rows > 0 && C > 0 && C % 4 == 0, "colstats: bad args rows=%ld C=%d", rows, C);
+int mx_colreduce_parts(long rows, int C) {
+  if (rows <= 0 || C <= 0 || C % 4) return MX_EARG;
+  return colreduce_parts(rows, C);
+}
+
+int mx_colstats(const float* X, long rows, int C, float* part, void* stream) {
+  MX_CHECK_ARG(X && part && rows > 0 && C > 0 && C % 4 == 0, "colstats: bad args rows=%ld C=%d", rows, C);
   FStats f{X, C};
-  launch_colreduce<FStats, 2, false, double>(f, rows, C, 1, stats, stats + C, (hipStream_t)stream);
+  launch_colreduce<FStats, 2, false, float>(f, rows, C, 1, part, part, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
-int mx_bn_finalize(const double* stats, int C, double count, const float* gamma, const float* beta, float* running_mean,
+int mx_bn_finalize(const float* part, int P, int C, double count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
-                   float* mean, float* rstd, void* stream) {
+                   float* mean, float* rstd, double* acc, void* stream) {
   MX_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale && shift && mean && rstd,
                "bn_finalize: null argument");
-  MX_CHECK_ARG(!training || (stats && count > 0), "bn_finalize: training needs stats and count");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, stats, C, count, gamma,
+  MX_CHECK_ARG(!training || (part && P > 0 && count > 0 && acc), "bn_finalize: training needs partial statistics, count and acc[2C]");
+  if (training) launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, C, count, gamma,
                      beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd);
   MX_LAUNCH_CHECK();
   return MX_OK;
@@ -293,21 +349,22 @@ int mx_bn_apply(const float* P, const float* scale, const float* shift, const fl
 // sums[2C] += (sum g_eff, sum g_eff * X)
 int mx_bn_bwd_reduce(const float* G, const float* X, const float* row_scale, const float* gate, const float* gate_add,
                      const float* act_scale, const float* act_shift, long rows, int C, int rows_per_sample,
-                     double* sums, void* stream) {
-  MX_CHECK_ARG(G && X && sums && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bn_bwd_reduce: bad args");
+                     float* part, void* stream) {
+  MX_CHECK_ARG(G && X && part && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bn_bwd_reduce: bad args");
   MX_CHECK_ARG((gate == nullptr) == (gate_add == nullptr), "bn_bwd_reduce: gate and gate_add come together");
   MX_CHECK_ARG((act_scale == nullptr) == (act_shift == nullptr), "bn_bwd_reduce: act scale/shift come together");
   FBwdReduce f{GEff{G, X, row_scale, gate, gate_add, act_scale, act_shift, C, rows_per_sample}};
-  launch_colreduce<FBwdReduce, 2, false, double>(f, rows, C, rows_per_sample, sums, sums + C, (hipStream_t)stream);
+  launch_colreduce<FBwdReduce, 2, false, float>(f, rows, C, rows_per_sample, part, part, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
-int mx_bn_bwd_finalize(const double* sums, int C, double count, const float* gamma, const float* mean, const float* rstd,
-                       int training, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream) {
-  MX_CHECK_ARG(sums && gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3 && C > 0 && count > 0,
+int mx_bn_bwd_finalize(const float* part, int P, int C, double count, const float* gamma, const float* mean, const float* rstd,
+                       int training, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, double* acc, void* stream) {
+  MX_CHECK_ARG(part && P > 0 && gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3 && acc && C > 0 && count > 0,
                "bn_bwd_finalize: bad args");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, C, count, gamma,
+  launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, C, count, gamma,
                      mean, rstd, training, dgamma, dbeta, c1, c2, c3);
   MX_LAUNCH_CHECK();
   return MX_OK;

@@ -31,7 +31,9 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_exp_f32 + v_rcp_f32 (both <= 1 ulp): ~1e-7 relative, far inside the stated fp32 tolerance, and ~4x fewer
+// instructions than the IEEE-exact division sequence hipcc emits for 1.0f / x
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 __device__ __forceinline__ float swishf_(float x) { return x * sigmoidf_(x); }
 // d/dx [x*sigmoid(x)] = s * (1 + x * (1 - s))   (src/efficientnet_pytorch/utils.py:44-47)
 __device__ __forceinline__ float swish_gradf_(float x) {

@@ -23,7 +23,7 @@ struct DwArgs {
   const float* dy;     // bwd_weight: dY
   const float* res;    // bwd_data: optional residual added to dX
   float* y;            // fwd: Y; bwd_data: dX; bwd_weight: dW [C,1,K,K] (+=)
-  double* stats;       // fwd: [2C] or null
+  float* stats;        // fwd: partial statistics [N*tiles][2][C] or null
   int N, H, W, Ho, Wo, C, pad;
   int tiles_x, tiles_y;
   int tiles_per_block;   // bwd_weight
@@ -48,18 +48,40 @@ __device__ __forceinline__ void dw_stage_weights(const DwArgs& a, float* wl, int
   }
 }
 
+// Stage one input tile.  All global loads of a thread are issued before the first use (the tile needs
+// <= 12 float4 per thread), so a workgroup has its whole tile in flight instead of one line per wave.
 template <int K, int S, int TH, int TW>
 __device__ __forceinline__ void dw_stage_input(const DwArgs& a, float4* tile, int n, int oy0, int ox0, int c0, int tid) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  constexpr int TOT = IH * IW * C4B, PER = (TOT + 255) / 256;
   const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
-  for (int i = tid; i < IH * IW * C4B; i += 256) {
-    int c4 = i % C4B, pix = i / C4B;
+  const int c4 = tid % C4B, c = c0 + 4 * c4;
+  float4 v[PER];
+  unsigned ok = 0;
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int i = tid + 256 * k;
+    int pix = i / C4B;
     int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-    int c = c0 + 4 * c4;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.C)
-      v = dw_load(a, a.x + (((long)n * a.H + iy) * a.W + ix) * a.C + c, c);
-    tile[i] = v;
+    v[k] = make_float4(0, 0, 0, 0);
+    if (i < TOT && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.C) {
+      v[k] = ld4(a.x + (((long)n * a.H + iy) * a.W + ix) * a.C + c);
+      ok |= 1u << k;
+    }
+  }
+  float4 s = make_float4(0, 0, 0, 0), t = s;
+  if (a.sc && c < a.C) { s = ld4(a.sc + c); t = ld4(a.sh + c); }
+#pragma unroll
+  for (int k = 0; k < PER; ++k) {
+    int i = tid + 256 * k;
+    if (i < TOT) {
+      float4 x = v[k];
+      if (a.sc && ((ok >> k) & 1u)) {
+        x.x = swishf_(s.x * x.x + t.x); x.y = swishf_(s.y * x.y + t.y);
+        x.z = swishf_(s.z * x.z + t.z); x.w = swishf_(s.w * x.w + t.w);
+      }
+      tile[i] = x;
+    }
   }
 }
 
@@ -87,7 +109,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   float4 acc[OX];
 #pragma unroll
   for (int o = 0; o < OX; ++o) acc[o] = make_float4(0, 0, 0, 0);
-#pragma unroll
+  // one kernel row at a time (8-12 input float4 live): fully unrolling ky for k=5 took 256 VGPRs = 1 wave/SIMD
+#pragma unroll 1
   for (int ky = 0; ky < K; ++ky) {
     float4 in[(OX - 1) * S + K];
 #pragma unroll
@@ -129,8 +152,9 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     }
     __syncthreads();
     if (tid < CB && c0 + tid < a.C) {
-      unsafeAtomicAdd(a.stats + c0 + tid, (double)red[tid]);
-      unsafeAtomicAdd(a.stats + a.C + c0 + tid, (double)red[CB + tid]);
+      float* prow = a.stats + ((long)n * gridDim.x + blockIdx.x) * 2 * a.C;   // one partial row per (sample, tile)
+      prow[c0 + tid] = red[tid];
+      prow[a.C + c0 + tid] = red[CB + tid];
     }
   }
 }
@@ -154,14 +178,24 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(DwArgs a) {
   auto fdiv = [](int p, int q) { return (p >= 0) ? p / q : -((-p + q - 1) / q); };
   const int oy_lo = fdiv(iy0 + a.pad - K + 1 + S - 1, S), ox_lo = fdiv(ix0 + a.pad - K + 1 + S - 1, S);
   dw_stage_weights<K>(a, wl, c0, tid);
-  for (int i = tid; i < OH * OW * C4B; i += 256) {
-    int c4 = i % C4B, pix = i / C4B;
-    int oy = oy_lo + pix / OW, ox = ox_lo + pix % OW;
-    int c = c0 + 4 * c4;
-    float4 v = make_float4(0, 0, 0, 0);
-    if (oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo && c < a.C)
-      v = ld4(a.x + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + c);
-    tile[i] = v;
+  {
+    constexpr int TOT = OH * OW * C4B, PER = (TOT + 255) / 256;
+    float4 v[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int i = tid + 256 * k;
+      int c4s = i % C4B, pix = i / C4B;
+      int oy = oy_lo + pix / OW, ox = ox_lo + pix % OW;
+      int cs = c0 + 4 * c4s;
+      v[k] = make_float4(0, 0, 0, 0);
+      if (i < TOT && oy >= 0 && oy < a.Ho && ox >= 0 && ox < a.Wo && cs < a.C)
+        v[k] = ld4(a.x + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + cs);
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int i = tid + 256 * k;
+      if (i < TOT) tile[i] = v[k];
+    }
   }
   __syncthreads();
   const int c4 = tid % C4B, q = tid / C4B;   // q in [0,32)
@@ -301,7 +335,13 @@ static int dw_check(const DwArgs& a, int K, int S, const char* who) {
 extern "C" {
 
 // Y = dwconv(act(X)); act = swish(scale*x+shift) if scale != null. stats[2C] += (sum Y, sum Y^2).
-int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, double* stats, int N,
+// number of partial-statistics rows mx_dwconv_fwd writes
+int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || (S != 1 && S != 2)) return MX_EARG;
+  return N * cdiv(Ho, 8) * cdiv(Wo, S == 1 ? 16 : 8);
+}
+
+int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats, int N,
                   int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
   DwArgs a{};
   a.x = X; a.sc = scale; a.sh = shift; a.w = W; a.y = Y; a.stats = stats;

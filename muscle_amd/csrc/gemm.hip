@@ -17,6 +17,7 @@
 // nothing here).  Global->register->LDS staging is double buffered with one barrier per K step.
 #include "common.h"
 #include <type_traits>
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -29,15 +30,14 @@ struct GemmArgs {
   const float* bias;        // [N] or null
   const float* residual;    // [M, ldc] or null
   int relu;
-  double* stats;            // [2*N] or null
+  float* stats;             // partial statistics [Mtiles][2][N] or null
   int ksplit;               // TN: rows of R per z-slice
 };
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
-constexpr int BK = 16;
 
 // load a [rows x BK] slab of a row-major [R, ld] matrix (k contiguous) and store it k-major
-template <int ROWS, int PAD>
+template <int ROWS, int PAD, int BK>
 struct SlabK {   // matrix is [rows_total, K] with k contiguous -> transposing store
   static constexpr int TOTAL = ROWS * (BK / 4);
   static constexpr int PER = (TOTAL + 255) / 256;
@@ -47,7 +47,7 @@ struct SlabK {   // matrix is [rows_total, K] with k contiguous -> transposing s
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int idx = tid + 256 * i;
-      int k4 = idx & 3, row = idx >> 2;
+      int k4 = idx % (BK / 4), row = idx / (BK / 4);
       int r = r0 + row, k = k0 + 4 * k4;
       float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
       if (idx < TOTAL && r < rows_total && k < K) {
@@ -61,7 +61,7 @@ struct SlabK {   // matrix is [rows_total, K] with k contiguous -> transposing s
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
       int idx = tid + 256 * i;
-      int k4 = idx & 3, row = idx >> 2;
+      int k4 = idx % (BK / 4), row = idx / (BK / 4);
       if (idx < TOTAL) {
         float* p = lds + (4 * k4) * (ROWS + PAD) + row;
         p[0] = v[i].x; p[ROWS + PAD] = v[i].y; p[2 * (ROWS + PAD)] = v[i].z; p[3 * (ROWS + PAD)] = v[i].w;
@@ -71,7 +71,7 @@ struct SlabK {   // matrix is [rows_total, K] with k contiguous -> transposing s
 };
 
 // load a [BK x COLS] slab of a row-major [Kdim, ld] matrix (cols contiguous) -> direct store
-template <int COLS, int PAD>
+template <int COLS, int PAD, int BK>
 struct SlabN {
   static constexpr int C4 = COLS / 4;
   static constexpr int TOTAL = BK * C4;
@@ -102,7 +102,7 @@ struct SlabN {
   }
 };
 
-template <int LAYOUT, int WM, int WN, int TM, int TN>
+template <int LAYOUT, int WM, int WN, int TM, int TN, int BK>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int PADA = (LAYOUT == L_TN) ? 4 : 1;
@@ -137,8 +137,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  typename std::conditional<LAYOUT == L_TN, SlabN<BM, PADA>, SlabK<BM, PADA>>::type sa;
-  typename std::conditional<LAYOUT == L_NT, SlabK<BN, PADB>, SlabN<BN, PADB>>::type sb;
+  typename std::conditional<LAYOUT == L_TN, SlabN<BM, PADA, BK>, SlabK<BM, PADA, BK>>::type sa;
+  typename std::conditional<LAYOUT == L_NT, SlabK<BN, PADB, BK>, SlabN<BN, PADB, BK>>::type sb;
 
   auto load = [&](int k0) {
     if constexpr (LAYOUT == L_TN) sa.load(g.a, A, g.lda, m0, g.M, k0, kend, tid);
@@ -228,10 +228,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
       }
     }
     __syncthreads();
+    float* prow = g.stats + (long)blockIdx.x * 2 * g.N;      // one partial row per M tile, summed in fp64 later
     for (int i = tid; i < BN; i += 256) {
       if (n0 + i < g.N) {
-        unsafeAtomicAdd(g.stats + n0 + i, (double)red[i]);
-        unsafeAtomicAdd(g.stats + g.N + n0 + i, (double)red[BN + i]);
+        prow[n0 + i] = red[i];
+        prow[g.N + n0 + i] = red[BN + i];
       }
     }
   }
@@ -240,28 +241,57 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-template <int LAYOUT, int WM, int WN, int TM, int TN>
+template <int LAYOUT, int WM, int WN, int TM, int TN, int BK = 16>
 static void launch(const GemmArgs& g, int batch_or_splits, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), batch_or_splits);
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN>), grid, dim3(256), 0, st, g);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, g);
+}
+
+// Tile configurations (block tile BM x BN; 4 waves).  EfficientNet's channel counts (48, 80, 160, 224, 288, 480,
+// 1344, ...) are multiples of 32 but rarely of 128, so BN is chosen per call.  Measured on MI355X over the B7
+// shapes (tools/gemm_sweep.py, profiles/r01_gemm_sweep.txt): the small 128x32 tile (7 workgroups per CU hide the
+// staging latency; the A re-reads it causes are absorbed by L2) wins or ties everywhere except where N is a
+// multiple of 96 or 128; tiles wider than 128 and 256-row tiles lose at every shape and were dropped.
+struct TileCfg { int bm, bn; };
+static const TileCfg kCfgs[] = {
+    {128, 128},   // 0: 2x2 waves, 2x2 MFMA tiles each
+    {128, 96},    // 1: 4x1 waves, 1x3
+    {128, 32},    // 2: 4x1 waves, 1x1
+    {256, 64},    // 3: 4x1 waves, 2x2   (kept for the tuning sweep)
+    {128, 64},    // 4: 4x1 waves, 1x2   (kept for the tuning sweep)
+    {128, 128},   // 5: as 0 with BK = 32
+    {128, 64},    // 6: 2x2 waves, 2x1
+    {128, 64},    // 7: 2x2 waves, 2x1, BK = 32
+    {128, 32},    // 8: as 2 with BK = 32
+    {128, 96},    // 9: as 1 with BK = 32
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+static int pick_cfg(int M, int N, int K) {
+  (void)M; (void)K;
+  if (const char* e = getenv("MX_GEMM_CFG")) {           // tuning override (tools/gemm_sweep.py)
+    int forced = atoi(e);
+    if (forced >= 0 && forced < kNumCfgs) return forced;
+  }
+  if (N >= 384 && N % 128 == 0) return 0;
+  if (N % 96 == 0) return 1;
+  return 2;
 }
 
 template <int LAYOUT>
 static void dispatch(const GemmArgs& g, int zdim, hipStream_t st) {
-  // choose the N tile with the least padding waste; ties -> wider tile
-  const int cands[5] = {128, 96, 64, 32, 192};
-  int best = 128;
-  long bestw = -1;
-  for (int i = 0; i < 4; ++i) {
-    long padded = (long)cdiv(g.N, cands[i]) * cands[i];
-    if (bestw < 0 || padded < bestw) { bestw = padded; best = cands[i]; }
-  }
-  switch (best) {
-    case 128: launch<LAYOUT, 2, 2, 2, 2>(g, zdim, st); break;   // 128 x 128
-    case 96:  launch<LAYOUT, 4, 1, 1, 3>(g, zdim, st); break;   // 128 x 96
-    case 64:  launch<LAYOUT, 4, 1, 2, 2>(g, zdim, st); break;   // 256 x 64
-    default:  launch<LAYOUT, 4, 1, 2, 1>(g, zdim, st); break;   // 256 x 32
+  switch (pick_cfg(g.M, g.N, g.K)) {
+    case 0: launch<LAYOUT, 2, 2, 2, 2>(g, zdim, st); break;
+    case 1: launch<LAYOUT, 4, 1, 1, 3>(g, zdim, st); break;
+    case 2: launch<LAYOUT, 4, 1, 1, 1>(g, zdim, st); break;
+    case 3: launch<LAYOUT, 4, 1, 2, 2>(g, zdim, st); break;
+    case 4: launch<LAYOUT, 4, 1, 1, 2>(g, zdim, st); break;
+    case 5: launch<LAYOUT, 2, 2, 2, 2, 32>(g, zdim, st); break;
+    case 6: launch<LAYOUT, 2, 2, 2, 1>(g, zdim, st); break;
+    case 7: launch<LAYOUT, 2, 2, 2, 1, 32>(g, zdim, st); break;
+    case 8: launch<LAYOUT, 4, 1, 1, 1, 32>(g, zdim, st); break;
+    default: launch<LAYOUT, 4, 1, 1, 3, 32>(g, zdim, st); break;
   }
 }
 
@@ -293,12 +323,13 @@ static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
     MX_CHECK_ARG(g.M % 4 == 0 && g.N % 4 == 0, "gemm TN: M=%d and N=%d must be multiples of 4", g.M, g.N);
     MX_CHECK_ARG(batch == 1, "gemm TN: not batched");
     // split the pixel reduction so the grid fills the chip (>= ~1024 blocks), >= 512 rows per split
-    long tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128);
+    const TileCfg tc = kCfgs[pick_cfg(g.M, g.N, g.K)];
+    long tiles = (long)cdiv(g.M, tc.bm) * cdiv(g.N, tc.bn);
     int splits = (int)((2048 + tiles - 1) / tiles);
     int maxs = cdiv(g.K, 512);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;
-    int ks = cdiv(cdiv(g.K, splits), BK) * BK;
+    int ks = cdiv(cdiv(g.K, splits), 32) * 32;
     g.ksplit = ks;
     splits = cdiv(g.K, ks);
     dispatch<L_TN>(g, splits, st);
@@ -311,9 +342,15 @@ extern "C" {
 
 // C[M,N] = A'[M,K] * W[N,K]^T (+bias) (+residual) (relu); stats[2N] += column sum / sumsq.
 // A' = prologue(A; a_mode, a_scale, a_shift, a_gate, rows_per_sample).
+// number of partial-statistics rows mx_pw_fwd writes for an [M, N] output
+int mx_pw_fwd_parts(int M, int N, int K) {
+  if (M <= 0 || N <= 0 || K <= 0) return MX_EARG;
+  return cdiv(M, kCfgs[pick_cfg(M, N, K)].bm);
+}
+
 int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_shift, const float* a_gate,
               int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,
-              const float* bias, const float* residual, int relu, double* stats, void* stream) {
+              const float* bias, const float* residual, int relu, float* stats, void* stream) {
   GemmArgs g{};
   g.a = MxOperand{A, a_scale, a_shift, a_gate, a_mode, rows_per_sample};
   g.b = MxOperand{W, nullptr, nullptr, nullptr, MX_PLAIN, 1};

@@ -64,39 +64,57 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* ggate, const
   }
 }
 
-// (B) per channel c (one thread): db2[c] += sum_n ge; dW2[c,j] += sum_n ge[n,c] r[n,j];
-//     dW1[j,c] += sum_n gh[n,j] s[n,c];  add[n,c] = inv_hw * sum_j gh[n,j] W1[j,c].   No atomics: c is owned.
+// (B) thread = channel c, block row = chunk of SE_JB squeeze units: dW2[c,j] += sum_n ge[n,c] r[n,j];
+//     dW1[j,c] += sum_n gh[n,j] s[n,c] (both owned, no atomics); add[n,c] += inv_hw * sum_{j in chunk} gh[n,j] W1[j,c]
+//     (fp32 atomics across the <= 20 chunks; `add` is zero-filled by the entry point); db2 by chunk 0.
+constexpr int SE_NB = 32, SE_JB = 8;
 __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* ggate, const float* gate, const float* s, const float* h,
                                                        const float* gh, const float* W1, float inv_hw, float* add, float* dW1,
                                                        float* dW2, float* db2, int N, int C, int SQ) {
-  extern __shared__ float sh[];          // r[N][SQ], ghs[N][SQ]
+  extern __shared__ float sh[];          // r[N][SE_JB], ghs[N][SE_JB]
   float* r = sh;
-  float* ghs = sh + (long)N * SQ;
-  for (int i = threadIdx.x; i < N * SQ; i += 256) { r[i] = swishf_(h[i]); ghs[i] = gh[i]; }
+  float* ghs = sh + (long)N * SE_JB;
+  const int j0 = blockIdx.y * SE_JB, jn = min(SE_JB, SQ - j0);
+  for (int i = threadIdx.x; i < N * SE_JB; i += 256) {
+    int n = i / SE_JB, jj = i % SE_JB;
+    bool ok = jj < jn;
+    r[i] = ok ? swishf_(h[(long)n * SQ + j0 + jj]) : 0.f;
+    ghs[i] = ok ? gh[(long)n * SQ + j0 + jj] : 0.f;
+  }
   __syncthreads();
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  float sb = 0.f;
-  for (int n = 0; n < N; ++n) {
-    float g = gate[(long)n * C + c];
-    sb += ggate[(long)n * C + c] * g * (1.f - g);
-  }
-  db2[c] += sb;
-  for (int j = 0; j < SQ; ++j) {
-    float a2 = 0.f, a1 = 0.f;
-    for (int n = 0; n < N; ++n) {
-      float g = gate[(long)n * C + c];
-      float ge = ggate[(long)n * C + c] * g * (1.f - g);
-      a2 += ge * r[n * SQ + j];
-      a1 += ghs[n * SQ + j] * s[(long)n * C + c];
+  for (int n0 = 0; n0 < N; n0 += SE_NB) {
+    float ge[SE_NB], sv[SE_NB], acc[SE_NB];
+    float sb = 0.f;
+#pragma unroll
+    for (int n = 0; n < SE_NB; ++n) {
+      ge[n] = sv[n] = acc[n] = 0.f;
+      if (n0 + n < N) {
+        float g = gate[(long)(n0 + n) * C + c];
+        ge[n] = ggate[(long)(n0 + n) * C + c] * g * (1.f - g);
+        sv[n] = s[(long)(n0 + n) * C + c];
+        sb += ge[n];
+      }
     }
-    dW2[(long)c * SQ + j] += a2;
-    dW1[(long)j * C + c] += a1;
-  }
-  for (int n = 0; n < N; ++n) {
-    float acc = 0.f;
-    for (int j = 0; j < SQ; ++j) acc += ghs[n * SQ + j] * W1[(long)j * C + c];
-    add[(long)n * C + c] = acc * inv_hw;
+    if (blockIdx.y == 0) db2[c] += sb;
+    for (int jj = 0; jj < jn; ++jj) {
+      float a2 = 0.f, a1 = 0.f;
+      const float w = W1[(long)(j0 + jj) * C + c];
+#pragma unroll
+      for (int n = 0; n < SE_NB; ++n) {
+        const int nn = (n0 + n < N) ? n0 + n : 0;     // ge/sv are 0 beyond N
+        a2 += ge[n] * r[nn * SE_JB + jj];
+        const float g = ghs[nn * SE_JB + jj];
+        a1 += g * sv[n];
+        acc[n] += g * w;
+      }
+      dW2[(long)c * SQ + j0 + jj] += a2;
+      dW1[(long)(j0 + jj) * C + c] += a1;
+    }
+#pragma unroll
+    for (int n = 0; n < SE_NB; ++n)
+      if (n0 + n < N) unsafeAtomicAdd(add + (long)(n0 + n) * C + c, acc[n] * inv_hw);
   }
 }
 
@@ -147,13 +165,12 @@ int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float
   MX_CHECK_ARG(ggate && gate && s && h && W1 && W2 && add && dW1 && db1 && dW2 && db2, "se_bwd: null pointer");
   MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd: bad extents N=%d C=%d SQ=%d", N, C, SQ);
   MX_CHECK_ARG(gh_scratch != nullptr, "se_bwd: gh_scratch [N*SQ] required");
-  size_t shb = (size_t)2 * N * SQ * sizeof(float);
-  MX_CHECK_ARG(shb <= 160 * 1024, "se_bwd: N*SQ=%d too large for LDS staging", N * SQ);
-  if (shb > 48 * 1024)
-    hipFuncSetAttribute((const void*)se_bwd_b_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shb);
+  size_t shb = (size_t)2 * N * SE_JB * sizeof(float);
+  MX_CHECK_ARG(shb <= 48 * 1024, "se_bwd: N=%d too large for LDS staging", N);
+  hipMemsetAsync(add, 0, sizeof(float) * (size_t)N * C, (hipStream_t)stream);
   hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
                      C, SQ);
-  hipLaunchKernelGGL(se_bwd_b_kernel, dim3(cdiv(C, 256)), dim3(256), shb, (hipStream_t)stream, ggate, gate, s, h, gh_scratch, W1,
+  hipLaunchKernelGGL(se_bwd_b_kernel, dim3(cdiv(C, 256), cdiv(SQ, SE_JB)), dim3(256), shb, (hipStream_t)stream, ggate, gate, s, h, gh_scratch, W1,
                      inv_hw, add, dW1, dW2, db2, N, C, SQ);
   MX_LAUNCH_CHECK();
   return MX_OK;

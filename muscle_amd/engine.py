@@ -80,8 +80,8 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
     # stem: im2col + MFMA GEMM (K = 27 padded to 28), BN statistics in the GEMM epilogue
     tape.cols = ops.stem_im2col(img, H0, W0, lo)
     C0 = cfg.stem_out
-    stats = ops.new_stats(C0, dev) if training else None
-    raw = ops.pw_fwd(tape.cols, stem_weight28(backbone), C0, stats=stats)
+    raw, stats = ops.pw_fwd(tape.cols, stem_weight28(backbone), C0, want_stats=True) if training else \
+        (ops.pw_fwd(tape.cols, stem_weight28(backbone), C0), None)
     tape.stem_raw = raw.view(N, H0, W0, C0)
     tape.stem_bn = ops.bn_finalize(stats, N * H0 * W0, backbone._bn0, training)
 
@@ -93,23 +93,31 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
         M, Mo = N * h * w, N * ho * wo
         if b.expand:
             assert x_st is None
-            st0 = ops.new_stats(b.cexp, dev) if training else None
-            t.e_raw = ops.pw_fwd(x.view(M, b.cin), m._expand_conv.weight.view(b.cexp, b.cin), b.cexp, stats=st0)
+            st0 = None
+            t.e_raw = ops.pw_fwd(x.view(M, b.cin), m._expand_conv.weight.view(b.cexp, b.cin), b.cexp, want_stats=training)
+            if training:
+                t.e_raw, st0 = t.e_raw
             t.e_raw = t.e_raw.view(N, h, w, b.cexp)
             t.bn0 = ops.bn_finalize(st0, M, m._bn0, training)
             dw_in, dw_st = t.e_raw, t.bn0
         else:
             dw_in, dw_st = x, x_st
-        st1 = ops.new_stats(b.cexp, dev) if training else None
-        t.d_raw = ops.dwconv_fwd(dw_in, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, ho, wo, st=dw_st, stats=st1)
+        st1 = None
+        t.d_raw = ops.dwconv_fwd(dw_in, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, ho, wo, st=dw_st,
+                                 want_stats=training)
+        if training:
+            t.d_raw, st1 = t.d_raw
         t.bn1 = ops.bn_finalize(st1, Mo, m._bn1, training)
         d2 = t.d_raw.view(Mo, b.cexp)
         pooled = ops.pool_sum(d2, ho * wo, st=t.bn1, act=True)
         t.s, t.h, t.gate = ops.se_fwd(pooled, 1.0 / (ho * wo), m._se_reduce.weight.view(b.se, b.cexp), m._se_reduce.bias,
                                       m._se_expand.weight.view(b.cexp, b.se), m._se_expand.bias)
-        st2 = ops.new_stats(b.cout, dev) if training else None
+        st2 = None
         t.p_raw = ops.pw_fwd(d2, m._project_conv.weight.view(b.cout, b.cexp), b.cout, a_mode=ops.BNACT,
-                             a_scale=t.bn1.scale, a_shift=t.bn1.shift, a_gate=t.gate, rows_per_sample=ho * wo, stats=st2)
+                             a_scale=t.bn1.scale, a_shift=t.bn1.shift, a_gate=t.gate, rows_per_sample=ho * wo,
+                             want_stats=training)
+        if training:
+            t.p_raw, st2 = t.p_raw
         t.bn2 = ops.bn_finalize(st2, Mo, m._bn2, training)
         if b.skip and training and b.drop_rate:
             keep = 1.0 - b.drop_rate

@@ -10,7 +10,7 @@ from typing import NamedTuple, Optional
 
 import torch
 
-from ._lib import call, ptr, stream
+from ._lib import call, lib, ptr, stream
 
 PLAIN, BNACT, AFFINE = 0, 1, 2
 
@@ -28,15 +28,18 @@ def _f32(*shape, device):
 
 # ---- GEMMs ------------------------------------------------------------------------------------
 def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None, rows_per_sample=1,
-           bias=None, residual=None, relu=False, stats=None, out=None, ldc=None):
-    """A: [M, K]; W: [N_out, K] -> [M, N_out]."""
+           bias=None, residual=None, relu=False, want_stats=False, out=None, ldc=None):
+    """A: [M, K]; W: [N_out, K] -> [M, N_out] (and, if want_stats, the partial BN statistics [P, 2, N_out])."""
     M, K = A.shape
     ldc = ldc or N_out
     if out is None:
         out = _f32(M, ldc, device=A.device)
+    stats = None
+    if want_stats:
+        stats = _f32(lib().mx_pw_fwd_parts(M, N_out, K), 2, N_out, device=A.device)
     call("mx_pw_fwd", ptr(A), a_mode, ptr(a_scale), ptr(a_shift), ptr(a_gate), rows_per_sample, ptr(W), ptr(out),
          M, K, N_out, A.stride(0), ldc, ptr(bias), ptr(residual), int(relu), ptr(stats), stream())
-    return out
+    return (out, stats) if want_stats else out
 
 
 def pw_dgrad(G, W, N_in, *, residual=None, out=None):
@@ -66,22 +69,22 @@ def bgemm(layout, A, B, out, M, N, K, *, relu=False):
 
 
 # ---- BatchNorm / elementwise ---------------------------------------------------------------------
-def new_stats(C, device):
-    return torch.zeros(2 * C, dtype=torch.float64, device=device)
-
-
-def colstats(X2d, stats):
-    call("mx_colstats", ptr(X2d), X2d.shape[0], X2d.shape[1], ptr(stats), stream())
+def colstats(X2d):
+    rows, C = X2d.shape
+    part = _f32(lib().mx_colreduce_parts(rows, C), 2, C, device=X2d.device)
+    call("mx_colstats", ptr(X2d), rows, C, ptr(part), stream())
+    return part
 
 
 def bn_finalize(stats, count, bn: torch.nn.BatchNorm2d, training: bool) -> BNState:
+    """stats: partial rows [P, 2, C] from a producer (None in eval mode)."""
     C = bn.num_features
     dev = bn.weight.device
     buf = _f32(4, C, device=dev)
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
-    call("mx_bn_finalize", ptr(stats), C, float(count), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+    call("mx_bn_finalize", ptr(stats), stats.shape[0] if stats is not None else 0, C, float(count), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
          ptr(bn.running_var), mom, float(bn.eps), int(training), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]),
-         stream())
+         ptr(torch.empty(2 * C, dtype=torch.float64, device=dev)) if training else None, stream())
     if training:
         bn.num_batches_tracked += 1
     return BNState(buf[0], buf[1], buf[2], buf[3])
@@ -102,14 +105,16 @@ def bn_backward(G2d, X2d, bn: torch.nn.BatchNorm2d, st: BNState, dgamma, dbeta, 
     `act` is the BNState whose affine feeds a SiLU that sits between this BN's output and G (i.e. the
     same BN: G is d/d swish(BN(X))), so the SiLU derivative is recomputed from X."""
     rows, C = X2d.shape
-    sums = new_stats(C, X2d.device)
+    P = lib().mx_colreduce_parts(rows, C)
+    sums = _f32(P, 2, C, device=X2d.device)
     a_sc = act.scale if act is not None else None
     a_sh = act.shift if act is not None else None
     call("mx_bn_bwd_reduce", ptr(G2d), ptr(X2d), ptr(row_scale), ptr(gate), ptr(gate_add), ptr(a_sc), ptr(a_sh), rows, C,
          rows_per_sample, ptr(sums), stream())
     c = _f32(3, C, device=X2d.device)
-    call("mx_bn_bwd_finalize", ptr(sums), C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
-         ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]), stream())
+    call("mx_bn_bwd_finalize", ptr(sums), P, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
+         ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]),
+         ptr(torch.empty(2 * C, dtype=torch.float64, device=X2d.device)), stream())
     if out is None:
         out = torch.empty_like(X2d)
     call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), ptr(row_scale), ptr(gate), ptr(gate_add), ptr(a_sc), ptr(a_sh),
@@ -126,12 +131,13 @@ def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=
 
 
 # ---- depthwise ------------------------------------------------------------------------------------
-def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, stats=None):
+def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, want_stats=False):
     N, H, Wd, C = X.shape
     Y = _f32(N, Ho, Wo, C, device=X.device)
+    stats = _f32(lib().mx_dwconv_fwd_parts(N, Ho, Wo, S), 2, C, device=X.device) if want_stats else None
     call("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),
          N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
-    return Y
+    return (Y, stats) if want_stats else Y
 
 
 def dwconv_bwd_data(dY, W, K, S, pad_lo, H, Wd, *, residual=None):

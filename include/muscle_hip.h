@@ -177,6 +177,15 @@ int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int
 int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsigned* prefix, const unsigned* krem,
               const unsigned* cnt_eq, const float* gup, float gscale, float* gsgcs, int N, int K, long HW, void* stream);
 
+/* The same ER loss computed straight from the low-resolution NHWC maps cam/sgc [N,h,w,L] (MuSCLe.py:256-257 fused in):
+ * no H*W-sized tensor is read or written.  gsgc [N,h,w,L] = d loss / d sgc_lowres. */
+int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
+                 unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss,
+                 void* stream);
+int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix, const unsigned* krem,
+                 const unsigned* cnt_eq, const float* gup, float gscale, float* gsgc, int N, int h, int w, int L, int K, int H,
+                 int W, void* stream);
+
 /* torch.optim.Adam(weight_decay) update on flat arrays (train_mcl.py:134,199,229) */
 int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
             float weight_decay, float bias_corr1, float sqrt_bias_corr2, void* stream);

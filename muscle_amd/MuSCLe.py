@@ -98,7 +98,7 @@ class MuSCLe(nn.Module):
         for blk in self.backbone._blocks[:last + 1]:
             ps += list(blk.parameters())
         ps += [self.fuse.weight, self.fuse.bias]
-        if cam_mode in ("cam", "logits"):
+        if cam_mode in ("cam", "logits", "cam_lr"):
             ps.append(self.fc.weight)
         if cam_mode == "logits":
             ps = [p for p in ps if p is not self.fuse.weight and p is not self.fuse.bias]
@@ -106,7 +106,7 @@ class MuSCLe(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, cam="cam", drop_u: Optional[Dict[int, torch.Tensor]] = None):
-        if cam not in ("logits", "cam", "pix"):
+        if cam not in ("logits", "cam", "pix", "cam_lr"):
             raise NotImplementedError(f"forward(cam={cam!r}) needs the BiFPN decoder (mode='dec'), not built yet")
         if not x.is_cuda:
             raise MuscleHipError("MuSCLe.forward runs on the HIP kernels only: move the model and input to a ROCm GPU")
@@ -115,7 +115,7 @@ class MuSCLe(nn.Module):
         if cam == "logits":
             self.logits = outs[1]
             return outs[0], outs[1]
-        if cam == "cam":
+        if cam in ("cam", "cam_lr"):
             self.logits = outs[3]
             return outs[0], outs[1], outs[2], outs[3]
         return outs[0], outs[1]
@@ -136,7 +136,7 @@ class MuSCLe(nn.Module):
         ht.fcw = fcw
         p7m = p7.view(M7, C7)
         emb = logits = None
-        if mode in ("cam", "logits"):
+        if mode in ("cam", "logits", "cam_lr"):
             emb = ops.ew(0, ops.pool_sum(p7m, hw), alpha=1.0 / hw)                      # GAP, MuSCLe.py:240
             logits = ops.pw_fwd(emb, fcw, K)                                             # fc (no bias), :241
             ht.emb = emb
@@ -171,6 +171,10 @@ class MuSCLe(nn.Module):
         ops.bgemm(1, aff, cam[:M7].view(N, hw, _CPAD), T, hw, _CPAD, ht.hwp)              # aff @ [cam | 1]
         ht.aff, ht.T = aff, T
         rv = ops.pcm_norm(T, torch.empty_like(T), K, 1e-5)                                # column-normalised aff applied
+        if mode == "cam_lr":
+            # internal mode of mcl_step: the low-resolution NHWC maps [N,h,w,24]; their bilinear upsampling
+            # (:256-257) is folded into the fused ER kernel, so the 2 x [N,21,H,W] tensors are never written
+            return (cam[:M7].view(N, h, w, _CPAD), rv.view(N, h, w, _CPAD), emb, logits), tape, ht
         cams = ops.upsample_to_nchw(cam[:M7].view(N, h, w, _CPAD), K, H, W)               # :256
         sgc = ops.upsample_to_nchw(rv.view(N, h, w, _CPAD), K, H, W)                      # :257
         if mode == "pix":
@@ -189,7 +193,7 @@ class MuSCLe(nn.Module):
         if mode == "logits":
             g_cams = g_sgc = None
             g_emb, g_logits = gouts
-        elif mode == "cam":
+        elif mode in ("cam", "cam_lr"):
             g_cams, g_sgc, g_emb, g_logits = gouts
         else:
             (g_cams, g_sgc), g_emb, g_logits = gouts, None, None
@@ -198,11 +202,17 @@ class MuSCLe(nn.Module):
             g_cam = torch.zeros(M7 + 4, _CPAD, dtype=torch.float32, device=dev)          # dL/d cam (low res), pre-relu mask
             have = False
             if g_cams is not None:
-                ops.upsample_to_nchw_bwd(g_cams.contiguous(), g_cam[:M7].view(N, h, w, _CPAD))
+                if mode == "cam_lr":
+                    g_cam[:M7].copy_(g_cams.reshape(M7, _CPAD))
+                else:
+                    ops.upsample_to_nchw_bwd(g_cams.contiguous(), g_cam[:M7].view(N, h, w, _CPAD))
                 have = True
             if g_sgc is not None:
-                g_rv = torch.zeros(N, hw, _CPAD, dtype=torch.float32, device=dev)
-                ops.upsample_to_nchw_bwd(g_sgc.contiguous(), g_rv.view(N, h, w, _CPAD))
+                if mode == "cam_lr":
+                    g_rv = g_sgc.contiguous().view(N, hw, _CPAD)
+                else:
+                    g_rv = torch.zeros(N, hw, _CPAD, dtype=torch.float32, device=dev)
+                    ops.upsample_to_nchw_bwd(g_sgc.contiguous(), g_rv.view(N, h, w, _CPAD))
                 gTb = torch.zeros(M7 + 4, _CPAD, dtype=torch.float32, device=dev)
                 gT = gTb[:M7].view(N, hw, _CPAD)
                 ops.pcm_norm(ht.T, gT, K, 1e-5, grv=g_rv)
@@ -225,7 +235,7 @@ class MuSCLe(nn.Module):
             if have:
                 g_cam_m = ops.ew(2, g_cam[:M7], y=ht.cam[:M7])                              # relu backward
                 g_p7 = ops.pw_dgrad(g_cam_m, ht.fcw, C7)                                    # through the detached fc weight
-        if mode in ("cam", "logits") and (g_emb is not None or g_logits is not None):
+        if mode in ("cam", "logits", "cam_lr") and (g_emb is not None or g_logits is not None):
             g_e = g_emb.contiguous() if g_emb is not None else None
             if g_logits is not None:
                 gl = torch.zeros(N, _CPAD, dtype=torch.float32, device=dev)

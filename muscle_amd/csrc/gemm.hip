@@ -160,25 +160,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     const float* as = As + cur * BK * SA + wm * TM * 32 + l31;
     const float* bs = Bs + cur * BK * SB + wn * TN * 32 + l31;
     const int kleft = min(BK, kend - (kbeg + kt * BK));
+    // the LDS stores of the next tile sit in the middle of the MFMA stream (the matrix pipe keeps draining the
+    // already issued MFMAs while they issue) instead of in front of the barrier, where every wave would stall
+    auto mfma_range = [&](int k_lo, int k_hi) {
 #pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      if (kk < kleft) {
-        float av[TM], bv[TN];
+      for (int kk = k_lo; kk < k_hi; kk += 2) {
+        if (kk < kleft) {
+          float av[TM], bv[TN];
 #pragma unroll
-        for (int i = 0; i < TM; ++i) av[i] = as[(kk + h) * SA + i * 32];
+          for (int i = 0; i < TM; ++i) av[i] = as[(kk + h) * SA + i * 32];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + h) * SB + j * 32];
+          for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + h) * SB + j * 32];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
       }
-    }
+    };
+    mfma_range(0, BK / 2);
     if (kt + 1 < nk) {
       sa.store(As + (cur ^ 1) * BK * SA, tid);
       sb.store(Bs + (cur ^ 1) * BK * SB, tid);
     }
+    mfma_range(BK / 2, BK);
     __syncthreads();
   }
 

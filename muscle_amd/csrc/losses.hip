@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void er_hist_kernel(const float* d, long row_l
   for (long i = beg + threadIdx.x; i < end; i += 256) {
     float v = row[i];
     unsigned key = __float_as_uint(v);
-    if ((key & himask) == pf) {
+    if (key != 0u && (key & himask) == pf) {     // exact zeros (masked channels) cannot change the top-k sum
       unsigned b = (key >> shift) & dm;
       atomicAdd(&lc[b], 1u);
       atomicAdd(&ls[b], v);
@@ -415,6 +415,180 @@ int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
   MX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(adam_kernel, dim3(gs((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
                      weight_decay, bias_corr1, sqrt_bias_corr2);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------
+// ER loss straight from the low-resolution maps (no full-resolution tensor is ever written):
+// cams_full / sgcs_full (MuSCLe.py:256-257, bilinear align_corners) are recomputed per pixel from the
+// [N,h,w,L] NHWC low-res CAM / SGC, then cam_softmaxnorm, mask, |diff| and the radix select as above.
+// Exact zeros (masked channels: ~88 % of all elements) are never histogrammed: they cannot change the sum, and
+// 64 lanes hitting LDS bin 0 serialised the pass.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void lr_coord(int d, int in, int out, int& i0, int& i1, float& w1) {
+  float scale = (out > 1) ? (float)(in - 1) / (float)(out - 1) : 0.f;
+  float s = scale * d;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  w1 = s - i0;
+}
+
+// fills a[K], b[K] with the softmaxnorm'ed upsampled cam / sgc at (n, Y, X); returns argmax of b's foreground
+__device__ __forceinline__ int lr_pixel(const float* cam, const float* sgc, int n, int Y, int X, int h, int w, int L, int K, int H,
+                                        int W, float* a, float* b, float& wy, float& wx, int& y0, int& y1, int& x0, int& x1) {
+  lr_coord(Y, h, H, y0, y1, wy);
+  lr_coord(X, w, W, x0, x1, wx);
+  const long base = (long)n * h * w * L;
+  const float* c00 = cam + base + ((long)y0 * w + x0) * L; const float* c01 = cam + base + ((long)y0 * w + x1) * L;
+  const float* c10 = cam + base + ((long)y1 * w + x0) * L; const float* c11 = cam + base + ((long)y1 * w + x1) * L;
+  const float* s00 = sgc + base + ((long)y0 * w + x0) * L; const float* s01 = sgc + base + ((long)y0 * w + x1) * L;
+  const float* s10 = sgc + base + ((long)y1 * w + x0) * L; const float* s11 = sgc + base + ((long)y1 * w + x1) * L;
+  float ma = -INFINITY, mb = -INFINITY;
+  for (int k = 1; k < K; ++k) {
+    a[k] = (1.f - wy) * ((1.f - wx) * c00[k] + wx * c01[k]) + wy * ((1.f - wx) * c10[k] + wx * c11[k]);
+    b[k] = (1.f - wy) * ((1.f - wx) * s00[k] + wx * s01[k]) + wy * ((1.f - wx) * s10[k] + wx * s11[k]);
+    ma = fmaxf(ma, a[k]); mb = fmaxf(mb, b[k]);
+  }
+  float sa = 0.f, sb = 0.f;
+  for (int k = 1; k < K; ++k) { a[k] = __expf(a[k] - ma); sa += a[k]; b[k] = __expf(b[k] - mb); sb += b[k]; }
+  float ia = 1.f / sa, ib = 1.f / sb, besta = -1.f, bestb = -1.f;
+  int am = 1;
+  for (int k = 1; k < K; ++k) {
+    a[k] *= ia; b[k] *= ib;
+    besta = fmaxf(besta, a[k]);
+    if (b[k] > bestb) { bestb = b[k]; am = k; }
+  }
+  a[0] = 1.f - besta; b[0] = 1.f - bestb;
+  return am;
+}
+
+__global__ __launch_bounds__(256) void er_lr_hist_kernel(const float* cam, const float* sgc, const float* lwb, int h, int w, int L,
+                                                         int K, int H, int W, int shift, int nbits, unsigned himask,
+                                                         const unsigned* prefix, unsigned* hcnt, float* hsum) {
+  __shared__ unsigned lc[RBINS];
+  __shared__ float ls[RBINS];
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < RBINS; i += 256) { lc[i] = 0; ls[i] = 0.f; }
+  __syncthreads();
+  const unsigned pf = prefix[n], dm = (1u << nbits) - 1u;
+  const long HW = (long)H * W;
+  const long per = (HW + gridDim.x - 1) / gridDim.x;
+  const long beg = blockIdx.x * per, end = min(HW, beg + per);
+  for (long p = beg + threadIdx.x; p < end; p += 256) {
+    float a[KMAX], b[KMAX], wy, wx;
+    int y0, y1, x0, x1;
+    lr_pixel(cam, sgc, n, (int)(p / W), (int)(p % W), h, w, L, K, H, W, a, b, wy, wx, y0, y1, x0, x1);
+    for (int k = 0; k < K; ++k) {
+      float m = lwb[n * K + k];
+      if (m == 0.f) continue;
+      float v = fabsf(a[k] - b[k]) * m;
+      unsigned key = __float_as_uint(v);
+      if (key != 0u && (key & himask) == pf) {
+        unsigned bb = (key >> shift) & dm;
+        atomicAdd(&lc[bb], 1u);
+        atomicAdd(&ls[bb], v);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RBINS; i += 256)
+    if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); unsafeAtomicAdd(&hsum[n * RBINS + i], ls[i]); }
+}
+
+// gradient w.r.t. the low-res SGC: one workgroup per low-res cell gathers from the full-res pixels it feeds
+__global__ __launch_bounds__(256) void er_lr_bwd_kernel(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix,
+                                                        const unsigned* krem, const unsigned* cnt_eq, const float* gup,
+                                                        float gscale, float* gsgc, int h, int w, int L, int K, int H, int W) {
+  __shared__ float red[4][KMAX];
+  const int cell = blockIdx.x, n = blockIdx.y;
+  const int cy = cell / w, cx = cell % w;
+  if (gup) gscale *= gup[0];
+  // full-res rows / cols whose interpolation touches (cy, cx): source coordinate in (cy-1, cy+1)
+  const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
+  int Ylo = (sy > 0.f) ? (int)floorf((cy - 1) / sy) : 0, Yhi = (sy > 0.f) ? (int)ceilf((cy + 1) / sy) : H - 1;
+  int Xlo = (sx > 0.f) ? (int)floorf((cx - 1) / sx) : 0, Xhi = (sx > 0.f) ? (int)ceilf((cx + 1) / sx) : W - 1;
+  Ylo = max(Ylo, 0); Yhi = min(Yhi, H - 1); Xlo = max(Xlo, 0); Xhi = min(Xhi, W - 1);
+  const int nx = Xhi - Xlo + 1, cnt = (Yhi - Ylo + 1) * nx;
+  const unsigned tk = prefix[n];
+  const float tiew = cnt_eq[n] ? (float)krem[n] / (float)cnt_eq[n] : 0.f;
+  float acc[KMAX];
+  for (int k = 0; k < K; ++k) acc[k] = 0.f;
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const int Y = Ylo + i / nx, X = Xlo + i % nx;
+    float a[KMAX], b[KMAX], g[KMAX], wy, wx;
+    int y0, y1, x0, x1;
+    const int am = lr_pixel(cam, sgc, n, Y, X, h, w, L, K, H, W, a, b, wy, wx, y0, y1, x0, x1);
+    float wgt = 0.f;     // bilinear weight of this cell for this pixel
+    if (y0 == cy) wgt += (x0 == cx ? (1.f - wy) * (1.f - wx) : 0.f) + ((x1 == cx && x1 != x0) ? (1.f - wy) * wx : 0.f);
+    if (y1 == cy && y1 != y0) wgt += (x0 == cx ? wy * (1.f - wx) : 0.f) + ((x1 == cx && x1 != x0) ? wy * wx : 0.f);
+    if (wgt == 0.f) continue;
+    for (int k = 0; k < K; ++k) {
+      float m = lwb[n * K + k];
+      float df = a[k] - b[k];
+      unsigned key = __float_as_uint(fabsf(df) * m);
+      float ww = (key > tk) ? 1.f : ((key == tk) ? tiew : 0.f);
+      float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+      g[k] = -sg * m * ww * gscale;
+    }
+    g[am] -= g[0];
+    float dot = 0.f;
+    for (int k = 1; k < K; ++k) dot += g[k] * b[k];
+    for (int k = 1; k < K; ++k) acc[k] += wgt * b[k] * (g[k] - dot);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int k = 1; k < K; ++k) {
+    float v = wave_sum(acc[k]);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < L) {
+    int k = threadIdx.x;
+    float v = (k >= 1 && k < K) ? red[0][k] + red[1][k] + red[2][k] + red[3][k] : 0.f;
+    gsgc[((long)n * h * w + cell) * L + k] = v;
+  }
+}
+
+extern "C" {
+
+// ER loss from the low-res NHWC maps cam/sgc [N,h,w,L] for an H x W image (train_mcl.py:175-188 + MuSCLe.py:256-257 fused).
+// state buffers as mx_er_fwd (prefix and sum_gt zeroed by the caller); nothing of size H*W is allocated.
+int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
+                 unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss,
+                 void* stream) {
+  MX_CHECK_ARG(cam && sgc && lwb && krem && prefix && sum_gt && cnt_eq && hcnt && hsum && loss, "er_lr_fwd: null pointer");
+  MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && H > 0 && W > 0, "er_lr_fwd: bad extents");
+  MX_CHECK_ARG(k >= 1 && k <= (long)K * H * W, "er_lr_fwd: k=%ld out of range for rows of %ld (torch.topk would raise)", k, (long)K * H * W);
+  hipStream_t st = (hipStream_t)stream;
+  hipMemsetD32Async((hipDeviceptr_t)krem, (int)(unsigned)k, N, st);
+  const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
+  const unsigned himask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
+  long HW = (long)H * W;
+  int chunks = (int)((HW + 4095) / 4096);
+  if (chunks > 256) chunks = 256;
+  for (int ps = 0; ps < 3; ++ps) {
+    hipMemsetAsync(hcnt, 0, sizeof(unsigned) * N * RBINS, st);
+    hipMemsetAsync(hsum, 0, sizeof(float) * N * RBINS, st);
+    hipLaunchKernelGGL(er_lr_hist_kernel, dim3(chunks, N), dim3(256), 0, st, cam, sgc, lwb, h, w, L, K, H, W, shifts[ps], bits[ps],
+                       himask[ps], prefix, hcnt, hsum);
+    hipLaunchKernelGGL(er_scan_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
+                       cnt_eq, N);
+  }
+  hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)k), loss);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix, const unsigned* krem,
+                 const unsigned* cnt_eq, const float* gup, float gscale, float* gsgc, int N, int h, int w, int L, int K, int H,
+                 int W, void* stream) {
+  MX_CHECK_ARG(cam && sgc && lwb && prefix && krem && cnt_eq && gsgc, "er_lr_bwd: null pointer");
+  MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L <= 256 && H > 0 && W > 0, "er_lr_bwd: bad extents");
+  hipLaunchKernelGGL(er_lr_bwd_kernel, dim3(h * w, N), dim3(256), 0, (hipStream_t)stream, cam, sgc, lwb, prefix, krem, cnt_eq, gup,
+                     gscale, gsgc, h, w, L, K, H, W);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -72,6 +72,45 @@ class _ERLoss(torch.autograd.Function):
         return None, out, None, None
 
 
+class _ERLossLowRes(torch.autograd.Function):
+    """The same loss from the low-resolution NHWC maps [N,h,w,24] of MuSCLe.forward(cam='cam_lr'): upsampling,
+    cam_softmaxnorm, mask, |diff| and the top-k select are recomputed per pixel inside the kernels."""
+
+    @staticmethod
+    def forward(ctx, cam_lr, sgc_lr, lwb, k, H, W):
+        cam_lr, sgc_lr, lwb = cam_lr.contiguous().float(), sgc_lr.contiguous().float(), lwb.contiguous().float()
+        N, h, w, L = cam_lr.shape
+        K = lwb.shape[1]
+        if k > K * H * W:
+            raise RuntimeError(f"selected index k={k} out of range for rows of {K * H * W} (torch.topk raises the same)")
+        dev = cam_lr.device
+        st_u = torch.zeros(3, N, dtype=torch.int32, device=dev)          # krem, prefix, cnt_eq
+        sum_gt = torch.zeros(N, dtype=torch.float32, device=dev)
+        hcnt = torch.empty(N * _RBINS, dtype=torch.int32, device=dev)
+        hsum = torch.empty(N * _RBINS, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
+        call("mx_er_lr_fwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), N, h, w, L, K, H, W, int(k), ptr(st_u[0]), ptr(st_u[1]),
+             ptr(sum_gt), ptr(st_u[2]), ptr(hcnt), ptr(hsum), ptr(loss), stream())
+        ctx.save_for_backward(cam_lr, sgc_lr, lwb, st_u)
+        ctx.dims = (int(k), H, W)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        cam_lr, sgc_lr, lwb, st_u = ctx.saved_tensors
+        k, H, W = ctx.dims
+        N, h, w, L = cam_lr.shape
+        out = torch.empty_like(sgc_lr)
+        gup = g.contiguous().float().reshape(1)
+        call("mx_er_lr_bwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), ptr(st_u[1]), ptr(st_u[0]), ptr(st_u[2]), ptr(gup),
+             1.0 / (N * k), ptr(out), N, h, w, L, lwb.shape[1], H, W, stream())
+        return None, out, None, None, None, None
+
+
+def er_loss_lowres(cam_lr, sgc_lr, label_with_bg, valid_channel: int, H: int, W: int):
+    return _ERLossLowRes.apply(cam_lr, sgc_lr, label_with_bg, int(0.2 * valid_channel * H * W), H, W)
+
+
 def er_loss(raw_cams, raw_sgcs, label_with_bg, valid_channel: int):
     n, c, h, w = raw_cams.shape
     return _ERLoss.apply(raw_cams, raw_sgcs, label_with_bg, int(0.2 * valid_channel * h * w))
@@ -81,7 +120,7 @@ def er_loss(raw_cams, raw_sgcs, label_with_bg, valid_channel: int):
 # loop body
 # ---------------------------------------------------------------------------
 def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_u=None, crop_geom=None,
-             valid_channel: Optional[int] = None, grad_hook=None, imc_sync: bool = False):
+             valid_channel: Optional[int] = None, grad_hook=None, imc_sync: bool = False, fused_er: bool = True):
     """One iteration of train_mcl.py:153-229 on the HIP path: same order, same epoch gates (4/8/12), same
     loss composition, two optimizer steps once ep >= 8.
 
@@ -92,6 +131,8 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
     gradient all-reduce plugs in here (muscle_amd.dist).
     imc_sync: reproduce the reference's Python-float fall-through for IMC with a device->host read
     (default: add the device-side loss, which is exactly 0 with zero gradient in that case).
+    fused_er: compute the ER term from the low-resolution CAM / SGC (same numbers; the two [N,21,H,W] maps of
+    MuSCLe.py:256-257 are never materialised).  False = go through the public forward(cam='cam') tensors.
     Returns the dict of the seven loss terms train_mcl.py:243-249 prints.
     """
     img, label = batch["img"], batch["label"].float()
@@ -100,7 +141,10 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
     model.train()
     n = label.shape[0]
     label_with_bg = torch.cat((torch.ones((n, 1), dtype=label.dtype, device=label.device), label), dim=1)
-    raw_cams, raw_sgcs, emb, logits = model(img, cam="cam", drop_u=drop_u)
+    if fused_er:
+        cam_lr, sgc_lr, emb, logits = model(img, cam="cam_lr", drop_u=drop_u)
+    else:
+        raw_cams, raw_sgcs, emb, logits = model(img, cam="cam", drop_u=drop_u)
     if valid_channel is None:
         valid_channel = int(label.sum().cpu())
     p = L.sigmoid(logits[:, 1:])
@@ -108,7 +152,10 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
     out["loss_softmargin"] = L.MultiLabelSoftMarginLoss()(logits[:, 1:], label)
     out["loss_pair"] = L.Log_Sum_Exp_Pairwise_Loss(p, label).mean()
     loss_cls = out["loss_pair"] + out["loss_softmargin"] + out["loss_focal"]
-    out["loss_er"] = er_loss(raw_cams, raw_sgcs, label_with_bg, valid_channel)
+    if fused_er:
+        out["loss_er"] = er_loss_lowres(cam_lr.detach(), sgc_lr, label_with_bg, valid_channel, img.shape[2], img.shape[3])
+    else:
+        out["loss_er"] = er_loss(raw_cams, raw_sgcs, label_with_bg, valid_channel)
     loss = loss_cls + out["loss_er"]
     out["loss_imc"] = 0
     if ep >= 4:

@@ -175,6 +175,34 @@ def test_adam_golden():
 PHASE1 = ["step_b0_ep0.npz", "step_b0_ep4.npz", "step_b0_ep4_imc0.npz", "step_b7_ep4.npz"]
 
 
+def test_er_lowres_matches_fullres():
+    """The fused low-resolution ER kernels against the materialised path (public forward + full-res ER kernel)."""
+    import muscle_amd as M
+    from muscle_amd.train_step import er_loss_lowres
+    cfg, sd, model = build("efficientnet-b0", 9)
+    n, size = 3, 80
+    x = T(synth.normal(9, "x", (n, 3, size, size)).astype(np.float32)).to(DEV)
+    lab = T(synth.synth_labels(n, 9)).to(DEV)
+    lwb = torch.cat((torch.ones(n, 1, device=DEV), lab), 1)
+    du = {k: v.to(DEV) for k, v in gu.drop_draws(cfg, n, 5).items()}
+    model.train()
+    cams, sgc, _, _ = model(x, cam="cam", drop_u=du)
+    l_full = M.er_loss(cams.detach(), sgc, lwb, int(lab.sum()))
+    model.zero_grad(); l_full.backward()
+    g_full = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    cfg, sd, model2 = build("efficientnet-b0", 9)
+    model2.train()
+    cam_lr, sgc_lr, _, _ = model2(x, cam="cam_lr", drop_u=du)
+    l_lr = er_loss_lowres(cam_lr.detach(), sgc_lr, lwb, int(lab.sum()), size, size)
+    l_lr.backward()
+    close(l_lr, float(l_full), 2e-5)
+    for k, p in model2.named_parameters():
+        if k in g_full:
+            sc = float(g_full[k].abs().max())
+            if sc > 1e-7:
+                assert float((p.grad - g_full[k]).abs().max()) <= 2e-3 * sc + 1e-9, k
+
+
 @pytest.mark.parametrize("fname", PHASE1)
 @pytest.mark.parametrize("imc_sync", [False, True])
 def test_mcl_step_phase1_golden(fname, imc_sync):

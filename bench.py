@@ -123,11 +123,18 @@ def main():
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch N>1 with torch.distributed.run")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the product path has no CPU fallback)")
+    import torch.distributed as dist
+    # MUSCLE_DIST_BACKEND=gloo + MUSCLE_SHARE_GPU=1: rehearsal of the N>1 flow with all ranks on one GPU (tests only)
+    backend = os.environ.get("MUSCLE_DIST_BACKEND", "nccl")
+    if os.environ.get("MUSCLE_SHARE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    import torch.distributed as dist
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import muscle_amd
     from muscle_amd.dist import GradAverager, broadcast_parameters
@@ -155,6 +162,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    host_t0 = [0.0]
+
     barrier()
     timer.on = (rank == 0)
     t0 = time.perf_counter()
@@ -164,7 +173,7 @@ def main():
     dt = time.perf_counter() - t0
     timer.on = False
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t)
     if rank != 0:

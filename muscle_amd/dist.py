@@ -24,11 +24,15 @@ class GradAverager:
         if self.world == 1:
             return
         arena = model.last_grad_sink.arena
-        if arena.is_cuda:
-            dist.all_reduce(arena, op=dist.ReduceOp.AVG, group=self.group)
-        else:                                      # gloo (CPU tests) has no AVG
-            dist.all_reduce(arena, op=dist.ReduceOp.SUM, group=self.group)
-            arena.div_(self.world)
+        if dist.get_backend(self.group) == "nccl":
+            dist.all_reduce(arena, op=dist.ReduceOp.AVG, group=self.group)         # RCCL over xGMI
+        else:
+            # gloo: CPU unit tests, and single-GPU rehearsals of the multi-process flow (no AVG, host staging)
+            buf = arena.cpu() if arena.is_cuda else arena
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf.div_(self.world)
+            if arena.is_cuda:
+                arena.copy_(buf)
         self.bytes_reduced += arena.numel() * 4
 
 
@@ -36,5 +40,11 @@ def broadcast_parameters(model, src: int = 0, group=None):
     """Make every replica start from rank `src`'s parameters and buffers."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
+    gloo = dist.get_backend(group) != "nccl"
     for t in list(model.parameters()) + list(model.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+        if gloo and t.is_cuda:
+            buf = t.data.cpu()
+            dist.broadcast(buf, src=src, group=group)
+            t.data.copy_(buf)
+        else:
+            dist.broadcast(t.data, src=src, group=group)

@@ -198,3 +198,19 @@ def synth_drop_masks(cfg: NetCfg, n: int, seed: int = 0, tag: str = "drop") -> D
     floor(keep + u).  Replayed on both sides so parity does not depend on torch's RNG."""
     return {b.index: uniform(seed, f"{tag}:{b.index}", (n,)).astype(np.float32)
             for b in cfg.blocks if b.skip and b.drop_rate > 0}
+
+
+def synth_soft_mask(label: np.ndarray, size: int, seed: int = 0) -> np.ndarray:
+    """Config-4 pseudo-label [N, 21, S, S] float32 (what VOC12SegDataset yields, src/data.py:69-123): background
+    0.35 everywhere plus one soft disc per positive class."""
+    n, nf = label.shape
+    m = np.zeros((n, nf + 1, size, size), dtype=np.float32)
+    m[:, 0] = 0.35
+    yy, xx = np.mgrid[0:size, 0:size].astype(np.float32)
+    for i in range(n):
+        u = uniform(seed, f"mask:{i}", (nf, 3))
+        for c in np.nonzero(label[i])[0]:
+            cy, cx, r = (0.2 + 0.6 * u[c, 0]) * size, (0.2 + 0.6 * u[c, 1]) * size, (0.15 + 0.2 * u[c, 2]) * size
+            d = np.sqrt((yy - cy) ** 2 + (xx - cx) ** 2)
+            m[i, c + 1] = np.clip(1.0 - d / r, 0.0, 1.0).astype(np.float32)
+    return m

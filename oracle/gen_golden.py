@@ -430,6 +430,136 @@ def gen_forward(src, name, n, size, seed, fname):
     print(fname, "emb", out["emb"].shape, "cams max", float(cams.max()), "eval cams max", float(cams_e.max()))
 
 
+# ---------------------------------------------------------------------------
+# config 4: decoder mode + BEACON FieldLoss (train_muscle.py:171-203)
+# ---------------------------------------------------------------------------
+def muscle_loop_body():
+    with open(os.path.join(REF, "train_muscle.py")) as f:
+        tree = ast.parse(f.read())
+    main = [n for n in tree.body if isinstance(n, ast.If)][-1]
+    ep_loop = [n for n in main.body if isinstance(n, ast.For) and getattr(n.target, "id", "") == "ep"][0]
+    it_loop = [n for n in ep_loop.body if isinstance(n, ast.For)][0]
+    stmts = [s_ for s_ in it_loop.body if s_.end_lineno <= 203]
+    return compile(ast.Module(stmts, []), "train_muscle.py", "exec")
+
+
+def smooth_field(seed, name, shape, passes=3):
+    """Deterministic smooth random maps (box-blurred noise) so class boundaries are clean curves."""
+    x = torch.from_numpy(synth.normal(seed, name, shape).astype(np.float32))
+    k = torch.ones(shape[1], 1, 5, 5) / 25.0
+    for _ in range(passes):
+        x = torch.nn.functional.conv2d(x, k, padding=2, groups=shape[1])
+    return (x / x.std()).contiguous()
+
+
+def gen_field_units(src, fname="units_field.npz", seed=4):
+    import random
+    import src.edge as ref_edge
+    n, c, ch, hw, kk, step = 2, 21, 16, 64, 8, 3
+    seg = smooth_field(seed, "fl.seg", (n, c, hw, hw)) * 0.05
+    ft = smooth_field(seed, "fl.ft", (n, ch, hw, hw), 1).requires_grad_()
+    lab = synth.synth_labels(n, seed)
+    lab[:, :] = 0
+    lab[0, [2, 7]] = 1
+    lab[1, [7, 11, 14]] = 1
+    mask = torch.from_numpy(synth.synth_soft_mask(lab, hw, seed))
+    lwb = torch.cat((torch.ones(n, 1), torch.from_numpy(lab)), 1)
+    crit = ref_edge.FieldLoss(sobel_size=5, beta=1e2, k=kk)
+    random.seed(77)
+    loss, edge_fg = crit(seg, ft, mask, lwb, step)
+    out = {"meta": np.array([n, c, ch, hw, kk, step, seed]), "label": lab,
+           "is_tensor": np.array(torch.is_tensor(loss)), "edge_fg": edge_fg.numpy()}
+    if torch.is_tensor(loss):
+        loss.backward()
+        out["loss"], out["dft"] = np.array(float(loss)), ft.grad.numpy()
+    # degenerate: no foreground label -> no boundary pixel survives the label mask -> returns False (edge.py:376-378)
+    l0, _ = crit(seg, ft.detach(), mask, torch.cat((torch.ones(n, 1), torch.zeros(n, c - 1)), 1), step)
+    out["nolabel_returns_false"] = np.array(l0 is False)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "loss", out.get("loss"), "grad nnz", int((out.get("dft", np.zeros(1)) != 0).sum()))
+
+
+def gen_muscle_step(src, name, n, size, seed, fname, lamb, k, step, lr=1e-5, torch_seed=13):
+    import random
+    import src.edge as ref_edge
+    cfg = net_cfg(name, True)
+    sd = synth.synth_state_dict(cfg, seed, mode="dec", layers=3)
+    model = src.MuSCLe(num_classes=21, pretrained=name, layers=3, MemoryEfficient=True, last_pooling=True, mode="dec")
+    model.load_state_dict({k_: torch.from_numpy(np.asarray(v)) for k_, v in sd.items()}, strict=True)
+    lab = synth.synth_labels(n, seed)
+    img = torch.from_numpy(synth.normal(seed, "img", (n, 3, size, size)).astype(np.float32))
+    mask = torch.from_numpy(synth.synth_soft_mask(lab, size, seed))
+    opt = torch.optim.Adam(params=model.parameters(), lr=lr, weight_decay=1e-5)
+    rec = RecordingAdam(model, opt)
+    torch.manual_seed(torch_seed)
+    drop_u = [torch.rand([n, 1, 1, 1]).view(-1).numpy().copy() for b in cfg.blocks if b.skip and b.drop_rate]
+    drop_idx = [b.index for b in cfg.blocks if b.skip and b.drop_rate]
+
+    class Args:
+        pass
+    args = Args()
+    args.lamb, args.step = lamb, step
+    ns = dict(torch=torch, model=model, optimizer=rec, args=args, criterion1=torch.nn.CrossEntropyLoss(),
+              criterion2=ref_edge.FieldLoss(sobel_size=5, beta=1e2, k=k),
+              pack=("name", img, torch.from_numpy(lab), mask))
+    model.train()
+    random.seed(78)
+    torch.manual_seed(torch_seed)
+    clip_log = []
+    real_clip = torch.nn.utils.clip_grad_norm_
+
+    def logging_clip(params, max_norm, norm_type=2):
+        tn = real_clip(params, max_norm, norm_type=norm_type)
+        clip_log.append(float(tn))
+        return tn
+    torch.nn.utils.clip_grad_norm_ = logging_clip
+    try:
+        exec(muscle_loop_body(), ns)
+    finally:
+        torch.nn.utils.clip_grad_norm_ = real_clip
+    out = {
+        "meta": np.array([n, size, seed, torch_seed, k, step], dtype=np.int64), "name": np.array(name),
+        "lamb": np.array(lamb), "lr": np.array(lr),
+        "drop_idx": np.array(drop_idx, dtype=np.int64), "drop_u": np.array(drop_u, dtype=np.float32).reshape(len(drop_idx), n),
+        "losses": np.array([float(ns["l1"]), float(ns["l2"])]), "l2_is_tensor": np.array(torch.is_tensor(ns["l2"])),
+        "grad_norm": np.array(clip_log),
+        "seg_map_s4": ns["seg_map"].detach().numpy()[:, :, ::4, ::4].copy() if "seg_map" in ns else np.zeros(1),
+        "param_keys": np.array([k_ for k_, _ in model.named_parameters()]),
+        "grad1": rec.records[0][0], "delta1": rec.records[0][1], "bn_after": bn_summary(model),
+    }
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "losses", out["losses"], "grad norm", clip_log)
+
+
+def gen_seg_forward(src, name, n, size, seed, fname):
+    cfg = net_cfg(name, True)
+    sd = synth.synth_state_dict(cfg, seed, mode="dec", layers=3)
+    model = src.MuSCLe(num_classes=21, pretrained=name, layers=3, MemoryEfficient=True, last_pooling=True, mode="dec")
+    model.load_state_dict({k_: torch.from_numpy(np.asarray(v)) for k_, v in sd.items()}, strict=True)
+    x = torch.from_numpy(synth.normal(seed, "fwd.x", (n, 3, size, size)).astype(np.float32))
+    torch.manual_seed(31)
+    drop_u = [torch.rand([n, 1, 1, 1]).view(-1).numpy().copy() for b in cfg.blocks if b.skip and b.drop_rate]
+    model.train()
+    torch.manual_seed(31)
+    seg, ft = model(x, cam="seg")
+    out = {"meta": np.array([n, size, seed], dtype=np.int64), "name": np.array(name),
+           "drop_idx": np.array([b.index for b in cfg.blocks if b.skip and b.drop_rate], dtype=np.int64),
+           "drop_u": np.array(drop_u, dtype=np.float32),
+           "seg_s4": seg.detach().numpy()[:, :, ::4, ::4].copy(), "ft_s8": ft.detach().numpy()[:, :, ::8, ::8].copy(),
+           "seg_stats": np.array([float(seg.double().sum()), float(seg.double().pow(2).sum())]),
+           "ft_stats": np.array([float(ft.double().sum()), float(ft.double().pow(2).sum())]),
+           "bn_after": bn_summary(model)}
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "seg absmax", float(seg.abs().max()))
+
+
+def main_config4(src):
+    gen_field_units(src)
+    gen_seg_forward(src, "efficientnet-b3", 2, 96, 21, "seg_forward_b3.npz")
+    gen_muscle_step(src, "efficientnet-b3", 2, 96, 22, "muscle_step_b3_ce.npz", lamb=0.0, k=8, step=3)
+    gen_muscle_step(src, "efficientnet-b3", 2, 128, 23, "muscle_step_b3_beacon.npz", lamb=0.05, k=8, step=3)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -450,6 +580,7 @@ def main():
     gen_step(src, tree, "efficientnet-b0", 4, 96, 64, 12, 0, "step_b0_ep12_lr0.npz", lr=0.0)
     gen_step(src, tree, "efficientnet-b3", 4, 64, 64, 12, 6, "step_b3_ep12_lr0.npz", lr=0.0)
     gen_step(src, tree, "efficientnet-b7", 4, 64, 32, 4, 8, "step_b7_ep4.npz")
+    main_config4(src)
 
 
 if __name__ == "__main__":

@@ -220,6 +220,34 @@ int mx_emd_best(const float* score, const int* pairs, int npairs, int nsamples, 
 int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsamples, int maxn1, int maxn2, float* traj,
                 const float* gup, float gscale, float* gx, void* stream);
 
+/* ---- decoder mode / config 4: BiFPN support, CE, gradient clipping, BEACON FieldLoss ------------------------------ */
+
+/* F.avg_pool2d(k=3,s=2,p=1) on NHWC (MuSCLe.py:51,54); bwd: x = pooled gradient, y = input gradient */
+int mx_avgpool3s2(const float* x, float* y, int N, int H, int W, int C, int bwd, void* stream);
+/* adjoint of mx_resize_nhwc (no relu): gsrc += W^T gdst */
+int mx_resize_nhwc_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int C, int Hd, int Wd, void* stream);
+/* CrossEntropyLoss(seg [N,K,HW], argmax_k mask) (train_muscle.py:189-191): loss[0] += mean; bwd: gseg = gup[0]*dL/dseg */
+int mx_ce_argmax(const float* seg, const float* mask, const float* gup, float* loss, float* gseg, int N, int K, long HW, int bwd,
+                 void* stream);
+/* clip_grad_norm_(max_norm, 2) on a flat gradient arena (train_muscle.py:202); norm_out (optional) = total norm */
+int mx_clip_grad_norm(float* grads, long n, float max_norm, double* sq_scratch, float* norm_out, void* stream);
+/* FieldLoss stage 1 (edge.py:423-440,45-89): softmax(beta*seg)[1:], 5x5 Sobel per labelled class, magnitude,
+ * 8-way orientation, per-(n,class) max (float bits), edge_fg = sum over classes */
+int mx_field_edges(const float* seg, const float* lab_fg, float beta, float* prob, float* mag, unsigned char* orient, unsigned* mx,
+                   float* edge_fg, int N, int K, int H, int W, void* stream);
+/* stage 2 (edge.py:196-229,372-375): per slot {n,class}: ordered out / in point lists [S][H*W], counts [S][3] */
+int mx_field_select(const float* mag, const unsigned char* orient, const unsigned* mx, const int* slots, int nslots, int step,
+                    int* out_list, int* in_list, int* counts, int F, int H, int W, void* stream);
+/* stage 3: channel-softmaxed dense features (mode 0 full-res NCHW, mode 1 low-res NHWC upsampled on the fly) and
+ * class-softmaxed mask at the sampled points pts {n, pixel} */
+int mx_field_gather(const float* dense, int mode, int h, int w, const float* mask, const int* pts, int npts, float* feat, float* mfeat,
+                    int CH, int K, int ML, int H, int W, void* stream);
+/* stage 5 (edge.py:231-261,330-347): loss += terms/nsamples, gsim = d loss / d sim, per slot of k x k similarities */
+int mx_field_terms(const float* sim, const float* simm, int nslots, int k, float inv_n, float* loss, float* gsim, void* stream);
+/* stage 6: softmax backward at the out points, scattered (+=) into the dense-feature gradient */
+int mx_field_scatter(const float* feat, const float* gfeat, const int* pts, int npts, int mode, int h, int w, const float* gup,
+                     float* gdense, int CH, int H, int W, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

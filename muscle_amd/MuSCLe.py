@@ -9,7 +9,7 @@ Same constructor, same `forward(x, cam=...)` return tuples, same `state_dict()` 
   * it only runs on a ROCm GPU: on CPU tensors forward() raises (there is no fallback path);
   * parameter gradients are written to `p.grad` by the module's own backward (they are views of
     one flat fp32 arena, which is what the DP all-reduce and the fused Adam consume).
-`mode='dec'` (BiFPN decoder of train_muscle.py) is not built yet.
+`mode='dec'` builds the BiFPN decoder of train_muscle.py (muscle_amd/dec.py): forward(x, cam='seg'|'vis').
 """
 from __future__ import annotations
 
@@ -18,7 +18,7 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
-from . import engine, ops
+from . import dec, engine, ops
 from ._lib import MuscleHipError
 from .arch import net_cfg
 from .efficientnet import EfficientNet
@@ -35,6 +35,7 @@ class _ArenaSink(engine.GradSink):
 
     def __init__(self, params: List[nn.Parameter]):
         super().__init__()
+        self.touched = set()
         total = sum((p.numel() + 3) // 4 * 4 for p in params)
         self.arena = torch.zeros(total, dtype=torch.float32, device=params[0].device)
         self.params = params
@@ -44,6 +45,7 @@ class _ArenaSink(engine.GradSink):
             off += (p.numel() + 3) // 4 * 4
 
     def of(self, p):
+        self.touched.add(id(p))
         return self.bufs[id(p)]
 
 
@@ -82,7 +84,8 @@ class MuSCLe(nn.Module):
             self.pool = nn.AdaptiveAvgPool2d((1, 1))
             self.fc = nn.Linear(tc[6], num_classes, bias=False)
         else:
-            raise NotImplementedError("mode='dec' (BiFPN decoder, src/MuSCLe.py:115-148) is not built yet")
+            self.layers = layers
+            self.BIFPN = dec.BIFPN(tc, layers, bifpn_channels)
         self.fuse_dec = nn.Conv2d(bifpn_channels, num_classes, 1)
         self.logits = None
         self._anchor = torch.zeros(1, requires_grad=True)      # makes autograd call our backward; not a parameter
@@ -97,6 +100,9 @@ class MuSCLe(nn.Module):
         last = self.cfg.taps[6]
         for blk in self.backbone._blocks[:last + 1]:
             ps += list(blk.parameters())
+        if self.mode != "enc":
+            # candidates; the dead branches of the last BiFPN layer (out4..out7) never get touched and keep grad None
+            return ps + list(self.BIFPN.parameters()) + [self.fuse_dec.weight, self.fuse_dec.bias]
         ps += [self.fuse.weight, self.fuse.bias]
         if cam_mode in ("cam", "logits", "cam_lr"):
             ps.append(self.fc.weight)
@@ -106,11 +112,21 @@ class MuSCLe(nn.Module):
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, cam="cam", drop_u: Optional[Dict[int, torch.Tensor]] = None):
-        if cam not in ("logits", "cam", "pix", "cam_lr"):
-            raise NotImplementedError(f"forward(cam={cam!r}) needs the BiFPN decoder (mode='dec'), not built yet")
+        if cam in ("seg", "vis", "seg_p3"):
+            if self.mode == "enc":
+                raise AttributeError("forward(cam='seg') needs MuSCLe(mode='dec') (the encoder model has no BIFPN)")
+        elif cam in ("logits", "cam", "pix", "cam_lr"):
+            if self.mode != "enc":
+                raise AttributeError(f"forward(cam={cam!r}) needs MuSCLe(mode='enc') (the decoder model has no fc / fuse)")
+        else:
+            raise ValueError(f"unknown cam mode {cam!r}")
         if not x.is_cuda:
             raise MuscleHipError("MuSCLe.forward runs on the HIP kernels only: move the model and input to a ROCm GPU")
         x = x.contiguous().float()
+        if cam == "vis":                                   # MuSCLe.py:290-298: no_grad seg forward, returns (seg_map, p7)
+            with torch.no_grad():
+                seg_map, p7 = _Forward.apply(x, self._anchor, self, "vis", drop_u)
+            return seg_map, p7
         outs = _Forward.apply(x, self._anchor, self, cam, drop_u)
         if cam == "logits":
             self.logits = outs[1]
@@ -120,7 +136,88 @@ class MuSCLe(nn.Module):
             return outs[0], outs[1], outs[2], outs[3]
         return outs[0], outs[1]
 
+    # ---- decoder mode (MuSCLe.py:281-298) ------------------------------------------------------------
+    def _fuse_dec_padded(self, dev):
+        C = self.fuse_dec.in_channels
+        w = torch.zeros(_CPAD, C, dtype=torch.float32, device=dev)
+        w[:self.classes] = self.fuse_dec.weight.detach().view(self.classes, C)
+        b = torch.zeros(_CPAD, dtype=torch.float32, device=dev)
+        b[:self.classes] = self.fuse_dec.bias.detach()
+        return w, b
+
+    def _run_forward_dec(self, x, mode, drop_u):
+        cfg, K = self.cfg, self.classes
+        N, _, H, W = x.shape
+        tape = engine.backbone_forward(self.backbone, cfg, x, self.training, drop_u)
+        t = cfg.taps
+        feats = [tape.blocks[i].out for i in t[2:7]]
+        tp = dec.Tape(None, self.training)
+        p3 = dec.bifpn_forward(tp, self.BIFPN, feats, cfg.last_pooling)
+        _, h, w, C = p3.shape
+        w24, b24 = self._fuse_dec_padded(x.device)
+        # fuse_dec is linear and the bilinear weights sum to one, so conv(upsample(p3)) == upsample(conv(p3)):
+        # the 1x1 conv runs at 1/8 resolution and only its 21-channel result is upsampled
+        seg_lr = ops.pw_fwd(p3.view(N * h * w, C), w24, _CPAD, bias=b24).view(N, h, w, _CPAD)
+        ht = _HeadTape()
+        ht.h, ht.w, ht.H, ht.W, ht.mode, ht.fcw = h, w, H, W, mode, w24
+        ht.f, ht.T, ht.fs = tp, seg_lr, feats           # reuse slots: BiFPN tape, low-res logits, tap tensors
+        ht.cam = p3
+        seg_map = ops.upsample_to_nchw(seg_lr, K, H, W)
+        if mode == "vis":
+            return (seg_map, tape.blocks[t[6]].out.permute(0, 3, 1, 2).contiguous()), tape, ht
+        if mode == "seg_p3":
+            return (seg_map, p3), tape, ht
+        dense_ft = ops.upsample_to_nchw(p3, C, H, W)
+        return (seg_map, dense_ft), tape, ht
+
+    def _run_backward_dec(self, tape, ht, mode, gouts):
+        cfg, K = self.cfg, self.classes
+        N = tape.N
+        g_seg, g_ft = gouts
+        tp, seg_lr, feats, p3 = ht.f, ht.T, ht.fs, ht.cam
+        _, h, w, C = p3.shape
+        M3 = N * h * w
+        dev = p3.device
+        sink = _ArenaSink(self.live_parameters(mode))
+        for blk_p in sink.params[:0]:
+            pass
+        tp.sink = sink
+        g_p3 = None
+        if g_seg is not None:
+            g_lr = torch.zeros(N, h, w, _CPAD, dtype=torch.float32, device=dev)
+            ops.upsample_to_nchw_bwd(g_seg.contiguous(), g_lr)
+            g2 = g_lr.view(M3, _CPAD)
+            dW = torch.zeros(_CPAD, C, dtype=torch.float32, device=dev)
+            ops.pw_wgrad(g2, p3.view(M3, C), dW)
+            sink.of(self.fuse_dec.weight).view(K, C).add_(dW[:K])
+            sink.of(self.fuse_dec.bias).add_(ops.pool_sum(g2, M3).view(_CPAD)[:K])
+            g_p3 = ops.pw_dgrad(g2, ht.fcw, C).view(N, h, w, C)
+        if g_ft is not None:
+            if mode == "seg_p3":
+                gp = g_ft.contiguous()
+            else:
+                gp = torch.zeros(N, h, w, C, dtype=torch.float32, device=dev)
+                ops.upsample_to_nchw_bwd(g_ft.contiguous(), gp)
+            g_p3 = gp if g_p3 is None else ops.ew(1, g_p3, gp, alpha=1.0)
+        if g_p3 is not None:
+            tp.add_grad(p3, g_p3)
+            tp.run_backward()
+            tap_grads = {}
+            for i, f in zip(cfg.taps[2:7], feats):
+                g = tp.grad(f)
+                if g is not None:
+                    tap_grads[i] = g
+            # backbone parameters are always touched once a gradient reaches the chain
+            engine.backbone_backward(self.backbone, cfg, tape, tap_grads, sink)
+        for p in sink.params:
+            if id(p) in sink.touched:
+                g = sink.bufs[id(p)]
+                p.grad = g if p.grad is None else p.grad + g
+        self.last_grad_sink = sink
+
     def _run_forward(self, x, mode, drop_u):
+        if mode in ("seg", "vis", "seg_p3"):
+            return self._run_forward_dec(x, mode, drop_u)
         cfg, K = self.cfg, self.classes
         N, _, H, W = x.shape
         dev = x.device
@@ -183,6 +280,8 @@ class MuSCLe(nn.Module):
 
     # ---- backward -----------------------------------------------------------------------------------
     def _run_backward(self, tape, ht, mode, gouts):
+        if mode in ("seg", "seg_p3"):
+            return self._run_backward_dec(tape, ht, mode, gouts)
         cfg, K = self.cfg, self.classes
         N = tape.N
         p7 = tape.blocks[cfg.taps[6]].out
@@ -250,7 +349,7 @@ class MuSCLe(nn.Module):
         if g_p7 is not None:
             engine.backbone_backward(self.backbone, cfg, tape, {cfg.taps[6]: g_p7.view(N, h, w, C7)}, sink)
         for p in sink.params:
-            g = sink.of(p)
+            g = sink.bufs[id(p)]
             if p.grad is None:
                 p.grad = g
             else:

@@ -8,10 +8,11 @@ from .MuSCLe import MuSCLe  # noqa: F401
 from .loss_multilabel import (FocalLoss, Log_Sum_Exp_Pairwise_Loss, MultiLabelSoftMarginLoss,  # noqa: F401
                               image_level_contrast)
 from .optim import FusedAdam  # noqa: F401
-from .train_step import cam_softmaxnorm, er_loss, mcl_step  # noqa: F401
+from .train_step import cam_softmaxnorm, er_loss, mcl_step, muscle_step  # noqa: F401
+from . import edge  # noqa: F401
 from .phase2 import EMD, PixPro, cam_maxnorm, get_dynamic_crops  # noqa: F401
 from . import phase2 as torchutils  # noqa: F401  (reference name of the module holding get_dynamic_crops)
 
 __all__ = ["MuSCLe", "FocalLoss", "Log_Sum_Exp_Pairwise_Loss", "MultiLabelSoftMarginLoss", "image_level_contrast",
            "FusedAdam", "cam_softmaxnorm", "er_loss", "mcl_step", "EMD", "PixPro", "cam_maxnorm", "get_dynamic_crops",
-           "torchutils"]
+           "torchutils", "edge", "muscle_step"]

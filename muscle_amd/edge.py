@@ -1,0 +1,166 @@
+"""BEACON boundary loss — drop-in for `src.edge.FieldLoss` (src/edge.py:175-384) on the HIP kernels of csrc/dec.hip, plus
+the cross entropy against the arg-max pseudo-label and the gradient clipping of the train_muscle.py loop body.
+
+The reference walks (sample, class) pairs in Python, thresholds a Sobel edge map of softmax(beta * seg), samples k boundary
+points on each side with `random.sample` and compares k x k similarity matrices of channel-softmaxed dense features and of
+the class-softmaxed soft mask.  Here stages 1-2 (edges, ordered point lists), 3 (feature gather), 4 (similarity GEMMs on
+MFMA), 5 (the eight FP/FN/TP/TN terms and their gradient) and 6 (softmax backward + scatter) are kernels; the host only
+reads the per-class point counts back (the reference synchronises at the same places) and replays Python's `random`
+in the reference's draw order, so a seeded run picks the same points.
+"""
+from __future__ import annotations
+
+import random
+from typing import Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from ._lib import call, ptr, stream
+
+_ML = 24
+
+
+class _FieldLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dense, plan):
+        dev = dense.device
+        S, k, CH = plan["S"], plan["k"], plan["CH"]
+        N, K, H, W = plan["seg_shape"]
+        mode, h, w = plan["mode"], plan["h"], plan["w"]
+        npts = S * k
+        feat = torch.empty(2, npts, CH, dtype=torch.float32, device=dev)          # [out | in]
+        mfeat = torch.empty(2, npts, _ML, dtype=torch.float32, device=dev)
+        for side in (0, 1):
+            call("mx_field_gather", ptr(dense), mode, h, w, ptr(plan["mask"]), ptr(plan["pts"][side]), npts, ptr(feat[side]),
+                 ptr(mfeat[side]), CH, K, _ML, H, W, stream())
+        sim = torch.empty(S, k, k, dtype=torch.float32, device=dev)
+        simm = torch.empty(S, k, k, dtype=torch.float32, device=dev)
+        ops.bgemm(0, feat[0].view(S, k, CH), feat[1].view(S, k, CH), sim, k, k, CH)
+        ops.bgemm(0, mfeat[0].view(S, k, _ML), mfeat[1].view(S, k, _ML), simm, k, k, _ML)
+        loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        gsim = torch.empty_like(sim)
+        call("mx_field_terms", ptr(sim), ptr(simm), S, k, 1.0 / N, ptr(loss), ptr(gsim), stream())
+        ctx.save_for_backward(feat, gsim)
+        ctx.plan = plan
+        ctx.dshape = dense.shape
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, gsim = ctx.saved_tensors
+        plan = ctx.plan
+        S, k, CH = plan["S"], plan["k"], plan["CH"]
+        N, K, H, W = plan["seg_shape"]
+        dev = feat.device
+        gfo = torch.empty(S, k, CH, dtype=torch.float32, device=dev)
+        ops.bgemm(1, gsim, feat[1].view(S, k, CH), gfo, k, CH, k)                   # d sim / d outs = gsim @ ins
+        gd = torch.zeros(ctx.dshape, dtype=torch.float32, device=dev)
+        gup = g.contiguous().float().reshape(1)
+        call("mx_field_scatter", ptr(feat[0]), ptr(gfo), ptr(plan["pts"][0]), S * k, plan["mode"], plan["h"], plan["w"], ptr(gup),
+             ptr(gd), CH, H, W, stream())
+        return gd, None
+
+
+class FieldLoss(nn.Module):
+    def __init__(self, num_classes=21, gaussian_size=7, k=100, guassian_sigma=None, sobel_size=5, beta=1e3):
+        super().__init__()
+        if sobel_size != 5:
+            raise NotImplementedError("the HIP path implements the 5x5 Sobel the reference trains with (train_muscle.py:163)")
+        if k % 4 or k > 256:
+            raise NotImplementedError("k must be a multiple of 4 and <= 256")
+        self.num_fg_cls, self.k, self.beta = num_classes - 1, k, beta
+
+    def forward(self, seg_map, dense_ft, mask, label_with_bg, step=7, dense_is_lowres_nhwc: bool = False):
+        """Returns (loss, edge magnitude [N,H,W]); loss is a tensor, the int 0 when no class has more than k points on
+        both sides, or False when fewer than 10 boundary pixels exist (edge.py:376-383).
+        dense_ft: [N,CH,H,W] as MuSCLe.forward(cam='seg') returns it, or — dense_is_lowres_nhwc — the decoder's
+        1/8-resolution NHWC map, upsampled on the fly at the sampled points only."""
+        seg = seg_map.detach().contiguous().float()
+        N, K, H, W = seg.shape
+        dev = seg.device
+        F_ = K - 1
+        lab = label_with_bg[:, 1:].contiguous().float()
+        HW = H * W
+        prob = torch.empty(N, F_, HW, dtype=torch.float32, device=dev)
+        mag = torch.empty(N, F_, HW, dtype=torch.float32, device=dev)
+        orient = torch.empty(N, F_, HW, dtype=torch.uint8, device=dev)
+        mx = torch.empty(N * F_, dtype=torch.int32, device=dev)
+        edge_fg = torch.empty(N, H, W, dtype=torch.float32, device=dev)
+        call("mx_field_edges", ptr(seg), ptr(lab), float(self.beta), ptr(prob), ptr(mag), ptr(orient), ptr(mx), ptr(edge_fg), N, K,
+             H, W, stream())
+        del prob
+        lab_h = lab.cpu()
+        slots = [(b, c) for b in range(N) for c in range(F_) if lab_h[b, c] != 0]
+        if not slots:
+            return False, edge_fg
+        S0 = len(slots)
+        slots_t = torch.tensor(slots, dtype=torch.int32, device=dev)
+        out_list = torch.empty(S0, HW, dtype=torch.int32, device=dev)
+        in_list = torch.empty(S0, HW, dtype=torch.int32, device=dev)
+        counts = torch.empty(S0, 3, dtype=torch.int32, device=dev)
+        call("mx_field_select", ptr(mag), ptr(orient), ptr(mx), ptr(slots_t), S0, int(step), ptr(out_list), ptr(in_list), ptr(counts),
+             F_, H, W, stream())
+        cnt = counts.cpu().tolist()                       # the reference synchronises here too (boolean indexing)
+        if sum(c[2] for c in cnt) < 10:
+            return False, edge_fg
+        k = self.k
+        sel_out, sel_in, ns = [], [], []
+        for s, (b, c) in enumerate(slots):
+            n_out, n_in = cnt[s][0], cnt[s][1]
+            if n_in > k and n_out > k:
+                r_out = random.sample(range(n_out), k)    # edge.py:298-299: outs first, then ins
+                r_in = random.sample(range(n_in), k)
+                sel_out += [s * HW + r for r in r_out]
+                sel_in += [s * HW + r for r in r_in]
+                ns += [b] * k
+        if not ns:
+            return 0, edge_fg
+        S = len(ns) // k
+        nt = torch.tensor(ns, dtype=torch.int32, device=dev)
+        pts = []
+        for lst, sel in ((out_list, sel_out), (in_list, sel_in)):
+            pix = lst.view(-1)[torch.tensor(sel, dtype=torch.int64, device=dev)]
+            pts.append(torch.stack((nt, pix), dim=1).contiguous())
+        dense = dense_ft.contiguous().float()
+        if dense_is_lowres_nhwc:
+            mode, h, w, CH = 1, dense.shape[1], dense.shape[2], dense.shape[3]
+        else:
+            mode, h, w, CH = 0, 0, 0, dense.shape[1]
+        plan = dict(S=S, k=k, CH=CH, seg_shape=(N, K, H, W), mode=mode, h=h, w=w, pts=pts, mask=mask.detach().contiguous().float())
+        return _FieldLossFn.apply(dense, plan), edge_fg
+
+
+class _CEArgmax(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, seg, mask):
+        seg, mask = seg.contiguous().float(), mask.contiguous().float()
+        N, K, H, W = seg.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=seg.device)
+        call("mx_ce_argmax", ptr(seg), ptr(mask), None, ptr(loss), None, N, K, H * W, 0, stream())
+        ctx.save_for_backward(seg, mask)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        seg, mask = ctx.saved_tensors
+        N, K, H, W = seg.shape
+        out = torch.empty_like(seg)
+        call("mx_ce_argmax", ptr(seg), ptr(mask), ptr(g.contiguous().float().reshape(1)), None, ptr(out), N, K, H * W, 1, stream())
+        return out, None
+
+
+def cross_entropy_argmax(seg_map, soft_mask):
+    """nn.CrossEntropyLoss()(seg_map, torch.argmax(soft_mask, dim=1)) (train_muscle.py:189-191) in one kernel."""
+    return _CEArgmax.apply(seg_map, soft_mask)
+
+
+def clip_grad_norm_(model, max_norm: float):
+    """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) on the model's flat gradient arena
+    (train_muscle.py:202).  Returns the total norm as a 0-dim device tensor (no host synchronisation)."""
+    arena = model.last_grad_sink.arena
+    sq = torch.empty(1, dtype=torch.float64, device=arena.device)
+    norm = torch.empty(1, dtype=torch.float32, device=arena.device)
+    call("mx_clip_grad_norm", ptr(arena), arena.numel(), float(max_norm), ptr(sq), ptr(norm), stream())
+    return norm[0]

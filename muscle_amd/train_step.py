@@ -177,3 +177,33 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
         from . import phase2
         phase2.run(model, optimizer, batch, ep, label_with_bg, out, crop_geom=crop_geom, grad_hook=grad_hook)
     return out
+
+
+def muscle_step(model, optimizer, batch: Dict[str, torch.Tensor], *, lamb: float = 0.05, step: int = 7, k: int = 128,
+                criterion2=None, drop_u=None, grad_hook=None, fused: bool = True):
+    """One iteration of train_muscle.py:171-203 on the HIP path: seg forward of MuSCLe(mode='dec'), cross entropy against the
+    arg-max of the soft pseudo-label, lamb * BEACON FieldLoss, backward, clip_grad_norm_(9), optimizer step.
+    batch: {"img" [N,3,S,S], "label" [N,20], "mask" [N,21,S,S]} on the GPU.
+    fused: the FieldLoss samples the decoder's 1/8-resolution features at the chosen points (the [N,256,S,S] dense_ft of
+    MuSCLe.py:285 is never materialised); False goes through the public forward(cam='seg') tensors."""
+    from . import edge
+    img, label, mask = batch["img"], batch["label"].float(), batch["mask"]
+    optimizer.zero_grad()
+    model.train()
+    n = label.shape[0]
+    label_with_bg = torch.cat((torch.ones((n, 1), dtype=label.dtype, device=label.device), label), dim=1)
+    seg_map, ft = model(img, cam="seg_p3" if fused else "seg", drop_u=drop_u)
+    l1 = edge.cross_entropy_argmax(seg_map, mask)
+    loss, l2 = l1, 0
+    if lamb > 0:
+        crit = criterion2 if criterion2 is not None else edge.FieldLoss(sobel_size=5, beta=1e2, k=k)
+        l2, _ = crit(seg_map, ft, mask, label_with_bg, step, dense_is_lowres_nhwc=fused)
+        if torch.is_tensor(l2):
+            loss = l1 + lamb * l2
+    optimizer.zero_grad()
+    loss.backward()
+    if grad_hook is not None:
+        grad_hook(model, 1)
+    total = edge.clip_grad_norm_(model, 9)
+    optimizer.step()
+    return {"loss_seg": l1, "loss_beacon": l2, "grad_norm": total}

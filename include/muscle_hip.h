@@ -67,9 +67,10 @@ int mx_bn_finalize(const float* part, int P, int C, double count, const float* g
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                    float* mean, float* rstd, double* acc, void* stream);
 
-/* out = (scale[c]*P + shift[c]) [swish if act] [* row_scale[n]] [+ residual]   (BN2 + drop_connect + skip) */
+/* out = (scale[c]*P + shift[c]) [swish if act] [* gate[n,c]] [* row_scale[n]] [+ residual]
+ * (BN2 + drop_connect + skip; with act + gate: the activated, SE-gated project-conv input, model.py:78-84) */
 int mx_bn_apply(const float* P, const float* scale, const float* shift, const float* row_scale, const float* residual,
-                float* out, long rows, int C, int rows_per_sample, int act, void* stream);
+                const float* gate, float* out, long rows, int C, int rows_per_sample, int act, void* stream);
 
 /* effective upstream gradient  g = G [* row_scale[n]] ; [g = g*gate[n,c] + gate_add[n,c]] ;
  * [g *= swish'(act_scale[c]*X + act_shift[c])] ;  part[mx_colreduce_parts(rows,C)][2][C] = partial (sum g, sum g*X) */

@@ -269,9 +269,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc,
 // ---------------------------------------------------------------------------
 // streaming elementwise kernels
 // ---------------------------------------------------------------------------
-// out = (sc[c]*P + sh[c]) [swish] [* rs[n]] [+ R]
+// out = (sc[c]*P + sh[c]) [swish] [* gate[n,c]] [* rs[n]] [+ R]
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* P, const float* sc, const float* sh, const float* rs,
-                                                       const float* R, float* out, long total4, int C, int rps, int act) {
+                                                       const float* R, const float* gate, float* out, long total4, int C,
+                                                       int rps, int act) {
   const int c4n = C / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
     long r = i / c4n;
@@ -280,6 +281,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* P, const flo
     float4 a = ld4(sc + c), b = ld4(sh + c);
     v.x = a.x * v.x + b.x; v.y = a.y * v.y + b.y; v.z = a.z * v.z + b.z; v.w = a.w * v.w + b.w;
     if (act) { v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w); }
+    if (gate) { float4 g = ld4(gate + (r / rps) * C + c); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
     if (rs) { float s = rs[r / rps]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
     if (R) { float4 q = ld4(R + i * 4); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
     st4(out + i * 4, v);
@@ -337,11 +339,11 @@ int mx_bn_finalize(const float* part, int P, int C, double count, const float* g
 }
 
 int mx_bn_apply(const float* P, const float* scale, const float* shift, const float* row_scale, const float* residual,
-                float* out, long rows, int C, int rows_per_sample, int act, void* stream) {
+                const float* gate, float* out, long rows, int C, int rows_per_sample, int act, void* stream) {
   MX_CHECK_ARG(P && scale && shift && out && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bn_apply: bad args");
   long total4 = rows * (C / 4);
   hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total4)), dim3(256), 0, (hipStream_t)stream, P, scale, shift,
-                     row_scale, residual, out, total4, C, rows_per_sample, act);
+                     row_scale, residual, gate, out, total4, C, rows_per_sample, act);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

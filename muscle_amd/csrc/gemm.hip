@@ -271,6 +271,8 @@ static const TileCfg kCfgs[] = {
     {128, 64},    // 7: 2x2 waves, 2x1, BK = 32
     {128, 32},    // 8: as 2 with BK = 32
     {128, 96},    // 9: as 1 with BK = 32
+    {256, 128},   // 10: 2x2 waves, 4x2 tiles
+    {128, 256},   // 11: 2x2 waves, 2x4 tiles
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -297,7 +299,9 @@ static void dispatch(const GemmArgs& g, int zdim, hipStream_t st) {
     case 6: launch<LAYOUT, 2, 2, 2, 1>(g, zdim, st); break;
     case 7: launch<LAYOUT, 2, 2, 2, 1, 32>(g, zdim, st); break;
     case 8: launch<LAYOUT, 4, 1, 1, 1, 32>(g, zdim, st); break;
-    default: launch<LAYOUT, 4, 1, 1, 3, 32>(g, zdim, st); break;
+    case 9: launch<LAYOUT, 4, 1, 1, 3, 32>(g, zdim, st); break;
+    case 10: launch<LAYOUT, 2, 2, 4, 2>(g, zdim, st); break;
+    default: launch<LAYOUT, 2, 2, 2, 4>(g, zdim, st); break;
   }
 }
 

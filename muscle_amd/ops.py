@@ -90,11 +90,11 @@ def bn_finalize(stats, count, bn: torch.nn.BatchNorm2d, training: bool) -> BNSta
     return BNState(buf[0], buf[1], buf[2], buf[3])
 
 
-def bn_apply(P2d, st: BNState, *, row_scale=None, residual=None, rows_per_sample=1, act=False, out=None):
+def bn_apply(P2d, st: BNState, *, row_scale=None, residual=None, gate=None, rows_per_sample=1, act=False, out=None):
     rows, C = P2d.shape
     if out is None:
         out = torch.empty_like(P2d)
-    call("mx_bn_apply", ptr(P2d), ptr(st.scale), ptr(st.shift), ptr(row_scale), ptr(residual), ptr(out), rows, C,
+    call("mx_bn_apply", ptr(P2d), ptr(st.scale), ptr(st.shift), ptr(row_scale), ptr(residual), ptr(gate), ptr(out), rows, C,
          rows_per_sample, int(act), stream())
     return out
 

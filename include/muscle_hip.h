@@ -93,6 +93,14 @@ int mx_bn_bwd_apply(const float* G, const float* X, const float* row_scale, cons
 int mx_pool_sum(const float* X, const float* G, const float* scale, const float* shift, int act, long rows, int C,
                 int rows_per_sample, float* out, void* stream);
 
+/* SE + BN1 backward reductions in one pass over (dA, X = d_raw): out5[5][N][C] += per-(sample,channel) sums of
+ * {dA*act, dA*s', s', dA*s'*X, s'*X} with z = scale*X+shift, act = swish(z), s' = swish'(z); out5[0] is dL/dgate
+ * (model.py:84).  mx_bn1_sums then forms the BatchNorm-1 backward sums for g = (dA*gate + add)*s' as one partial
+ * row part[2C] (P = 1 for mx_bn_bwd_finalize) without a second pass over the tensors. */
+int mx_se_bn1_pool(const float* dA, const float* X, const float* scale, const float* shift, long rows, int C, int rows_per_sample,
+                   float* out5, void* stream);
+int mx_bn1_sums(const float* pooled5, const float* gate, const float* add, int N, int C, float* part, void* stream);
+
 /* ---- depthwise k x k convolution, k in {3,5}, stride in {1,2}: model.py:50-52,78; utils.py:122-145 ---- */
 
 /* Y = dwconv(act(X)), act = swish(scale*x+shift) when scale != NULL; stats (optional) = partial (sum Y, sum Y^2)

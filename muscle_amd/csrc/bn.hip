@@ -174,6 +174,72 @@ struct FPool {           // per-sample: sum act(x) ; optionally sum g*act(x)
 };
 
 // ---------------------------------------------------------------------------
+// SE / BN1 backward in ONE pass over (dA, d_raw): per (sample, channel)
+//   out[0] = sum dA * act            (gradient of the SE gate, model.py:84)
+//   out[1] = sum dA * s'(z)          out[2] = sum s'(z)
+//   out[3] = sum dA * s'(z) * x      out[4] = sum s'(z) * x          z = a*x + b, act = swish(z), x = d_raw
+// The BatchNorm-1 backward sums for g = (dA*gate + add) * s'(z) are then sum_n gate*out[1] + add*out[2] (and with x),
+// which needs `add` (the SE backward) but no second pass over the tensors.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void se_bn1_pool_kernel(const float* G, const float* X, const float* a, const float* b, ColGeom g,
+                                                          float* out /*[5][N][C]*/, long plane) {
+  __shared__ float4 sm[5][256];
+  const int tid = threadIdx.x;
+  const int used = g.tcols * g.rpp;
+  const int tc = tid % g.tcols, tr = tid / g.tcols;
+  const int c4 = blockIdx.y * g.tcols + tc;
+  const int sample = blockIdx.z;
+  const long r0 = (long)sample * g.rps + (long)blockIdx.x * g.rows_per_block;
+  const long r1 = min((long)(sample + 1) * g.rps, r0 + g.rows_per_block);
+  float4 acc[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) acc[i] = make_float4(0, 0, 0, 0);
+  if (tid < used && c4 < g.c4) {
+    const int c = 4 * c4;
+    const float4 aa = ld4(a + c), bb = ld4(b + c);
+    for (long r = r0 + tr; r < r1; r += g.rpp) {
+      const float4 x = ld4(X + r * g.C + c), ga = ld4(G + r * g.C + c);
+#define SE1(f)                                                  \
+      {                                                           \
+        float z = aa.f * x.f + bb.f, sg = sigmoidf_(z);           \
+        float act = z * sg, sp = sg * (1.f + z * (1.f - sg));     \
+        acc[0].f += ga.f * act; acc[1].f += ga.f * sp; acc[2].f += sp; \
+        acc[3].f += ga.f * sp * x.f; acc[4].f += sp * x.f;        \
+      }
+      SE1(x) SE1(y) SE1(z) SE1(w)
+#undef SE1
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 5; ++i) sm[i][tid] = acc[i];
+  __syncthreads();
+  if (tid < g.tcols && c4 < g.c4) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+      float4 s0 = sm[i][tid];
+      for (int k = 1; k < g.rpp; ++k) { float4 t0 = sm[i][tid + k * g.tcols]; s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w; }
+      float* o = out + i * plane + (long)sample * g.C + 4 * c4;
+      unsafeAtomicAdd(o + 0, s0.x); unsafeAtomicAdd(o + 1, s0.y); unsafeAtomicAdd(o + 2, s0.z); unsafeAtomicAdd(o + 3, s0.w);
+    }
+  }
+}
+
+// part[1][2][C] = (sum_n gate*S1 + add*S2, sum_n gate*S3 + add*S4): the BN1 backward sums, in fp64 -> fp32 partial row
+__global__ void bn1_sums_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* add, int N, int C, float* part) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long plane = (long)N * C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const long i = (long)n * C + c;
+    s0 += (double)gate[i] * pooled[plane + i] + (double)add[i] * pooled[2 * plane + i];
+    s1 += (double)gate[i] * pooled[3 * plane + i] + (double)add[i] * pooled[4 * plane + i];
+  }
+  part[c] = (float)s0;
+  part[C + c] = (float)s1;
+}
+
+// ---------------------------------------------------------------------------
 // per-channel finalisation kernels (tiny)
 // ---------------------------------------------------------------------------
 // Two-level reduction of the partial rows part[P][2][C]: level 1 (this kernel, grid = channel chunks x row slices)
@@ -386,6 +452,27 @@ int mx_bn_bwd_apply(const float* G, const float* X, const float* row_scale, cons
 
 // out[n,c] += sum_hw f(X[n,hw,c]) with f = [affine a,b] [swish] [* G]; used for the SE squeeze
 // (model.py:82), the global average pool of the head (MuSCLe.py:240) and their backward reductions.
+// out[5][N][C] (zero-filled by the caller) += the five per-(sample, channel) sums described at se_bn1_pool_kernel
+int mx_se_bn1_pool(const float* dA, const float* X, const float* scale, const float* shift, long rows, int C, int rows_per_sample,
+                   float* out5, void* stream) {
+  MX_CHECK_ARG(dA && X && scale && shift && out5 && rows > 0 && C % 4 == 0 && rows_per_sample > 0 && rows % rows_per_sample == 0,
+               "se_bn1_pool: bad args");
+  const int N = (int)(rows / rows_per_sample);
+  ColGeom g = col_geom(rows, C, rows_per_sample, rows_per_sample, N);
+  dim3 grid(cdiv(rows_per_sample, g.rows_per_block), cdiv(g.c4, g.tcols), N);
+  hipLaunchKernelGGL(se_bn1_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, dA, X, scale, shift, g, out5, (long)N * C);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// part[2C] (one partial row for mx_bn_bwd_finalize with P = 1) from the pooled sums, the SE gate and the SE backward `add`
+int mx_bn1_sums(const float* pooled5, const float* gate, const float* add, int N, int C, float* part, void* stream) {
+  MX_CHECK_ARG(pooled5 && gate && add && part && N > 0 && C > 0, "bn1_sums: bad args");
+  hipLaunchKernelGGL(bn1_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, pooled5, gate, add, N, C, part);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
 int mx_pool_sum(const float* X, const float* G, const float* scale, const float* shift, int act, long rows, int C,
                 int rows_per_sample, float* out, void* stream) {
   MX_CHECK_ARG(X && out && rows > 0 && C % 4 == 0 && rows_per_sample > 0 && rows % rows_per_sample == 0,

@@ -187,14 +187,17 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
                          x_shift=t.bn1.shift, x_gate=t.gate, rows_per_sample=hw)
         ga = ops.pw_dgrad(dp, m._project_conv.weight.view(b.cout, b.cexp), b.cexp)          # dL/d(act*gate) [Mo,Cexp]
         del dp
-        # SE: gate gradient = sum_hw ga * act ; excitation backward gives the pooled-path term
-        ggate = ops.pool_sum(d2, hw, G=ga, st=t.bn1, act=True)
-        add = ops.se_bwd(ggate, t.gate, t.s, t.h, m._se_reduce.weight.view(b.se, b.cexp), m._se_expand.weight.view(b.cexp, b.se),
+        # One pass over (ga, d_raw) yields the SE gate gradient sum_hw ga*act AND the per-sample pieces of the BN1 backward
+        # sums; the excitation backward then gives the pooled-path term `add`, and the BN1 sums follow without
+        # touching the big tensors again.
+        pooled5 = ops.se_bn1_pool(ga, d2, t.bn1, hw)
+        add = ops.se_bwd(pooled5[0], t.gate, t.s, t.h, m._se_reduce.weight.view(b.se, b.cexp), m._se_expand.weight.view(b.cexp, b.se),
                          1.0 / hw, sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
                          sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias))
         # BN1 backward with g = (ga*gate + add) * swish'(bn1(d_raw)), in place over ga
-        dd = ops.bn_backward(ga, d2, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training, gate=t.gate,
-                             gate_add=add, act=t.bn1, rows_per_sample=hw, out=ga).view(N, t.Ho, t.Wo, b.cexp)
+        dd = ops.bn_backward_from_sums(ga, d2, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training,
+                                       ops.bn1_sums(pooled5, t.gate, add), gate=t.gate, gate_add=add, rows_per_sample=hw,
+                                       out=ga).view(N, t.Ho, t.Wo, b.cexp)
         # depthwise
         dw_in, dw_st = (t.e_raw, t.bn0) if b.expand else (t.x, t.x_st)
         ops.dwconv_bwd_weight(dw_in, dd, sink.of(m._depthwise_conv.weight), b.kernel, b.stride, b.pad_lo, st=dw_st)

@@ -122,6 +122,33 @@ def bn_backward(G2d, X2d, bn: torch.nn.BatchNorm2d, st: BNState, dgamma, dbeta, 
     return out
 
 
+def bn_backward_from_sums(G2d, X2d, bn, st: BNState, dgamma, dbeta, training: bool, part, *, gate, gate_add, rows_per_sample, out):
+    """As bn_backward for g = (G*gate + gate_add)*swish'(bn(X)), with the reduction already available as one partial row."""
+    rows, C = X2d.shape
+    c = _f32(3, C, device=X2d.device)
+    call("mx_bn_bwd_finalize", ptr(part), 1, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
+         ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]),
+         ptr(torch.empty(2 * C, dtype=torch.float64, device=X2d.device)), stream())
+    call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), None, ptr(gate), ptr(gate_add), ptr(st.scale), ptr(st.shift),
+         ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(out), rows, C, rows_per_sample, stream())
+    return out
+
+
+def se_bn1_pool(dA2d, X2d, st: BNState, rows_per_sample):
+    rows, C = X2d.shape
+    N = rows // rows_per_sample
+    out = torch.zeros(5, N, C, dtype=torch.float32, device=X2d.device)
+    call("mx_se_bn1_pool", ptr(dA2d), ptr(X2d), ptr(st.scale), ptr(st.shift), rows, C, rows_per_sample, ptr(out), stream())
+    return out
+
+
+def bn1_sums(pooled5, gate, add):
+    _, N, C = pooled5.shape
+    part = _f32(1, 2, C, device=gate.device)
+    call("mx_bn1_sums", ptr(pooled5), ptr(gate), ptr(add), N, C, ptr(part), stream())
+    return part
+
+
 def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=False):
     rows, C = X2d.shape
     out = torch.zeros(rows // rows_per_sample, C, dtype=torch.float32, device=X2d.device)

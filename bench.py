@@ -82,6 +82,7 @@ def pointwise_flops_per_image(cfg, size):
 def cpu_baseline(model_name, size, view, ep, seconds_budget=25.0):
     """The oracle (a CPU port of the reference's loop body) on this host's cores; bounded sample."""
     from oracle import mcl_oracle as O
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # the GPU box's CPU share for one GPU
     n = 2
     cfg = arch.net_cfg(model_name, False)
     torch.manual_seed(0)

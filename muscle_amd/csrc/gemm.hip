@@ -115,6 +115,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
+  // Rasterisation: M tiles fastest.  Tried and measured on MI355X (profiles/r01_pmc_fetch_write_per_kernel.json shows
+  // FETCH_SIZE ~3-4x the algorithmic bytes: every N tile re-streams A from beyond L2): an XCD-aware N-fastest order
+  // (the N tiles of an M tile back to back on one XCD) left NT/NN unchanged and made the weight gradient 1.5x slower;
+  // binding reduction slices to XCDs cost 13 %.  The re-reads are served by the 256 MiB Infinity Cache and are not
+  // what limits these kernels.
   const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int z = blockIdx.z;
 
@@ -159,26 +164,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     if (kt + 1 < nk) load(kbeg + (kt + 1) * BK);
     const float* as = As + cur * BK * SA + wm * TM * 32 + l31;
     const float* bs = Bs + cur * BK * SB + wn * TN * 32 + l31;
-    const int kleft = min(BK, kend - (kbeg + kt * BK));
+    // No "k < kend" test inside the MFMA stream: the slab loaders zero-fill rows/columns beyond kend, so the tail of a
+    // partial last K tile multiplies zeros.  (With the test, every k-pair became its own basic block and hipcc put an
+    // s_waitcnt lgkmcnt(0) between each pair's ds_reads and its four MFMAs, exposing the LDS latency 8 times per tile.)
     // the LDS stores of the next tile sit in the middle of the MFMA stream (the matrix pipe keeps draining the
     // already issued MFMAs while they issue) instead of in front of the barrier, where every wave would stall
+    // operands of k-pair kk+2 are read from LDS before the MFMAs of pair kk issue (one pair of register sets, static
+    // indices after unrolling), so the ~100-cycle LDS latency hides under the 4 x 64 MFMA cycles in flight
+    float av[2][TM], bv[2][TN];
+    auto lds_read = [&](int kk, int slot) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) av[slot][i] = as[(kk + h) * SA + i * 32];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bv[slot][j] = bs[(kk + h) * SB + j * 32];
+    };
     auto mfma_range = [&](int k_lo, int k_hi) {
 #pragma unroll
       for (int kk = k_lo; kk < k_hi; kk += 2) {
-        if (kk < kleft) {
-          float av[TM], bv[TN];
+        const int slot = (kk >> 1) & 1;
+        if (kk + 2 < BK) lds_read(kk + 2, slot ^ 1);
+        __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of this pair's MFMAs (hipcc sinks it otherwise)
 #pragma unroll
-          for (int i = 0; i < TM; ++i) av[i] = as[(kk + h) * SA + i * 32];
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int j = 0; j < TN; ++j) bv[j] = bs[(kk + h) * SB + j * 32];
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[slot][i], bv[slot][j], acc[i][j], 0, 0, 0);
       }
     };
+    lds_read(0, 0);
     mfma_range(0, BK / 2);
     if (kt + 1 < nk) {
       sa.store(As + (cur ^ 1) * BK * SA, tid);

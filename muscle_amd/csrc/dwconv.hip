@@ -304,6 +304,227 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Fused stride-1 backward of  [BN0+SiLU] -> depthwise -> BN1 -> SiLU -> SE gate  in ONE pass over the tensors:
+//   * the BatchNorm-1 data gradient dd = c1*g + c2*d + c3, g = (dA*gate + add) * swish'(a1*d + b1), is formed while the
+//     tile is staged (it is never written to HBM),
+//   * weight gradient dW[c,ky,kx] += sum dd * act(X) and data gradient gX = dwconv^T(dd) are both computed from the
+//     two staged tiles (same tile geometry: odd kernel, symmetric pad),
+//   * for expand blocks the epilogue multiplies by swish'(a0*x + b0) and accumulates the BatchNorm-0 backward sums
+//     (sum g, sum g*x) as one partial row per workgroup, so no separate reduction pass over (gX, X) is needed.
+// Replaces bn_bwd_apply (2 reads + 1 write), dw_bwd_data, dw_bwd_weight and the BN0 reduction (2 reads).
+// ---------------------------------------------------------------------------
+struct DwFusedArgs {
+  const float* dA; const float* d;                    // [N,H,W,C] each (stride 1: output size == input size)
+  const float* gate; const float* add;                // [N,C]
+  const float* a1; const float* b1;                   // BN1 scale / shift
+  const float* c1; const float* c2; const float* c3;  // BN1 backward coefficients
+  const float* x; const float* a0; const float* b0;   // dw input (raw) and its BN0 scale / shift (null = plain input)
+  const float* w; const float* res;                   // weights [C,1,K,K]; residual added to gX (plain-input case)
+  float* gx; float* dw; float* part;                  // outputs: gX (or g*swish'), dW (+=), BN0 partial sums [groups][2][C]
+  int N, H, W, C, pad, tiles_x, tiles_y, tiles_per_block;
+};
+
+template <int K, int TH, int TW, int OX>
+__global__ __launch_bounds__(256, (K == 5 ? 2 : 3)) void dw_bwd_fused_kernel(DwFusedArgs a) {
+  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256, CH = (K == 5) ? 4 : 3;
+  static_assert(TH * (TW / OX) * C4B == 256 && PER % CH == 0, "thread mapping");
+  __shared__ float4 tx[TOT];     // act(X) with halo
+  __shared__ float4 td[TOT];     // dd with halo
+  __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
+  __shared__ float red[K * K * CB];
+  __shared__ __attribute__((aligned(16))) float cst[9 * CB];   // a1 b1 c1 c2 c3 a0 b0 | gate add (per tile)
+  const int tid = threadIdx.x, c0 = blockIdx.y * CB;
+  const int c4 = tid % C4B, q = tid / C4B;
+  const int oyl = q / (TW / OX), oxl = (q % (TW / OX)) * OX;
+  const int c = c0 + 4 * c4;
+  const bool cok = c < a.C;
+  const bool has_bn0 = a.a0 != nullptr;
+  // weights wl[tap][CB]
+  for (int i = tid; i < K * K * CB; i += 256) {
+    int cc = i % CB, tap = i / CB;
+    wl[i] = (c0 + cc < a.C) ? a.w[(long)(c0 + cc) * K * K + tap] : 0.f;
+  }
+  // per-channel constants live in LDS (9 float4 per thread would otherwise sit in VGPRs for the whole tile loop)
+  for (int i = tid; i < 7 * CB; i += 256) {
+    int cc = i % CB, j = i / CB;
+    const float* src = j == 0 ? a.a1 : j == 1 ? a.b1 : j == 2 ? a.c1 : j == 3 ? a.c2 : j == 4 ? a.c3 : j == 5 ? a.a0 : a.b0;
+    cst[i] = (src && c0 + cc < a.C) ? src[c0 + cc] : 0.f;
+  }
+  float4 part[K * K];
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) part[t] = make_float4(0, 0, 0, 0);
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  const long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
+  const long t_beg = (long)blockIdx.x * a.tiles_per_block, t_end = min(ntiles, t_beg + a.tiles_per_block);
+  for (long t = t_beg; t < t_end; ++t) {
+    const int n = (int)(t / (a.tiles_x * a.tiles_y));
+    const int rem = (int)(t % (a.tiles_x * a.tiles_y));
+    const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
+    const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+    __syncthreads();
+    if (tid < 2 * CB) {
+      int cc = tid % CB;
+      cst[7 * CB + tid] = (c0 + cc < a.C) ? (tid < CB ? a.gate : a.add)[(long)n * a.C + c0 + cc] : 0.f;
+    }
+    __syncthreads();
+    // stage both tiles, CH float4 triples in flight per thread (more would push the kernel under 2 waves/SIMD)
+#pragma unroll 1
+    for (int k0 = 0; k0 < PER; k0 += CH) {
+      asm volatile("" ::: "memory");   // keep the constant reloads inside the loop
+      float4 vx[CH], vg[CH], vd[CH];
+      float ok[CH];
+      // branch-free: out-of-image / out-of-range elements read a clamped (valid) address and are multiplied by 0
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        int i = min(tid + 256 * (k0 + k), TOT - 1), pix = i / C4B;
+        int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+        ok[k] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cok) ? 1.f : 0.f;
+        iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1);
+        const long off = (((long)n * a.H + iy) * a.W + ix) * a.C + (cok ? c : 0);
+        vx[k] = ld4(a.x + off); vg[k] = ld4(a.dA + off); vd[k] = ld4(a.d + off);
+      }
+      const float4 A1 = ld4(cst + 4 * c4), B1 = ld4(cst + CB + 4 * c4), C1 = ld4(cst + 2 * CB + 4 * c4),
+                   C2 = ld4(cst + 3 * CB + 4 * c4), C3 = ld4(cst + 4 * CB + 4 * c4), A0 = ld4(cst + 5 * CB + 4 * c4),
+                   B0 = ld4(cst + 6 * CB + 4 * c4), G = ld4(cst + 7 * CB + 4 * c4), AD = ld4(cst + 8 * CB + 4 * c4);
+#pragma unroll
+      for (int k = 0; k < CH; ++k) {
+        const int i = min(tid + 256 * (k0 + k), TOT - 1);   // duplicates of the last element rewrite the same value
+        float4 xv = vx[k], dd;
+        if (has_bn0) {
+          xv.x = swishf_(A0.x * xv.x + B0.x); xv.y = swishf_(A0.y * xv.y + B0.y);
+          xv.z = swishf_(A0.z * xv.z + B0.z); xv.w = swishf_(A0.w * xv.w + B0.w);
+        }
+#define DD1(f) dd.f = ok[k] * (C1.f * ((vg[k].f * G.f + AD.f) * swish_gradf_(A1.f * vd[k].f + B1.f)) + C2.f * vd[k].f + C3.f); xv.f *= ok[k];
+        DD1(x) DD1(y) DD1(z) DD1(w)
+#undef DD1
+        tx[i] = xv;
+        td[i] = dd;
+      }
+    }
+    __syncthreads();
+    // weight gradient: dd at the thread's OX output pixels times the shifted activated input
+    float4 g[OX];
+#pragma unroll
+    for (int o = 0; o < OX; ++o) g[o] = td[((oyl + a.pad) * IW + oxl + o + a.pad) * C4B + c4];
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+      asm volatile("" ::: "memory");   // one row of taps at a time: hoisting all K rows of LDS reads costs 4*K*(OX-1+K) VGPRs
+      float4 in[OX - 1 + K];
+#pragma unroll
+      for (int j = 0; j < OX - 1 + K; ++j) in[j] = tx[((oyl + ky) * IW + oxl + j) * C4B + c4];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+#pragma unroll
+        for (int o = 0; o < OX; ++o) {
+          float4 v = in[o + kx];
+          float4& p = part[ky * K + kx];
+          p.x += g[o].x * v.x; p.y += g[o].y * v.y; p.z += g[o].z * v.z; p.w += g[o].w * v.w;
+        }
+      }
+    }
+    // data gradient at the same pixels (as input positions): correlation of dd with the flipped kernel
+    float4 acc[OX];
+#pragma unroll
+    for (int o = 0; o < OX; ++o) acc[o] = make_float4(0, 0, 0, 0);
+#pragma unroll 1
+    for (int ky = 0; ky < K; ++ky) {
+      asm volatile("" ::: "memory");   // keep the K*K weight reads here (hoisted out of the tile loop they pin 4*K*K VGPRs)
+      float4 in[OX - 1 + K];
+#pragma unroll
+      for (int j = 0; j < OX - 1 + K; ++j) in[j] = td[((oyl + K - 1 - ky) * IW + oxl + j) * C4B + c4];
+#pragma unroll
+      for (int kx = 0; kx < K; ++kx) {
+        float4 w = ld4(wl + (ky * K + kx) * CB + 4 * c4);
+#pragma unroll
+        for (int o = 0; o < OX; ++o) {
+          float4 v = in[o + K - 1 - kx];
+          acc[o].x += w.x * v.x; acc[o].y += w.y * v.y; acc[o].z += w.z * v.z; acc[o].w += w.w * v.w;
+        }
+      }
+    }
+    const int oy = oy0 + oyl;
+    if (cok && oy < a.H) {
+      asm volatile("" ::: "memory");
+      const float4 A0 = ld4(cst + 5 * CB + 4 * c4), B0 = ld4(cst + 6 * CB + 4 * c4);
+#pragma unroll
+      for (int o = 0; o < OX; ++o) {
+        int ox = ox0 + oxl + o;
+        if (ox < a.W) {
+          const long off = (((long)n * a.H + oy) * a.W + ox) * a.C + c;
+          float4 v = acc[o];
+          if (a.a0) {
+            float4 xr = ld4(a.x + off);
+            v.x *= swish_gradf_(A0.x * xr.x + B0.x); v.y *= swish_gradf_(A0.y * xr.y + B0.y);
+            v.z *= swish_gradf_(A0.z * xr.z + B0.z); v.w *= swish_gradf_(A0.w * xr.w + B0.w);
+            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
+            s1.x += v.x * xr.x; s1.y += v.y * xr.y; s1.z += v.z * xr.z; s1.w += v.w * xr.w;
+          } else if (a.res) {
+            float4 r = ld4(a.res + off);
+            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+          }
+          st4(a.gx + off, v);
+        }
+      }
+    }
+  }
+  // leave: dW through LDS + fp32 atomics, BN0 sums as this workgroup's partial row
+  __syncthreads();
+  for (int i = tid; i < K * K * CB; i += 256) red[i] = 0.f;
+  __syncthreads();
+#pragma unroll
+  for (int t = 0; t < K * K; ++t) {
+    asm volatile("" ::: "memory");   // serialise the taps: interleaving all K*K shuffle chains doubles the live registers
+    float4 p = part[t];
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64); p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
+    }
+    if ((tid & 63) < C4B) {
+      atomicAdd(&red[t * CB + 4 * c4 + 0], p.x); atomicAdd(&red[t * CB + 4 * c4 + 1], p.y);
+      atomicAdd(&red[t * CB + 4 * c4 + 2], p.z); atomicAdd(&red[t * CB + 4 * c4 + 3], p.w);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < K * K * CB; i += 256) {
+    int cc = i % CB, tap = i / CB;
+    if (c0 + cc < a.C) unsafeAtomicAdd(a.dw + (long)(c0 + cc) * K * K + tap, red[i]);
+  }
+  if (a.part) {
+    __syncthreads();
+    if (tid < 2 * CB) red[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      s0.x += __shfl_xor(s0.x, o, 64); s0.y += __shfl_xor(s0.y, o, 64); s0.z += __shfl_xor(s0.z, o, 64); s0.w += __shfl_xor(s0.w, o, 64);
+      s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+    }
+    if ((tid & 63) < C4B) {
+      atomicAdd(&red[4 * c4 + 0], s0.x); atomicAdd(&red[4 * c4 + 1], s0.y); atomicAdd(&red[4 * c4 + 2], s0.z); atomicAdd(&red[4 * c4 + 3], s0.w);
+      atomicAdd(&red[CB + 4 * c4 + 0], s1.x); atomicAdd(&red[CB + 4 * c4 + 1], s1.y);
+      atomicAdd(&red[CB + 4 * c4 + 2], s1.z); atomicAdd(&red[CB + 4 * c4 + 3], s1.w);
+    }
+    __syncthreads();
+    if (tid < CB && c0 + tid < a.C) {
+      float* prow = a.part + (long)blockIdx.x * 2 * a.C;
+      prow[c0 + tid] = red[tid];
+      prow[a.C + c0 + tid] = red[CB + tid];
+    }
+  }
+}
+
+static void dw_fused_geom(int N, int H, int Wd, int C, int* tiles_x, int* tiles_y, int* tpb, int* groups) {
+  *tiles_x = cdiv(Wd, 16); *tiles_y = cdiv(H, 8);
+  long ntiles = (long)N * (*tiles_x) * (*tiles_y);
+  int chunks = cdiv(C, CB);
+  long g = 4096 / chunks;
+  if (g < 1) g = 1;
+  if (g > ntiles) g = ntiles;
+  *tpb = (int)((ntiles + g - 1) / g);
+  *groups = cdiv(ntiles, *tpb);
+}
+
 // ---------------------------------------------------------------------------
 // host
 // ---------------------------------------------------------------------------
@@ -389,6 +610,38 @@ int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift,
   a.tiles_per_block = (int)((ntiles + groups - 1) / groups);
   dim3 grid(cdiv(ntiles, a.tiles_per_block), chunks, 1);
   DW_DISPATCH(BWW_S1, BWW_S2, K, S, grid, (hipStream_t)stream, a);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// number of BN0 partial-statistics rows mx_dwconv_bwd_fused writes
+int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C) {
+  if (N <= 0 || H <= 0 || Wd <= 0 || C <= 0) return MX_EARG;
+  int tx, ty, tpb, groups;
+  dw_fused_geom(N, H, Wd, C, &tx, &ty, &tpb, &groups);
+  return groups;
+}
+
+// Stride-1 backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> SE gate fused (see dw_bwd_fused_kernel):
+//   gX = dwconv^T(dd) [* swish'(a0*X+b0)] [+ residual];  dW += sum dd*act(X);  part = BN0 backward partial sums (a0 != NULL)
+int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
+                        const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
+                        const float* W, const float* residual, float* gX, float* dW, float* part, int N, int H, int Wd, int C,
+                        int K, int pad_lo, void* stream) {
+  MX_CHECK_ARG(dA && D && gate && add && a1 && b1 && c1 && c2 && c3 && X && W && gX && dW, "dwconv_bwd_fused: null pointer");
+  MX_CHECK_ARG((a0 == nullptr) == (b0 == nullptr), "dwconv_bwd_fused: a0/b0 come together");
+  MX_CHECK_ARG(!a0 || part, "dwconv_bwd_fused: BN0 present -> part required");
+  MX_CHECK_ARG((K == 3 || K == 5) && pad_lo == (K - 1) / 2, "dwconv_bwd_fused: stride 1 with symmetric pad only (K=%d pad=%d)", K, pad_lo);
+  MX_CHECK_ARG(N > 0 && H > 0 && Wd > 0 && C > 0 && C % 4 == 0, "dwconv_bwd_fused: bad extents");
+  DwFusedArgs a{};
+  a.dA = dA; a.d = D; a.gate = gate; a.add = add; a.a1 = a1; a.b1 = b1; a.c1 = c1; a.c2 = c2; a.c3 = c3;
+  a.x = X; a.a0 = a0; a.b0 = b0; a.w = W; a.res = residual; a.gx = gX; a.dw = dW; a.part = a0 ? part : nullptr;
+  a.N = N; a.H = H; a.W = Wd; a.C = C; a.pad = pad_lo;
+  int groups;
+  dw_fused_geom(N, H, Wd, C, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups);
+  dim3 grid(groups, cdiv(C, CB), 1);
+  if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

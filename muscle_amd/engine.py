@@ -159,6 +159,9 @@ class GradSink:
         return g
 
 
+FUSED_DW_BACKWARD = True
+
+
 def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, torch.Tensor], sink: GradSink):
     """tap_grads: {block index: dL/d out [N,Ho,Wo,Cout]} for the tapped features.  Parameter gradients are
     accumulated into `sink`.  The image gets no gradient (the reference never asks for one)."""
@@ -194,38 +197,48 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         add = ops.se_bwd(pooled5[0], t.gate, t.s, t.h, m._se_reduce.weight.view(b.se, b.cexp), m._se_expand.weight.view(b.cexp, b.se),
                          1.0 / hw, sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
                          sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias))
-        # BN1 backward with g = (ga*gate + add) * swish'(bn1(d_raw)), in place over ga
-        dd = ops.bn_backward_from_sums(ga, d2, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training,
-                                       ops.bn1_sums(pooled5, t.gate, add), gate=t.gate, gate_add=add, rows_per_sample=hw,
-                                       out=ga).view(N, t.Ho, t.Wo, b.cexp)
-        # depthwise
         dw_in, dw_st = (t.e_raw, t.bn0) if b.expand else (t.x, t.x_st)
-        ops.dwconv_bwd_weight(dw_in, dd, sink.of(m._depthwise_conv.weight), b.kernel, b.stride, b.pad_lo, st=dw_st)
         skip_res = g_out if b.skip else None            # d out / d x through the identity branch
-        if b.expand:
-            ge = ops.dwconv_bwd_data(dd, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, t.H, t.W)
-            del dd, ga
-            e2 = t.e_raw.view(M, b.cexp)
-            ge2 = ge.view(M, b.cexp)
-            de = ops.bn_backward(ge2, e2, m._bn0, t.bn0, sink.of(m._bn0.weight), sink.of(m._bn0.bias), training, act=t.bn0,
-                                 out=ge2)
-            ops.pw_wgrad(de, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
-            g_in = ops.pw_dgrad(de, m._expand_conv.weight.view(b.cexp, b.cin), b.cin,
-                                residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)
-            g_out = g_in.view(N, t.H, t.W, b.cin)
+        fused = FUSED_DW_BACKWARD and b.stride == 1 and b.pad_lo == (b.kernel - 1) // 2
+        if fused:
+            # stride 1: BN1 data gradient, depthwise weight + data gradients and the BN0 backward sums in one kernel
+            c1 = ops.bn_bwd_coeffs(ops.bn1_sums(pooled5, t.gate, add), Mo, m._bn1, t.bn1, sink.of(m._bn1.weight),
+                                   sink.of(m._bn1.bias), training)
+            gx, part0 = ops.dwconv_bwd_fused(ga.view(N, t.Ho, t.Wo, b.cexp), t.d_raw, t.gate, add, t.bn1, c1, dw_in, dw_st,
+                                             m._depthwise_conv.weight, sink.of(m._depthwise_conv.weight), b.kernel, b.pad_lo,
+                                             residual=None if dw_st is not None else skip_res)
+            del ga
         else:
+            # BN1 backward with g = (ga*gate + add) * swish'(bn1(d_raw)), in place over ga
+            dd = ops.bn_backward_from_sums(ga, d2, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training,
+                                           ops.bn1_sums(pooled5, t.gate, add), gate=t.gate, gate_add=add, rows_per_sample=hw,
+                                           out=ga).view(N, t.Ho, t.Wo, b.cexp)
+            ops.dwconv_bwd_weight(dw_in, dd, sink.of(m._depthwise_conv.weight), b.kernel, b.stride, b.pad_lo, st=dw_st)
             gx = ops.dwconv_bwd_data(dd, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, t.H, t.W,
-                                     residual=skip_res)
-            if t.x_st is not None:
-                # block 0: x is the stem's raw output, still behind BN0 + SiLU -> stem backward
-                s2 = tape.stem_raw.view(M, b.cin)
-                gx2 = gx.view(M, b.cin)
-                ds = ops.bn_backward(gx2, s2, backbone._bn0, tape.stem_bn, sink.of(backbone._bn0.weight),
-                                     sink.of(backbone._bn0.bias), training, act=tape.stem_bn, out=gx2)
-                dw28 = torch.zeros(cfg.stem_out, 28, dtype=torch.float32, device=ds.device)
-                ops.pw_wgrad(ds, tape.cols, dw28)
+                                     residual=None if dw_st is not None else skip_res)
+            del dd, ga
+        if dw_st is not None:
+            # the depthwise input sits behind a BatchNorm + SiLU (BN0 of an expand block, or the stem's BN for block 0)
+            bn_mod = m._bn0 if b.expand else backbone._bn0
+            raw2 = dw_in.view(M, dw_in.shape[3])
+            gx2 = gx.view(M, dw_in.shape[3])
+            if fused:
+                c0 = ops.bn_bwd_coeffs(part0, M, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training)
+                dz = ops.bn_bwd_apply_plain(gx2, raw2, c0, gx2)
+            else:
+                dz = ops.bn_backward(gx2, raw2, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training,
+                                     act=dw_st, out=gx2)
+            if b.expand:
+                ops.pw_wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
+                g_in = ops.pw_dgrad(dz, m._expand_conv.weight.view(b.cexp, b.cin), b.cin,
+                                    residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)
+                g_out = g_in.view(N, t.H, t.W, b.cin)
+            else:
+                # block 0: the input is the stem's raw output -> stem weight gradient
+                dw28 = torch.zeros(cfg.stem_out, 28, dtype=torch.float32, device=dz.device)
+                ops.pw_wgrad(dz, tape.cols, dw28)
                 sink.of(backbone._conv_stem.weight).view(cfg.stem_out, 27).add_(dw28[:, :27])
                 g_out = None
-            else:
-                g_out = gx
+        else:
+            g_out = gx
     return

@@ -134,6 +134,35 @@ def bn_backward_from_sums(G2d, X2d, bn, st: BNState, dgamma, dbeta, training: bo
     return out
 
 
+def bn_bwd_coeffs(part, rows, bn, st: BNState, dgamma, dbeta, training: bool):
+    """dgamma/dbeta (+=) and the [3,C] coefficients (c1,c2,c3) of dX = c1*g + c2*X + c3 from partial rows part[P][2][C]."""
+    P, _, C = part.shape
+    c = _f32(3, C, device=part.device)
+    call("mx_bn_bwd_finalize", ptr(part), P, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
+         ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]),
+         ptr(torch.empty(2 * C, dtype=torch.float64, device=part.device)), stream())
+    return c
+
+
+def bn_bwd_apply_plain(G2d, X2d, c, out):
+    """dX = c1*G + c2*X + c3 (G already carries every upstream factor)."""
+    rows, C = X2d.shape
+    call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), None, None, None, None, None, ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(out),
+         rows, C, 1, stream())
+    return out
+
+
+def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNState], W, dW, K, pad_lo, *, residual=None):
+    """Stride-1 fused backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> gate; returns (gX, BN0 partial sums or None)."""
+    N, H, Wd, C = X.shape
+    gX = _f32(N, H, Wd, C, device=X.device)
+    part = _f32(lib().mx_dwconv_bwd_fused_parts(N, H, Wd, C), 2, C, device=X.device) if st0 is not None else None
+    call("mx_dwconv_bwd_fused", ptr(dA), ptr(D), ptr(gate), ptr(add), ptr(st1.scale), ptr(st1.shift), ptr(c1[0]), ptr(c1[1]),
+         ptr(c1[2]), ptr(X), ptr(st0.scale) if st0 else None, ptr(st0.shift) if st0 else None, ptr(W), ptr(residual), ptr(gX),
+         ptr(dW), ptr(part), N, H, Wd, C, K, pad_lo, stream())
+    return gX, part
+
+
 def se_bn1_pool(dA2d, X2d, st: BNState, rows_per_sample):
     rows, C = X2d.shape
     N = rows // rows_per_sample

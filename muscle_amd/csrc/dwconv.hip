@@ -322,24 +322,29 @@ struct DwFusedArgs {
   const float* c1; const float* c2; const float* c3;  // BN1 backward coefficients
   const float* x; const float* a0; const float* b0;   // dw input (raw) and its BN0 scale / shift (null = plain input)
   const float* w; const float* res;                   // weights [C,1,K,K]; residual added to gX (plain-input case)
-  float* gx; float* dw; float* part;                  // outputs: gX (or g*swish'), dW (+=), BN0 partial sums [groups][2][C]
+  float* gx; float* dwpart; float* part;              // outputs: gX (or g*swish'), dW partial rows [groups][C*K*K], BN0 partial sums [groups][2][C]
   int N, H, W, C, pad, tiles_x, tiles_y, tiles_per_block;
 };
 
 template <int K, int TH, int TW, int OX>
-__global__ __launch_bounds__(256, (K == 5 ? 2 : 3)) void dw_bwd_fused_kernel(DwFusedArgs a) {
-  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256, CH = (K == 5) ? 4 : 3;
-  static_assert(TH * (TW / OX) * C4B == 256 && PER % CH == 0, "thread mapping");
+__global__ __launch_bounds__(256, 2) void dw_bwd_fused_kernel(DwFusedArgs a) {
+  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256, CH = (K == 5) ? 8 : 3;
+  static_assert(PER % CH == 0, "staging chunks");
   __shared__ float4 tx[TOT];     // act(X) with halo
   __shared__ float4 td[TOT];     // dd with halo
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
   __shared__ float red[K * K * CB];
   __shared__ __attribute__((aligned(16))) float cst[9 * CB];   // a1 b1 c1 c2 c3 a0 b0 | gate add (per tile)
   const int tid = threadIdx.x, c0 = blockIdx.y * CB;
-  const int c4 = tid % C4B, q = tid / C4B;
-  const int oyl = q / (TW / OX), oxl = (q % (TW / OX)) * OX;
+  const int c4 = tid % C4B;                        // staging: 4 channels per thread
   const int c = c0 + 4 * c4;
   const bool cok = c < a.C;
+  constexpr int C2B = CB / 2, PX = 8;              // compute: 2 channels x 8 pixels per thread
+  static_assert(TW % PX == 0 && TH * (TW / PX) * C2B == 256, "compute mapping");
+  const int c2 = tid % C2B, pq = tid / C2B;
+  const int pyl = pq / (TW / PX), pxl = (pq % (TW / PX)) * PX;
+  const int cc2 = c0 + 2 * c2;
+  const bool cok2 = cc2 < a.C;
   const bool has_bn0 = a.a0 != nullptr;
   // weights wl[tap][CB]
   for (int i = tid; i < K * K * CB; i += 256) {
@@ -352,10 +357,10 @@ __global__ __launch_bounds__(256, (K == 5 ? 2 : 3)) void dw_bwd_fused_kernel(DwF
     const float* src = j == 0 ? a.a1 : j == 1 ? a.b1 : j == 2 ? a.c1 : j == 3 ? a.c2 : j == 4 ? a.c3 : j == 5 ? a.a0 : a.b0;
     cst[i] = (src && c0 + cc < a.C) ? src[c0 + cc] : 0.f;
   }
-  float4 part[K * K];
+  float2 part[K * K];
 #pragma unroll
-  for (int t = 0; t < K * K; ++t) part[t] = make_float4(0, 0, 0, 0);
-  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  for (int t = 0; t < K * K; ++t) part[t] = make_float2(0, 0);
+  float2 s0 = make_float2(0, 0), s1 = s0;
   const long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
   const long t_beg = (long)blockIdx.x * a.tiles_per_block, t_end = min(ntiles, t_beg + a.tiles_per_block);
   for (long t = t_beg; t < t_end; ++t) {
@@ -374,13 +379,13 @@ __global__ __launch_bounds__(256, (K == 5 ? 2 : 3)) void dw_bwd_fused_kernel(DwF
     for (int k0 = 0; k0 < PER; k0 += CH) {
       asm volatile("" ::: "memory");   // keep the constant reloads inside the loop
       float4 vx[CH], vg[CH], vd[CH];
-      float ok[CH];
+      unsigned okm = 0;
       // branch-free: out-of-image / out-of-range elements read a clamped (valid) address and are multiplied by 0
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         int i = min(tid + 256 * (k0 + k), TOT - 1), pix = i / C4B;
         int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-        ok[k] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cok) ? 1.f : 0.f;
+        okm |= (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cok) ? (1u << k) : 0u;
         iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1);
         const long off = (((long)n * a.H + iy) * a.W + ix) * a.C + (cok ? c : 0);
         vx[k] = ld4(a.x + off); vg[k] = ld4(a.dA + off); vd[k] = ld4(a.d + off);
@@ -392,11 +397,12 @@ __global__ __launch_bounds__(256, (K == 5 ? 2 : 3)) void dw_bwd_fused_kernel(DwF
       for (int k = 0; k < CH; ++k) {
         const int i = min(tid + 256 * (k0 + k), TOT - 1);   // duplicates of the last element rewrite the same value
         float4 xv = vx[k], dd;
+        const float okf = ((okm >> k) & 1u) ? 1.f : 0.f;
         if (has_bn0) {
           xv.x = swishf_(A0.x * xv.x + B0.x); xv.y = swishf_(A0.y * xv.y + B0.y);
           xv.z = swishf_(A0.z * xv.z + B0.z); xv.w = swishf_(A0.w * xv.w + B0.w);
         }
-#define DD1(f) dd.f = ok[k] * (C1.f * ((vg[k].f * G.f + AD.f) * swish_gradf_(A1.f * vd[k].f + B1.f)) + C2.f * vd[k].f + C3.f); xv.f *= ok[k];
+#define DD1(f) dd.f = okf * (C1.f * ((vg[k].f * G.f + AD.f) * swish_gradf_(A1.f * vd[k].f + B1.f)) + C2.f * vd[k].f + C3.f); xv.f *= okf;
         DD1(x) DD1(y) DD1(z) DD1(w)
 #undef DD1
         tx[i] = xv;
@@ -404,106 +410,119 @@ __global__ __launch_bounds__(256, (K == 5 ? 2 : 3)) void dw_bwd_fused_kernel(DwF
       }
     }
     __syncthreads();
-    // weight gradient: dd at the thread's OX output pixels times the shifted activated input
-    float4 g[OX];
+    // Compute phases: a thread owns 2 channels x PX=8 consecutive pixels of one tile row.  (4 channels x 4 pixels needs 100
+    // accumulator VGPRs for K=5 and the allocator then spills; 2 x 8 needs 50 and keeps v_pk_fma_f32 over the channel pair.)
+    const float2* tx2 = reinterpret_cast<const float2*>(tx);
+    const float2* td2 = reinterpret_cast<const float2*>(td);
+    // weight gradient: dd at the thread's output pixels times the shifted activated input.  The pixel loop is a real
+    // loop over halves (QX pixels each): fully unrolled, the scheduler hoists every LDS read of the phase (K rows x
+    // (PX-1+K) float2) to the top and the kernel drops to 1 wave/SIMD or spills.
+    constexpr int QX = PX / 2;
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+      const int px = pxl + h * QX;
+      float2 g[QX];
 #pragma unroll
-    for (int o = 0; o < OX; ++o) g[o] = td[((oyl + a.pad) * IW + oxl + o + a.pad) * C4B + c4];
+      for (int o = 0; o < QX; ++o) g[o] = td2[((pyl + a.pad) * IW + px + o + a.pad) * C2B + c2];
 #pragma unroll
-    for (int ky = 0; ky < K; ++ky) {
-      asm volatile("" ::: "memory");   // one row of taps at a time: hoisting all K rows of LDS reads costs 4*K*(OX-1+K) VGPRs
-      float4 in[OX - 1 + K];
+      for (int ky = 0; ky < K; ++ky) {
+        float2 in[QX - 1 + K];
 #pragma unroll
-      for (int j = 0; j < OX - 1 + K; ++j) in[j] = tx[((oyl + ky) * IW + oxl + j) * C4B + c4];
+        for (int j = 0; j < QX - 1 + K; ++j) in[j] = tx2[((pyl + ky) * IW + px + j) * C2B + c2];
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
+        for (int o = 0; o < QX; ++o) {
 #pragma unroll
-        for (int o = 0; o < OX; ++o) {
-          float4 v = in[o + kx];
-          float4& p = part[ky * K + kx];
-          p.x += g[o].x * v.x; p.y += g[o].y * v.y; p.z += g[o].z * v.z; p.w += g[o].w * v.w;
+          for (int kx = 0; kx < K; ++kx) {
+            float2 v = in[o + kx];
+            float2& p = part[ky * K + kx];
+            p.x += g[o].x * v.x; p.y += g[o].y * v.y;
+          }
         }
       }
     }
     // data gradient at the same pixels (as input positions): correlation of dd with the flipped kernel
-    float4 acc[OX];
-#pragma unroll
-    for (int o = 0; o < OX; ++o) acc[o] = make_float4(0, 0, 0, 0);
+    float2 acc[PX];
 #pragma unroll 1
-    for (int ky = 0; ky < K; ++ky) {
-      asm volatile("" ::: "memory");   // keep the K*K weight reads here (hoisted out of the tile loop they pin 4*K*K VGPRs)
-      float4 in[OX - 1 + K];
+    for (int h = 0; h < 2; ++h) {
+      const int px = pxl + h * QX;
+      float2 ah[QX];
 #pragma unroll
-      for (int j = 0; j < OX - 1 + K; ++j) in[j] = td[((oyl + K - 1 - ky) * IW + oxl + j) * C4B + c4];
+      for (int o = 0; o < QX; ++o) ah[o] = make_float2(0, 0);
 #pragma unroll
-      for (int kx = 0; kx < K; ++kx) {
-        float4 w = ld4(wl + (ky * K + kx) * CB + 4 * c4);
+      for (int ky = 0; ky < K; ++ky) {
+        float2 in[QX - 1 + K];
 #pragma unroll
-        for (int o = 0; o < OX; ++o) {
-          float4 v = in[o + K - 1 - kx];
-          acc[o].x += w.x * v.x; acc[o].y += w.y * v.y; acc[o].z += w.z * v.z; acc[o].w += w.w * v.w;
+        for (int j = 0; j < QX - 1 + K; ++j) in[j] = td2[((pyl + K - 1 - ky) * IW + px + j) * C2B + c2];
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+          float2 w = *reinterpret_cast<const float2*>(wl + (ky * K + kx) * CB + 2 * c2);
+#pragma unroll
+          for (int o = 0; o < QX; ++o) {
+            float2 v = in[o + K - 1 - kx];
+            ah[o].x += w.x * v.x; ah[o].y += w.y * v.y;
+          }
         }
       }
-    }
-    const int oy = oy0 + oyl;
-    if (cok && oy < a.H) {
-      asm volatile("" ::: "memory");
-      const float4 A0 = ld4(cst + 5 * CB + 4 * c4), B0 = ld4(cst + 6 * CB + 4 * c4);
+      if (h == 0) {
 #pragma unroll
-      for (int o = 0; o < OX; ++o) {
-        int ox = ox0 + oxl + o;
+        for (int o = 0; o < QX; ++o) acc[o] = ah[o];
+      } else {
+#pragma unroll
+        for (int o = 0; o < QX; ++o) acc[QX + o] = ah[o];
+      }
+    }
+    const int oy = oy0 + pyl;
+    if (cok2 && oy < a.H) {
+      const float2 A0 = *reinterpret_cast<const float2*>(cst + 5 * CB + 2 * c2), B0 = *reinterpret_cast<const float2*>(cst + 6 * CB + 2 * c2);
+#pragma unroll
+      for (int o = 0; o < PX; ++o) {
+        int ox = ox0 + pxl + o;
         if (ox < a.W) {
-          const long off = (((long)n * a.H + oy) * a.W + ox) * a.C + c;
-          float4 v = acc[o];
-          if (a.a0) {
-            float4 xr = ld4(a.x + off);
+          const long off = (((long)n * a.H + oy) * a.W + ox) * a.C + cc2;
+          float2 v = acc[o];
+          if (has_bn0) {
+            float2 xr = *reinterpret_cast<const float2*>(a.x + off);
             v.x *= swish_gradf_(A0.x * xr.x + B0.x); v.y *= swish_gradf_(A0.y * xr.y + B0.y);
-            v.z *= swish_gradf_(A0.z * xr.z + B0.z); v.w *= swish_gradf_(A0.w * xr.w + B0.w);
-            s0.x += v.x; s0.y += v.y; s0.z += v.z; s0.w += v.w;
-            s1.x += v.x * xr.x; s1.y += v.y * xr.y; s1.z += v.z * xr.z; s1.w += v.w * xr.w;
+            s0.x += v.x; s0.y += v.y;
+            s1.x += v.x * xr.x; s1.y += v.y * xr.y;
           } else if (a.res) {
-            float4 r = ld4(a.res + off);
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            float2 r = *reinterpret_cast<const float2*>(a.res + off);
+            v.x += r.x; v.y += r.y;
           }
-          st4(a.gx + off, v);
+          *reinterpret_cast<float2*>(a.gx + off) = v;
         }
       }
     }
   }
-  // leave: dW through LDS + fp32 atomics, BN0 sums as this workgroup's partial row
+  // leave: dW and the BN0 sums as this workgroup's partial rows (global atomics here would have every workgroup of a
+  // channel chunk contend on the same K*K*32 addresses: measured ~20 us per workgroup)
   __syncthreads();
   for (int i = tid; i < K * K * CB; i += 256) red[i] = 0.f;
   __syncthreads();
 #pragma unroll
   for (int t = 0; t < K * K; ++t) {
-    asm volatile("" ::: "memory");   // serialise the taps: interleaving all K*K shuffle chains doubles the live registers
-    float4 p = part[t];
-#pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-      p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64); p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
-    }
-    if ((tid & 63) < C4B) {
-      atomicAdd(&red[t * CB + 4 * c4 + 0], p.x); atomicAdd(&red[t * CB + 4 * c4 + 1], p.y);
-      atomicAdd(&red[t * CB + 4 * c4 + 2], p.z); atomicAdd(&red[t * CB + 4 * c4 + 3], p.w);
-    }
+    float2 p = part[t];
+    p.x += __shfl_xor(p.x, 16, 64); p.y += __shfl_xor(p.y, 16, 64);
+    p.x += __shfl_xor(p.x, 32, 64); p.y += __shfl_xor(p.y, 32, 64);
+    if ((tid & 63) < C2B) { atomicAdd(&red[t * CB + 2 * c2 + 0], p.x); atomicAdd(&red[t * CB + 2 * c2 + 1], p.y); }
   }
   __syncthreads();
   for (int i = tid; i < K * K * CB; i += 256) {
     int cc = i % CB, tap = i / CB;
-    if (c0 + cc < a.C) unsafeAtomicAdd(a.dw + (long)(c0 + cc) * K * K + tap, red[i]);
+    if (c0 + cc < a.C) a.dwpart[(long)blockIdx.x * a.C * K * K + (long)(c0 + cc) * K * K + tap] = red[i];
   }
   if (a.part) {
     __syncthreads();
     if (tid < 2 * CB) red[tid] = 0.f;
     __syncthreads();
 #pragma unroll
-    for (int o = 8; o < 64; o <<= 1) {
-      s0.x += __shfl_xor(s0.x, o, 64); s0.y += __shfl_xor(s0.y, o, 64); s0.z += __shfl_xor(s0.z, o, 64); s0.w += __shfl_xor(s0.w, o, 64);
-      s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64); s1.z += __shfl_xor(s1.z, o, 64); s1.w += __shfl_xor(s1.w, o, 64);
+    for (int o = 16; o < 64; o <<= 1) {
+      s0.x += __shfl_xor(s0.x, o, 64); s0.y += __shfl_xor(s0.y, o, 64);
+      s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
     }
-    if ((tid & 63) < C4B) {
-      atomicAdd(&red[4 * c4 + 0], s0.x); atomicAdd(&red[4 * c4 + 1], s0.y); atomicAdd(&red[4 * c4 + 2], s0.z); atomicAdd(&red[4 * c4 + 3], s0.w);
-      atomicAdd(&red[CB + 4 * c4 + 0], s1.x); atomicAdd(&red[CB + 4 * c4 + 1], s1.y);
-      atomicAdd(&red[CB + 4 * c4 + 2], s1.z); atomicAdd(&red[CB + 4 * c4 + 3], s1.w);
+    if ((tid & 63) < C2B) {
+      atomicAdd(&red[2 * c2 + 0], s0.x); atomicAdd(&red[2 * c2 + 1], s0.y);
+      atomicAdd(&red[CB + 2 * c2 + 0], s1.x); atomicAdd(&red[CB + 2 * c2 + 1], s1.y);
     }
     __syncthreads();
     if (tid < CB && c0 + tid < a.C) {
@@ -512,6 +531,21 @@ __global__ __launch_bounds__(256, (K == 5 ? 2 : 3)) void dw_bwd_fused_kernel(DwF
       prow[a.C + c0 + tid] = red[CB + tid];
     }
   }
+}
+
+// dW[i] += sum_g part[g][i]; blockIdx.y takes a slice of the rows so a small C*K*K still fills the chip
+__global__ __launch_bounds__(256) void dw_parts_reduce_kernel(const float* __restrict__ part, int P, int rows_per_slice, int n,
+                                                              float* __restrict__ dW) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  int g = blockIdx.y * rows_per_slice;
+  const int g_end = min(P, g + rows_per_slice);
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  for (; g + 4 <= g_end; g += 4) {
+    s0 += part[(long)g * n + i]; s1 += part[(long)(g + 1) * n + i]; s2 += part[(long)(g + 2) * n + i]; s3 += part[(long)(g + 3) * n + i];
+  }
+  for (; g < g_end; ++g) s0 += part[(long)g * n + i];
+  unsafeAtomicAdd(dW + i, (s0 + s1) + (s2 + s3));
 }
 
 static void dw_fused_geom(int N, int H, int Wd, int C, int* tiles_x, int* tiles_y, int* tpb, int* groups) {
@@ -614,7 +648,7 @@ int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift,
   return MX_OK;
 }
 
-// number of BN0 partial-statistics rows mx_dwconv_bwd_fused writes
+// number of partial rows mx_dwconv_bwd_fused writes (BN0 sums [rows][2][C] and dW scratch [rows][C*K*K])
 int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C) {
   if (N <= 0 || H <= 0 || Wd <= 0 || C <= 0) return MX_EARG;
   int tx, ty, tpb, groups;
@@ -626,22 +660,31 @@ int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C) {
 //   gX = dwconv^T(dd) [* swish'(a0*X+b0)] [+ residual];  dW += sum dd*act(X);  part = BN0 backward partial sums (a0 != NULL)
 int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
                         const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
-                        const float* W, const float* residual, float* gX, float* dW, float* part, int N, int H, int Wd, int C,
-                        int K, int pad_lo, void* stream) {
-  MX_CHECK_ARG(dA && D && gate && add && a1 && b1 && c1 && c2 && c3 && X && W && gX && dW, "dwconv_bwd_fused: null pointer");
+                        const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,
+                        int Wd, int C, int K, int pad_lo, void* stream) {
+  MX_CHECK_ARG(dA && D && gate && add && a1 && b1 && c1 && c2 && c3 && X && W && gX && dW && dw_scratch, "dwconv_bwd_fused: null pointer");
   MX_CHECK_ARG((a0 == nullptr) == (b0 == nullptr), "dwconv_bwd_fused: a0/b0 come together");
   MX_CHECK_ARG(!a0 || part, "dwconv_bwd_fused: BN0 present -> part required");
   MX_CHECK_ARG((K == 3 || K == 5) && pad_lo == (K - 1) / 2, "dwconv_bwd_fused: stride 1 with symmetric pad only (K=%d pad=%d)", K, pad_lo);
   MX_CHECK_ARG(N > 0 && H > 0 && Wd > 0 && C > 0 && C % 4 == 0, "dwconv_bwd_fused: bad extents");
   DwFusedArgs a{};
   a.dA = dA; a.d = D; a.gate = gate; a.add = add; a.a1 = a1; a.b1 = b1; a.c1 = c1; a.c2 = c2; a.c3 = c3;
-  a.x = X; a.a0 = a0; a.b0 = b0; a.w = W; a.res = residual; a.gx = gX; a.dw = dW; a.part = a0 ? part : nullptr;
+  a.x = X; a.a0 = a0; a.b0 = b0; a.w = W; a.res = residual; a.gx = gX; a.dwpart = dw_scratch; a.part = a0 ? part : nullptr;
   a.N = N; a.H = H; a.W = Wd; a.C = C; a.pad = pad_lo;
   int groups;
   dw_fused_geom(N, H, Wd, C, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups);
   dim3 grid(groups, cdiv(C, CB), 1);
   if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  MX_LAUNCH_CHECK();
+  {
+    const int n = C * K * K, nb = cdiv(n, 256);
+    int slices = nb >= 512 ? 1 : cdiv(512, nb);
+    if (slices > cdiv(groups, 8)) slices = cdiv(groups, 8);
+    const int rps = cdiv(groups, slices);
+    hipLaunchKernelGGL(dw_parts_reduce_kernel, dim3(nb, cdiv(groups, rps)), dim3(256), 0, (hipStream_t)stream, dw_scratch, groups, rps,
+                       n, dW);
+  }
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -56,6 +56,25 @@ for C, H in shapes:
             dW = torch.zeros_like(W)
             t3 = timeit(lambda: ops.dwconv_bwd_weight(X4, dY, dW, K, 1, pad, st=st))
             print(f"dw k{K} C={C:5d} H={H:4d}: fwd {t*1e6:7.1f}us {2*gb/t:7.1f} GB/s | bwd_data {t2*1e6:7.1f}us {2*gb/t2:7.1f} GB/s | bwd_w {t3*1e6:7.1f}us {2*gb/t3:7.1f} GB/s")
+    if "dwfused" in which:
+        from muscle_amd._lib import call, ptr, stream, lib
+        for K in ((3,) if (C, H) in [(32, 224), (192, 224), (288, 112), (3840, 28)] else (5,) if (C, H) != (960, 28) else (3, 5)):
+            W = torch.randn(C, 1, K, K, device=dev); dW = torch.zeros_like(W)
+            X4 = X.view(N, H, H, C); dA = G.view(N, H, H, C); D = torch.randn(N, H, H, C, device=dev)
+            st0 = bnstate(C); pad = (K - 1) // 2
+            c1 = torch.randn(3, C, device=dev) * 0.1
+            tf = timeit(lambda: ops.dwconv_bwd_fused(dA, D, gate, add, st, c1, X4, st0, W, dW, K, pad))
+            dd = torch.empty_like(G)
+            def unfused():
+                call("mx_bn_bwd_apply", ptr(G), ptr(D), None, ptr(gate), ptr(add), ptr(st.scale), ptr(st.shift), ptr(c1[0]), ptr(c1[1]), ptr(c1[2]), ptr(dd), rows, C, H * H, stream())
+                d4 = dd.view(N, H, H, C)
+                ops.dwconv_bwd_weight(X4, d4, dW, K, 1, pad, st=st0)
+                ge = ops.dwconv_bwd_data(d4, W, K, 1, pad, H, H)
+                P = lib().mx_colreduce_parts(rows, C)
+                part = torch.empty(P, 2, C, device=dev)
+                call("mx_bn_bwd_reduce", ptr(ge), ptr(X), None, None, None, ptr(st0.scale), ptr(st0.shift), rows, C, 1, ptr(part), stream())
+            tu = timeit(unfused)
+            print(f"dwfused k{K} C={C:5d} H={H:4d}: fused {tf*1e6:7.1f}us ({4*gb/tf:6.0f} GB/s of 4 passes) | unfused {tu*1e6:7.1f}us", flush=True)
     del G, X
 if "gemm" in which:
     # (M, K, N) of expand / project fwd for representative blocks

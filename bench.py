@@ -154,6 +154,18 @@ def main():
     def step():
         return muscle_amd.mcl_step(model, opt, batch, a.epoch, valid_channel=vc, grad_hook=hook)
 
+    if a.epoch >= 8:
+        # phase 2 runs in eval mode (train_mcl.py:196): give the random-init model BatchNorm running statistics of its
+        # own activations (one train-mode pass at momentum 1.0), as SURVEY 8(c) prescribes for eval-mode work
+        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+        saved = [m.momentum for m in bns]
+        for m in bns:
+            m.momentum = 1.0
+        model.train()
+        with torch.no_grad():
+            model(batch["view1"], cam="pix")
+        for m, mo in zip(bns, saved):
+            m.momentum = mo
     for _ in range(a.warmup):
         step()
 
@@ -184,7 +196,15 @@ def main():
 
     imgs = a.batch * world * a.steps
     gemm_ms, gemm_launches = timer.total_ms()
-    flops = pointwise_flops_per_image(cfg, a.size) * a.batch * a.steps
+    full = a.epoch >= 12
+    flops_img = pointwise_flops_per_image(cfg, a.size)
+    if full:
+        # phase 2 (train_mcl.py:196-229): two view forwards (one of them under no_grad) + one view backward
+        mv = arch.forward_macs(cfg, view)
+        sv = cfg.stem_out_size(view)
+        stem_v = 28 * cfg.stem_out * sv * sv
+        flops_img += 2 * 2 * mv["pointwise"] + 4 * mv["pointwise"] + 2 * 2 * stem_v + 2 * stem_v
+    flops = flops_img * a.batch * a.steps
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -196,9 +216,11 @@ def main():
         "value": imgs / dt, "unit": "images/sec", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"train_mcl.py loop body, step-A (epoch-{a.epoch} gates: focal+softmargin+pairwise+ER"
-                               f"{'+IMC' if a.epoch >= 4 else ''}, one backward, one Adam step), MuSCLe({a.model}, "
-                               f"last_pooling=False, 21 classes), random-init weights",
+        "config": {"workload": (f"train_mcl.py loop body, step-full (epoch-{a.epoch} gates: phase 1 focal+softmargin+pairwise+ER+IMC, "
+                                f"backward, Adam; phase 2 PixPro+EMD on two {view}x{view} views, backward, Adam), " if full else
+                                f"train_mcl.py loop body, step-A (epoch-{a.epoch} gates: focal+softmargin+pairwise+ER"
+                                f"{'+IMC' if a.epoch >= 4 else ''}, one backward, one Adam step), ") +
+                               f"MuSCLe({a.model}, last_pooling=False, 21 classes), random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
                    "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused"},
         "losses": {k: (float(v) if torch.is_tensor(v) else v) for k, v in out.items()},
@@ -208,7 +230,7 @@ def main():
                      "launches_per_step": gemm_launches // max(a.steps, 1),
                      "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                      "time_share_of_step": gemm_ms * 1e-3 / dt,
-                     "algorithmic_gflop_per_image": pointwise_flops_per_image(cfg, a.size) / 1e9},
+                     "algorithmic_gflop_per_image": flops_img / 1e9},
     }
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.size, view, a.epoch)

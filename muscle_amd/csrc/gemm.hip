@@ -233,26 +233,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
     }
   }
   if (LAYOUT != L_TN && g.stats) {
-    __syncthreads();
-    float* red = smem;   // [2][BN]
-    for (int i = tid; i < 2 * BN; i += 256) red[i] = 0.f;
-    __syncthreads();
+    // column sums of the tile: each wave leaves its 32*TM-row partial in LDS (plain stores; the main loop's last barrier
+    // already retired every read of the operand tiles this aliases), one barrier, then the WM partials are added and
+    // written as this M tile's partial row (summed in fp64 later).  No LDS atomics, one barrier.
+    float* red = smem;   // [WM][2][BN]
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       float s = csum[j] + __shfl_xor(csum[j], 32, 64);
       float q = csq[j] + __shfl_xor(csq[j], 32, 64);
       if (h == 0) {
-        atomicAdd(&red[wn * TN * 32 + j * 32 + l31], s);
-        atomicAdd(&red[BN + wn * TN * 32 + j * 32 + l31], q);
+        red[(wm * 2 + 0) * BN + wn * TN * 32 + j * 32 + l31] = s;
+        red[(wm * 2 + 1) * BN + wn * TN * 32 + j * 32 + l31] = q;
       }
     }
     __syncthreads();
-    float* prow = g.stats + (long)blockIdx.x * 2 * g.N;      // one partial row per M tile, summed in fp64 later
-    for (int i = tid; i < BN; i += 256) {
-      if (n0 + i < g.N) {
-        prow[n0 + i] = red[i];
-        prow[g.N + n0 + i] = red[BN + i];
-      }
+    float* prow = g.stats + (long)blockIdx.x * 2 * g.N;
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, col = i - which * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BN + col];
+      if (n0 + col < g.N) prow[which * g.N + n0 + col] = v;
     }
   }
 }

@@ -102,8 +102,12 @@ struct SlabN {
   }
 };
 
+// The 128x128 tile is held to 128 registers (4 workgroups per CU instead of 3; no spills): the N = 384 / 640 layers have
+// 588 / 980 tiles, which 768 slots run as 0.77 / 1.28 rounds but 1024 slots run as one.
+constexpr int gemm_min_waves(int acc_regs, int bk) { return (acc_regs == 64 && bk == 16) ? 4 : 1; }
+
 template <int LAYOUT, int WM, int WN, int TM, int TN, int BK>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_kernel(GemmArgs g) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int PADA = (LAYOUT == L_TN) ? 4 : 1;
   constexpr int PADB = (LAYOUT == L_NT) ? 1 : 4;

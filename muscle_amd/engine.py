@@ -13,6 +13,8 @@ exactly what backward needs, so nothing else is saved.
 """
 from __future__ import annotations
 
+import os
+
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional
 
@@ -160,6 +162,49 @@ class GradSink:
 
 
 FUSED_DW_BACKWARD = True
+# Optional (MUSCLE_WGRAD_STREAM=1): weight-gradient GEMMs on a second HIP stream.  Nothing in the backward chain consumes
+# them (only the optimizer does), they are MFMA-bound and the chain between two of them (BN backward, SE, depthwise) is
+# HBM-bound.  Measured on MI355X, B7/448/bs32: 162.0 -> 156.3 ms/step (+3.6 %), whether the weight gradient starts with
+# or after its data-gradient twin - both kernels fill every CU's wave slots, so the second one only trickles in.  Off by
+# default: under overlap the per-launch GEMM durations bench.py reports as roofline.achieved stop meaning anything.
+WGRAD_SIDE_STREAM = os.environ.get("MUSCLE_WGRAD_STREAM", "0") == "1"
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+class _WgradLane:
+    def __init__(self, device):
+        self.s = None
+        self.pending = []
+        if WGRAD_SIDE_STREAM:
+            key = device.index if device.index is not None else torch.cuda.current_device()
+            if key not in _side_streams:
+                _side_streams[key] = torch.cuda.Stream(device=device)
+            self.s = _side_streams[key]
+
+    def wgrad(self, G, X, dW, **kw):
+        """Queue dW += G^T X'.  It is launched by the next flush(), i.e. right after the data-gradient GEMM of the same
+        conv has been enqueued on the main stream: two MFMA-bound GEMMs side by side gain nothing, a weight-gradient GEMM
+        next to the HBM-bound kernels that follow the data gradient does."""
+        if self.s is None:
+            return ops.pw_wgrad(G, X, dW, **kw)
+        self.pending.append((G, X, dW, kw))
+
+    def flush(self):
+        if self.s is None or not self.pending:
+            return
+        self.s.wait_stream(torch.cuda.current_stream())     # operands ready, the data-gradient GEMM done
+        with torch.cuda.stream(self.s):
+            for G, X, dW, kw in self.pending:
+                ops.pw_wgrad(G, X, dW, **kw)
+        for G, X, _, _ in self.pending:                      # the caller drops these before the side stream has read them
+            G.record_stream(self.s)
+            X.record_stream(self.s)
+        self.pending = []
+
+    def join(self):
+        self.flush()
+        if self.s is not None:
+            torch.cuda.current_stream().wait_stream(self.s)
 
 
 def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, torch.Tensor], sink: GradSink):
@@ -167,6 +212,7 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
     accumulated into `sink`.  The image gets no gradient (the reference never asks for one)."""
     N, training = tape.N, tape.training
     g_out: Optional[torch.Tensor] = None
+    lane = _WgradLane(tape.blocks[0].out.device)
     for t in reversed(tape.blocks):
         b, m = t.cfg, _blk(backbone, t.cfg.index)
         tg = tap_grads.get(b.index)
@@ -183,12 +229,13 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         # project conv: weight gradient against the recomputed activated+gated input, then data gradient
         d2 = t.d_raw.view(Mo, b.cexp)
         if t.a is not None:
-            ops.pw_wgrad(dp, t.a, sink.of(m._project_conv.weight).view(b.cout, b.cexp))
+            lane.wgrad(dp, t.a, sink.of(m._project_conv.weight).view(b.cout, b.cexp))
             t.a = None
         else:
-            ops.pw_wgrad(dp, d2, sink.of(m._project_conv.weight).view(b.cout, b.cexp), x_mode=ops.BNACT, x_scale=t.bn1.scale,
-                         x_shift=t.bn1.shift, x_gate=t.gate, rows_per_sample=hw)
+            lane.wgrad(dp, d2, sink.of(m._project_conv.weight).view(b.cout, b.cexp), x_mode=ops.BNACT, x_scale=t.bn1.scale,
+                       x_shift=t.bn1.shift, x_gate=t.gate, rows_per_sample=hw)
         ga = ops.pw_dgrad(dp, m._project_conv.weight.view(b.cout, b.cexp), b.cexp)          # dL/d(act*gate) [Mo,Cexp]
+        lane.flush()
         del dp
         # One pass over (ga, d_raw) yields the SE gate gradient sum_hw ga*act AND the per-sample pieces of the BN1 backward
         # sums; the excitation backward then gives the pooled-path term `add`, and the BN1 sums follow without
@@ -229,9 +276,10 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
                 dz = ops.bn_backward(gx2, raw2, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training,
                                      act=dw_st, out=gx2)
             if b.expand:
-                ops.pw_wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
+                lane.wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
                 g_in = ops.pw_dgrad(dz, m._expand_conv.weight.view(b.cexp, b.cin), b.cin,
                                     residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)
+                lane.flush()
                 g_out = g_in.view(N, t.H, t.W, b.cin)
             else:
                 # block 0: the input is the stem's raw output -> stem weight gradient
@@ -241,4 +289,5 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
                 g_out = None
         else:
             g_out = gx
+    lane.join()
     return

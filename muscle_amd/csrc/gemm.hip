@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
             v += bias;
             if (g.residual) v += g.residual[idx];
             if (g.relu) v = fmaxf(v, 0.f);
-            C[idx] = v;
+            __builtin_nontemporal_store(v, C + idx);
             csum[j] += v;
             csq[j] += v * v;
           }

@@ -151,6 +151,15 @@ int mx_resize_nhwc(const float* src, float* dst, int N, int Hs, int Ws, int C, i
 /* dst[n,k,Y,X] (NCHW) = bilinear_align_corners(src[n,:,:,k]); src NHWC with leading dimension lds (MuSCLe.py:256-257) */
 int mx_upsample_to_nchw(const float* src, float* dst, int N, int Hs, int Ws, int lds, int K, int Hd, int Wd, void* stream);
 
+/* ---- infer_mcl.py post-processing, one forward pass of the multi-scale / flip list:
+ * acc[k-1,Y,X] += resize_halfpixel( upsample_align_corners(src[:,:,k], Hs x Ws), H x W )[Y, flip ? W-1-X : X]  for k = 1..K-1
+ * (infer_mcl.py:124-148: model upsample, cv2.resize to the original size, np.flip of the odd passes, sum over passes).
+ * src: ONE sample, NHWC [h,w,lds], channel 0 = background. */
+int mx_infer_accum(const float* src, float* acc, int h, int w, int lds, int K, int Hs, int Ws, int H, int W, int flip, void* stream);
+/* in place per channel over [channels][HW] (infer_mcl.py:153-158 / :161-166): v = max(v,0); v[v < min+1e-6] = 0;
+ * v = (v - min - 1e-6) / (max - min + 1e-6) */
+int mx_infer_norm(float* acc, int channels, long HW, void* stream);
+
 /* adjoint of mx_upsample_to_nchw: gsrc (=|+=) W^T gdst */
 int mx_upsample_to_nchw_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int lds, int K, int Hd, int Wd,
                             int accumulate, void* stream);

@@ -52,7 +52,9 @@ class _ArenaSink(engine.GradSink):
 class _Forward(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, anchor, model, mode, drop_u):
-        need_grad = ctx.needs_input_grad[1]      # False under torch.no_grad(): nothing is kept then
+        # grad mode is always off inside Function.forward and needs_input_grad ignores torch.no_grad(), so the module's
+        # forward() records whether a backward can follow before it calls apply()
+        need_grad = model._save_for_backward
         outs, tape, head = model._run_forward(x, mode, drop_u)
         if need_grad:
             ctx.model, ctx.tape, ctx.head, ctx.mode = model, tape, head, mode
@@ -123,6 +125,7 @@ class MuSCLe(nn.Module):
         if not x.is_cuda:
             raise MuscleHipError("MuSCLe.forward runs on the HIP kernels only: move the model and input to a ROCm GPU")
         x = x.contiguous().float()
+        self._save_for_backward = torch.is_grad_enabled() and cam != "vis"
         if cam == "vis":                                   # MuSCLe.py:290-298: no_grad seg forward, returns (seg_map, p7)
             with torch.no_grad():
                 seg_map, p7 = _Forward.apply(x, self._anchor, self, "vis", drop_u)
@@ -148,7 +151,7 @@ class MuSCLe(nn.Module):
     def _run_forward_dec(self, x, mode, drop_u):
         cfg, K = self.cfg, self.classes
         N, _, H, W = x.shape
-        tape = engine.backbone_forward(self.backbone, cfg, x, self.training, drop_u)
+        tape = engine.backbone_forward(self.backbone, cfg, x, self.training, drop_u, save=getattr(self, "_save_for_backward", True))
         t = cfg.taps
         feats = [tape.blocks[i].out for i in t[2:7]]
         tp = dec.Tape(None, self.training)
@@ -221,7 +224,7 @@ class MuSCLe(nn.Module):
         cfg, K = self.cfg, self.classes
         N, _, H, W = x.shape
         dev = x.device
-        tape = engine.backbone_forward(self.backbone, cfg, x, self.training, drop_u)
+        tape = engine.backbone_forward(self.backbone, cfg, x, self.training, drop_u, save=getattr(self, "_save_for_backward", True))
         t = cfg.taps
         p1, p3, p5, p7 = (tape.blocks[i].out for i in (t[0], t[2], t[4], t[6]))
         _, h, w, C7 = p7.shape

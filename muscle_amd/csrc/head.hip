@@ -195,6 +195,78 @@ __global__ __launch_bounds__(256) void bcast_add_kernel(float* X, const float* v
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// infer_mcl.py:124-148 for one forward pass of the multi-scale / flip list, fused: the model's own
+// F.interpolate(align_corners=True) from the 1/16 map to the pass's input size (Hs x Ws), the script's cv2.resize
+// (bilinear, half-pixel centres, edge clamp) from there to the original image size (H x W), the un-flip of the odd
+// passes and the running sum over passes, for the K-1 foreground channels.  src: one sample, NHWC [h,w,lds], channel 0
+// is the background.  acc[k-1,Y,X] += value.  Neither the [21,Hs,Ws] nor the [H,W,21] intermediate exists.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float bil_lr(const float* b, int h, int w, int lds, int Hs, int Ws, int yy, int xx) {
+  int y0, y1, x0, x1;
+  float wy, wx;
+  bil_coord(yy, h, Hs, y0, y1, wy);
+  bil_coord(xx, w, Ws, x0, x1, wx);
+  float a00 = b[((long)y0 * w + x0) * lds], a01 = b[((long)y0 * w + x1) * lds];
+  float a10 = b[((long)y1 * w + x0) * lds], a11 = b[((long)y1 * w + x1) * lds];
+  return (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
+}
+
+// half-pixel source coordinate (cv2.resize INTER_LINEAR / torch align_corners=False): src = (dst+0.5)*in/out - 0.5, >= 0
+__device__ __forceinline__ void hp_coord(int d, int in, int out, int& i0, int& i1, float& w1) {
+  float s = ((float)d + 0.5f) * ((float)in / (float)out) - 0.5f;
+  if (s < 0.f) s = 0.f;
+  i0 = (int)s;
+  if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 + ((i0 < in - 1) ? 1 : 0);
+  w1 = s - i0;
+}
+
+__global__ __launch_bounds__(256) void infer_accum_kernel(const float* src, float* acc, int h, int w, int lds, int K, int Hs,
+                                                          int Ws, int H, int W, int flip) {
+  const long total = (long)(K - 1) * H * W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    int X = (int)(i % W);
+    long q = i / W;
+    int Y = (int)(q % H), k = (int)(q / H) + 1;
+    int Xr = flip ? (W - 1 - X) : X;            // np.flip(axis=1) after the resize
+    int y0, y1, x0, x1;
+    float wy, wx;
+    hp_coord(Y, Hs, H, y0, y1, wy);
+    hp_coord(Xr, Ws, W, x0, x1, wx);
+    const float* b = src + k;
+    float a00 = bil_lr(b, h, w, lds, Hs, Ws, y0, x0), a01 = bil_lr(b, h, w, lds, Hs, Ws, y0, x1);
+    float a10 = bil_lr(b, h, w, lds, Hs, Ws, y1, x0), a11 = bil_lr(b, h, w, lds, Hs, Ws, y1, x1);
+    acc[i] += (1.f - wy) * ((1.f - wx) * a00 + wx * a01) + wy * ((1.f - wx) * a10 + wx * a11);
+  }
+}
+
+// infer_mcl.py:153-158 per channel (one workgroup each): clamp at 0, min / max over the image, zero what is below
+// min + 1e-6, then (v - min - 1e-6) / (max - min + 1e-6).  In place.
+__global__ __launch_bounds__(256) void infer_norm_kernel(float* acc, long HW) {
+  __shared__ float smx[4], smn[4];
+  float* a = acc + (long)blockIdx.x * HW;
+  float mx = -3.4e38f, mn = 3.4e38f;
+  for (long i = threadIdx.x; i < HW; i += 256) {
+    float v = fmaxf(a[i], 0.f);
+    mx = fmaxf(mx, v);
+    mn = fminf(mn, v);
+  }
+  mx = wave_max(mx);
+  mn = wave_min(mn);
+  if ((threadIdx.x & 63) == 0) { smx[threadIdx.x >> 6] = mx; smn[threadIdx.x >> 6] = mn; }
+  __syncthreads();
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+  mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+  const float lo = mn + 1e-6f, den = mx - mn + 1e-6f;
+  for (long i = threadIdx.x; i < HW; i += 256) {
+    float v = fmaxf(a[i], 0.f);
+    if (v < lo) v = 0.f;
+    a[i] = (v - mn - 1e-6f) / den;
+  }
+}
+
 static int gs(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
 extern "C" {
@@ -271,6 +343,21 @@ int mx_bcast_add(float* X, const float* v, float alpha, long rows, int C, int ro
   MX_CHECK_ARG(X && v && rows > 0 && C % 4 == 0 && rows_per_sample > 0, "bcast_add: bad args");
   hipLaunchKernelGGL(bcast_add_kernel, dim3(gs(rows * (C / 4))), dim3(256), 0, (hipStream_t)stream, X, v, alpha, rows, C,
                      rows_per_sample);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_infer_accum(const float* src, float* acc, int h, int w, int lds, int K, int Hs, int Ws, int H, int W, int flip, void* stream) {
+  MX_CHECK_ARG(src && acc && h > 0 && w > 0 && K > 1 && K <= lds && Hs > 0 && Ws > 0 && H > 0 && W > 0, "infer_accum: bad args");
+  hipLaunchKernelGGL(infer_accum_kernel, dim3(gs((long)(K - 1) * H * W)), dim3(256), 0, (hipStream_t)stream, src, acc, h, w, lds, K,
+                     Hs, Ws, H, W, flip);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_infer_norm(float* acc, int channels, long HW, void* stream) {
+  MX_CHECK_ARG(acc && channels > 0 && HW > 0, "infer_norm: bad args");
+  hipLaunchKernelGGL(infer_norm_kernel, dim3(channels), dim3(256), 0, (hipStream_t)stream, acc, HW);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

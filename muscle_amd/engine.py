@@ -75,8 +75,11 @@ def stem_weight28(backbone):
 
 
 def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
-                     drop_u: Optional[Dict[int, torch.Tensor]] = None) -> Tape:
-    """img: NCHW fp32 CUDA.  Returns the tape; block outputs are tape.blocks[i].out (NHWC)."""
+                     drop_u: Optional[Dict[int, torch.Tensor]] = None, save: bool = True) -> Tape:
+    """img: NCHW fp32 CUDA.  Returns the tape; block outputs are tape.blocks[i].out (NHWC).
+    save=False (no backward will follow, e.g. under torch.no_grad()): every tensor that only backward would read is
+    released as soon as its consumer has been enqueued, and only the tapped block outputs stay alive, so inference at
+    batch 64 / 768x768 does not carry the training footprint."""
     N, _, H, W = img.shape
     dev = img.device
     tape = Tape(training=training, N=N)
@@ -144,6 +147,12 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
         t.out = ops.bn_apply(t.p_raw, t.bn2, row_scale=t.row_scale, residual=res, rows_per_sample=ho * wo).view(N, ho, wo, b.cout)
         tape.blocks.append(t)
         x, x_st, h, w = t.out, None, ho, wo
+        if not save:
+            t.x = t.e_raw = t.d_raw = t.p_raw = t.a = None
+            if b.index == 0:
+                tape.cols = tape.stem_raw = None
+            if len(tape.blocks) >= 2 and tape.blocks[-2].cfg.index not in cfg.taps:
+                tape.blocks[-2].out = None
     return tape
 
 

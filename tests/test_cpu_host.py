@@ -154,3 +154,31 @@ def test_dp_hook_two_ranks_gloo(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_infer_oracle_semantics_and_file_format(tmp_path):
+    """infer_mcl.py:107-182 restated in the oracle: dict keys = positive labels, float32 [H,W] maps, the min-max rule
+    with its 'below min + 1e-6 -> 0' quirk, un-flipping of odd passes, and the .npy dict layout evaluation.py reads."""
+    from oracle import mcl_oracle as O
+    from muscle_amd import synth, infer
+    from muscle_amd.arch import net_cfg
+    rng = np.random.default_rng(0)
+    stack = [rng.standard_normal((20, 6, 5)).astype(np.float32) for _ in range(4)]
+    n = O.infer_norm([s.copy() for s in stack])
+    s = np.sum(stack, axis=0)
+    s[s < 0] = 0
+    assert n.dtype == np.float32 and np.isclose(n.max(), 1.0, atol=1e-5)
+    for c in range(20):                                   # channel minimum is 0 here -> zeroed pixels sit at -1e-6/den
+        assert np.isclose(n[c].min(), (0 - s[c].min() - 1e-6) / (s[c].max() - s[c].min() + 1e-6), rtol=1e-4)
+    cfg = net_cfg("efficientnet-b0", False)
+    net = O.OracleNet("efficientnet-b0", synth.synth_state_dict(cfg, 3))
+    img = torch.from_numpy(synth.normal(3, "img", (1, 3, 40, 56)).astype(np.float32))
+    label = torch.zeros(1, 20)
+    label[0, [1, 19]] = 1
+    cam, sgc, score = O.infer_cam(net, [img, torch.flip(img, dims=[3])], label, 33, 47)
+    assert sorted(cam) == sorted(sgc) == [1, 19] and cam[1].shape == (33, 47) and cam[1].dtype == np.float32
+    assert score.shape == (20,) and float(score.min()) > 0 and float(score.max()) < 1
+    p = str(tmp_path / "a.npy")
+    infer.save_cam_dict(p, sgc)
+    back = infer.load_cam_dict(p)
+    assert sorted(back) == [1, 19] and np.array_equal(back[19], sgc[19])

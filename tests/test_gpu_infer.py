@@ -1,0 +1,91 @@
+"""GPU parity of the CAM-generation path (infer_mcl.py:107-182) against the CPU oracle on the same
+seeded inputs: multi-scale + flip forward passes of a non-square image, the fused upsample / resize / un-flip / sum
+kernel, the per-channel normalisation and the .npy dict layout.  The oracle stands in for cv2.resize with
+F.interpolate(align_corners=False) (same sampling rule; cv2 is not installed: parity unpinned at that one call)."""
+import numpy as np
+import pytest
+import torch
+
+from muscle_amd import synth
+from muscle_amd.arch import net_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.asarray(a))  # noqa: E731
+
+
+def _build(name, seed):
+    import muscle_amd
+    cfg = net_cfg(name, False)
+    sd = synth.synth_state_dict(cfg, seed)
+    m = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)
+    m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    return cfg, sd, m.to(DEV)
+
+
+def _img_list(seed, H, W, scales):
+    """VOC12ClsDatasetMSF order: for each scale the resized image, then its horizontal flip."""
+    base = T(synth.normal(seed, "img", (1, 3, H, W)).astype(np.float32))
+    out = []
+    for s in scales:
+        hs, ws = int(round(H * s)), int(round(W * s))
+        im = torch.nn.functional.interpolate(base, size=(hs, ws), mode="bilinear", align_corners=False)
+        out += [im, torch.flip(im, dims=[3])]
+    return out
+
+
+@pytest.mark.parametrize("name,H,W,scales", [("efficientnet-b0", 75, 100, (0.5, 1.0, 1.5, 2.0)),
+                                              ("efficientnet-b3", 64, 48, (1.0, 1.5))])
+def test_infer_cam_matches_oracle(name, H, W, scales, tmp_path):
+    from oracle import mcl_oracle as O
+    from muscle_amd import infer
+    seed = 31
+    cfg, sd, model = _build(name, seed)
+    imgs = _img_list(seed, H, W, scales)
+    label = torch.zeros(1, 20)
+    label[0, [2, 7, 14]] = 1.0
+    net = O.OracleNet(name, sd)
+    ocam, osgc, oscore = O.infer_cam(net, imgs, label, H, W)
+    gcam, gsgc, gscore = infer.infer_cam(model, [im.to(DEV) for im in imgs], label, H, W)
+    assert sorted(gcam) == sorted(ocam) == [2, 7, 14] and sorted(gsgc) == sorted(osgc)
+    for d_got, d_ref in ((gcam, ocam), (gsgc, osgc)):
+        for k in d_ref:
+            a, b = d_got[k], d_ref[k]
+            assert a.dtype == np.float32 and a.shape == (H, W)
+            # normalised maps live in [~0, 1]; the stated CAM tolerance is 1e-3 of the maximum.  The script's
+            # "norm[norm < min + 1e-6] = 0" makes the map discontinuous at the channel minimum: a pixel within fp32
+            # round-off of it lands on either side, i.e. at (0 - min - 1e-6)/den (the most negative value) or at ~+0.
+            # Such pixels may differ between any two fp32 implementations; everything else must agree.
+            bad = np.abs(a - b) > 1e-3
+            if bad.any():
+                lo = float(b.min())
+                flip = bad & (np.maximum(a, b) <= 2e-3) & (np.minimum(a, b) >= lo - 1e-3)
+                assert np.array_equal(bad, flip), (k, float(np.abs(a - b).max()))
+                assert bad.mean() <= 5e-3, (k, float(bad.mean()))
+    assert float((gscore.cpu() - oscore).abs().max()) <= 1e-5
+    # file format round trip (np.save of the dict; evaluation.py reads it with allow_pickle + .item())
+    p = str(tmp_path / "x.npy")
+    infer.save_cam_dict(p, gsgc)
+    back = np.load(p, allow_pickle=True).item()
+    assert sorted(back) == sorted(gsgc) and all(np.array_equal(back[k], gsgc[k]) for k in back)
+
+
+def test_infer_kernels_edge_cases():
+    """flip, a single-pixel low-res map, an all-negative channel (normalises to the reference's -1e-6/1e-6 quirk)."""
+    from muscle_amd._lib import call, ptr, stream
+    K, H, W = 21, 9, 7
+    src = torch.full((1, 1, 1, 24), -3.0, device=DEV)
+    src[..., 5] = 2.0
+    acc = torch.zeros(K - 1, H, W, device=DEV)
+    call("mx_infer_accum", ptr(src), ptr(acc), 1, 1, 24, K, 16, 16, H, W, 1, stream())
+    assert torch.allclose(acc[4], torch.full((H, W), 2.0, device=DEV)) and torch.allclose(acc[0], torch.full((H, W), -3.0, device=DEV))
+    call("mx_infer_norm", ptr(acc), K - 1, H * W, stream())
+    # constant positive channel: every pixel is < min + 1e-6 (fp32: 2.000001), is zeroed, and normalises to
+    # (0 - 2 - 1e-6) / 1e-6; the expected value is computed with the reference's own numpy statements
+    ref = np.full((H, W), 2.0, np.float32)
+    mn, mx = ref.min(), ref.max()
+    ref[ref < mn + 1e-6] = 0
+    ref = (ref - mn - 1e-6) / (mx - mn + 1e-6)
+    assert np.allclose(acc[4].cpu().numpy(), ref, rtol=1e-5)
+    # negative channel -> clamped to 0 -> (0 - 0 - 1e-6)/1e-6 = -1
+    assert np.allclose(acc[0].cpu().numpy(), -1.0, rtol=1e-5)

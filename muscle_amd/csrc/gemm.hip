@@ -161,11 +161,19 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
     load(kbeg);
     sa.store(As, tid);
     sb.store(Bs, tid);
+    if (nk > 1) load(kbeg + BK);
   }
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
-    if (kt + 1 < nk) load(kbeg + (kt + 1) * BK);
+    // The register slab holds K tile kt+1, requested a whole iteration ago.  It goes to the other LDS buffer right after
+    // the barrier (every wave has finished reading that buffer) and the request for tile kt+2 is issued at once, so
+    // each global load has a full iteration of MFMA work to land (stores in mid-iteration left it half of one).
+    if (kt + 1 < nk) {
+      sa.store(As + (cur ^ 1) * BK * SA, tid);
+      sb.store(Bs + (cur ^ 1) * BK * SB, tid);
+      if (kt + 2 < nk) load(kbeg + (kt + 2) * BK);
+    }
     const float* as = As + cur * BK * SA + wm * TM * 32 + l31;
     const float* bs = Bs + cur * BK * SB + wn * TN * 32 + l31;
     // No "k < kend" test inside the MFMA stream: the slab loaders zero-fill rows/columns beyond kend, so the tail of a
@@ -196,12 +204,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
       }
     };
     lds_read(0, 0);
-    mfma_range(0, BK / 2);
-    if (kt + 1 < nk) {
-      sa.store(As + (cur ^ 1) * BK * SA, tid);
-      sb.store(Bs + (cur ^ 1) * BK * SB, tid);
-    }
-    mfma_range(BK / 2, BK);
+    mfma_range(0, BK);
     __syncthreads();
   }
 

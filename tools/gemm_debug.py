@@ -12,7 +12,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         for _ in range(n): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3
-    for (M, K, N) in [(1605632, 32, 192), (1605632, 32, 32), (401408, 192, 48), (401408, 48, 288), (401408, 288, 48), (100352, 80, 480)]:
+    for (M, K, N) in [(25088, 640, 3840), (25088, 3840, 640), (25088, 384, 2304), (25088, 2304, 384), (25088, 224, 1344), (25088, 1344, 224), (100352, 80, 480), (401408, 48, 288), (1605632, 32, 192)]:
         A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.05
         fl = 2.0 * M * K * N
         t = timeit(lambda: ops.pw_fwd(A, W, N, want_stats=True))
@@ -20,7 +20,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         t2 = timeit(lambda: ops.pw_dgrad(G, W, K))
         dW = torch.zeros(N, K, device=dev)
         t3 = timeit(lambda: ops.pw_wgrad(G, A, dW))
-        print(f"  M={M} K={K} N={N}: fwd {t*1e6:7.1f} us dgrad {t2*1e6:7.1f} us wgrad {t3*1e6:7.1f} us | min-mem {(M*K+M*N)*4/5e12*1e6:6.1f} us", flush=True)
+        print(f"  M={M} K={K} N={N}: fwd {t*1e6:7.1f} us {fl/t/1e12:6.1f} TF | dgrad {t2*1e6:7.1f} us {fl/t2/1e12:6.1f} TF | wgrad {t3*1e6:7.1f} us {fl/t3/1e12:6.1f} TF", flush=True)
 else:
     for dbg in (0, 16, 8):
         print(f"MX_GEMM_DEBUG={dbg}", flush=True)

@@ -297,20 +297,42 @@ static const TileCfg kCfgs[] = {
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
-static int pick_cfg(int M, int N, int K) {
-  (void)M; (void)K;
+// Tile choice.  For the weight gradient (TN: the reduction is split until the grid fills the chip anyway) the measured
+// rule stands: 128x128 when N is a multiple of 128, 128x96 when a multiple of 96, else 128x32.  For the forward and
+// data-gradient GEMMs one more effect matters on 256 CUs: with few tiles per CU the slowest CU sets the time.
+// N = 384 at M = 25088 is 588 tiles of 128x128 = 2.3 per CU (some CUs run 3: 77 % balance) but 1176 tiles of 128x64 =
+// 4.6 per CU (92 %): measured 487 -> 407 us.  score = tile efficiency x (1 - N padding) x per-CU balance.
+static int pick_cfg(int layout, int M, int N, int K) {
+  (void)K;
   if (const char* e = getenv("MX_GEMM_CFG")) {           // tuning override (tools/gemm_sweep.py)
     int forced = atoi(e);
     if (forced >= 0 && forced < kNumCfgs) return forced;
   }
-  if (N >= 384 && N % 128 == 0) return 0;
-  if (N % 96 == 0) return 1;
-  return 2;
+  if (layout == L_TN) {
+    if (N >= 384 && N % 128 == 0) return 0;
+    if (N % 96 == 0) return 1;
+    return 2;
+  }
+  static const struct { int cfg; double eff; } cand[] = {{0, 1.00}, {1, 0.97}, {4, 0.95}, {2, 0.85}};   // big-shape TFLOP/s ratios
+  int best = 2;
+  double best_score = -1.0;
+  for (const auto& c : cand) {
+    const TileCfg t = kCfgs[c.cfg];
+    const long nt = cdiv(N, t.bn), tiles = (long)cdiv(M, t.bm) * nt;
+    const double pad = (double)N / (double)(nt * t.bn);
+    const double per_cu = (double)tiles / 256.0;
+    const double balance = per_cu / (double)(long)(per_cu + 0.999999);
+    if (c.cfg == 4 && N % 64 != 0) continue;               // 128x64 is only measured where it needs no padding
+    double score = c.eff * pad * balance;
+    if (per_cu < 2.0) score *= 0.85;                         // a lone workgroup per CU cannot hide its own latencies
+    if (score > best_score + 1e-9) { best_score = score; best = c.cfg; }
+  }
+  return best;
 }
 
 template <int LAYOUT>
 static void dispatch(const GemmArgs& g, int zdim, hipStream_t st) {
-  switch (pick_cfg(g.M, g.N, g.K)) {
+  switch (pick_cfg(LAYOUT, g.M, g.N, g.K)) {
     case 0: launch<LAYOUT, 2, 2, 2, 2>(g, zdim, st); break;
     case 1: launch<LAYOUT, 4, 1, 1, 3>(g, zdim, st); break;
     case 2: launch<LAYOUT, 4, 1, 1, 1>(g, zdim, st); break;
@@ -354,7 +376,7 @@ static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
     MX_CHECK_ARG(g.M % 4 == 0 && g.N % 4 == 0, "gemm TN: M=%d and N=%d must be multiples of 4", g.M, g.N);
     MX_CHECK_ARG(batch == 1, "gemm TN: not batched");
     // split the pixel reduction so the grid fills the chip (>= ~1024 blocks), >= 512 rows per split
-    const TileCfg tc = kCfgs[pick_cfg(g.M, g.N, g.K)];
+    const TileCfg tc = kCfgs[pick_cfg(L_TN, g.M, g.N, g.K)];
     long tiles = (long)cdiv(g.M, tc.bm) * cdiv(g.N, tc.bn);
     int splits = (int)((2048 + tiles - 1) / tiles);
     int maxs = cdiv(g.K, 512);
@@ -376,7 +398,7 @@ extern "C" {
 // number of partial-statistics rows mx_pw_fwd writes for an [M, N] output
 int mx_pw_fwd_parts(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return MX_EARG;
-  return cdiv(M, kCfgs[pick_cfg(M, N, K)].bm);
+  return cdiv(M, kCfgs[pick_cfg(L_NT, M, N, K)].bm);
 }
 
 int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_shift, const float* a_gate,

@@ -56,6 +56,7 @@ class _Forward(torch.autograd.Function):
         # forward() records whether a backward can follow before it calls apply()
         need_grad = model._save_for_backward
         outs, tape, head = model._run_forward(x, mode, drop_u)
+        ops.flush_batch_counters()               # BatchNorms of the decoder head
         if need_grad:
             ctx.model, ctx.tape, ctx.head, ctx.mode = model, tape, head, mode
         ctx.set_materialize_grads(False)      # unused outputs arrive as None instead of full-size zeros

@@ -281,13 +281,18 @@ static void launch_parts_reduce(const float* part, int P, int C, double* acc, hi
   hipLaunchKernelGGL(bn_parts_reduce_kernel, dim3(cdiv(C, 32), slices), dim3(256), 0, st, part, P, C, rps, acc);
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int C, double count, const float* gamma,
-                                   const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
-                                   float* scale, float* shift, float* mean_out, float* rstd_out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double st0 = 0.0, st1 = 0.0;
-  if (training) { st0 = acc[c]; st1 = acc[C + c]; }
+struct BnFwdFin {
+  double count; const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps; int training;
+  float* scale; float* shift; float* mean_out; float* rstd_out;
+};
+struct BnBwdFin {
+  double count; const float* gamma; const float* mean; const float* rstd; int training;
+  float* dgamma; float* dbeta; float* c1; float* c2; float* c3;
+};
+
+__device__ __forceinline__ void bn_fwd_finalize_one(int c, double st0, double st1, double count, const float* gamma,
+                                                    const float* beta, float* rmean, float* rvar, float momentum, float eps,
+                                                    int training, float* scale, float* shift, float* mean_out, float* rstd_out) {
   float mean, rstd;
   if (training) {
     double m = st0 / count;
@@ -310,12 +315,19 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int
   rstd_out[c] = rstd;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc, int C, double count, const float* gamma,
-                                       const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
-                                       float* c1, float* c2, float* c3) {
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int C, double count, const float* gamma,
+                                   const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
+                                   float* scale, float* shift, float* mean_out, float* rstd_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  const double sg = acc[c], sgx = acc[C + c];
+  double st0 = 0.0, st1 = 0.0;
+  if (training) { st0 = acc[c]; st1 = acc[C + c]; }
+  bn_fwd_finalize_one(c, st0, st1, count, gamma, beta, rmean, rvar, momentum, eps, training, scale, shift, mean_out, rstd_out);
+}
+
+__device__ __forceinline__ void bn_bwd_finalize_one(int c, double sg, double sgx, double count, const float* gamma,
+                                                    const float* mean, const float* rstd, int training, float* dgamma,
+                                                    float* dbeta, float* c1, float* c2, float* c3) {
   double m = mean[c], r = rstd[c], gm = gamma[c];
   double dg = r * (sgx - m * sg);
   dgamma[c] += (float)dg;
@@ -330,6 +342,44 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc,
     c2[c] = 0.f;
     c3[c] = 0.f;
   }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc, int C, double count, const float* gamma,
+                                       const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
+                                       float* c1, float* c2, float* c3) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  bn_bwd_finalize_one(c, acc[c], acc[C + c], count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3);
+}
+
+// Up to FUSED_FINALIZE_MAX_ROWS partial rows: reduction and finalisation in ONE launch (one workgroup = 32 channels x 8 row
+// lanes walks all rows).  The memset + reduce + finalise triple costs three ~5 us launches per BatchNorm per direction:
+// 324 BatchNorm finalisations per B7 step.
+constexpr int FUSED_FINALIZE_MAX_ROWS = 1024;
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* part, int P, int C, BnFwdFin f, BnBwdFin b) {
+  __shared__ double sh[2][8][32];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    int p = rl;
+    for (; p + 24 < P; p += 32) {
+      float a0 = part[(long)p * 2 * C + c], b0 = part[(long)p * 2 * C + C + c];
+      float a1 = part[(long)(p + 8) * 2 * C + c], b1 = part[(long)(p + 8) * 2 * C + C + c];
+      float a2 = part[(long)(p + 16) * 2 * C + c], b2 = part[(long)(p + 16) * 2 * C + C + c];
+      float a3 = part[(long)(p + 24) * 2 * C + c], b3 = part[(long)(p + 24) * 2 * C + C + c];
+      s0 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s1 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; p < P; p += 8) { s0 += (double)part[(long)p * 2 * C + c]; s1 += (double)part[(long)p * 2 * C + C + c]; }
+  }
+  sh[0][rl][cl] = s0; sh[1][rl][cl] = s1;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  for (int i = 1; i < 8; ++i) { s0 += sh[0][i][cl]; s1 += sh[1][i][cl]; }
+  if (BWD) bn_bwd_finalize_one(c, s0, s1, b.count, b.gamma, b.mean, b.rstd, b.training, b.dgamma, b.dbeta, b.c1, b.c2, b.c3);
+  else bn_fwd_finalize_one(c, s0, s1, f.count, f.gamma, f.beta, f.rmean, f.rvar, f.momentum, f.eps, 1, f.scale, f.shift, f.mean_out, f.rstd_out);
 }
 
 // ---------------------------------------------------------------------------
@@ -397,6 +447,12 @@ int mx_bn_finalize(const float* part, int P, int C, double count, const float* g
   MX_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale && shift && mean && rstd,
                "bn_finalize: null argument");
   MX_CHECK_ARG(!training || (part && P > 0 && count > 0 && acc), "bn_finalize: training needs partial statistics, count and acc[2C]");
+  if (training && P <= FUSED_FINALIZE_MAX_ROWS) {
+    BnFwdFin f{count, gamma, beta, running_mean, running_var, momentum, eps, 1, scale, shift, mean, rstd};
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part, P, C, f, BnBwdFin{});
+    MX_LAUNCH_CHECK();
+    return MX_OK;
+  }
   if (training) launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, C, count, gamma,
                      beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd);
@@ -431,6 +487,12 @@ int mx_bn_bwd_finalize(const float* part, int P, int C, double count, const floa
                        int training, float* dgamma, float* dbeta, float* c1, float* c2, float* c3, double* acc, void* stream) {
   MX_CHECK_ARG(part && P > 0 && gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3 && acc && C > 0 && count > 0,
                "bn_bwd_finalize: bad args");
+  if (P <= FUSED_FINALIZE_MAX_ROWS) {
+    BnBwdFin b{count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3};
+    hipLaunchKernelGGL(bn_reduce_finalize_kernel<true>, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part, P, C, BnFwdFin{}, b);
+    MX_LAUNCH_CHECK();
+    return MX_OK;
+  }
   launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, C, count, gamma,
                      mean, rstd, training, dgamma, dbeta, c1, c2, c3);

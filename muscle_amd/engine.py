@@ -60,6 +60,7 @@ class Tape:
     blocks: List[BlockTape] = field(default_factory=list)
 
 
+_keep_cache: Dict[tuple, torch.Tensor] = {}
 MATERIALISE_ABOVE = 128      # project convs with Cout above this use a materialised activated input
 
 
@@ -94,6 +95,18 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
     tape.stem_raw = raw.view(N, H0, W0, C0)
     tape.stem_bn = ops.bn_finalize(stats, N * H0 * W0, backbone._bn0, training)
 
+    drop_scales: Dict[int, torch.Tensor] = {}
+    if training and drop_u is None:
+        # drop_connect (utils.py:50-60): every block's Bernoulli(keep)/keep row scale in one go - per block it was a rand,
+        # an add, a floor and a div kernel, ~190 five-microsecond launches per B7 step
+        idx = [b.index for b in cfg.blocks if b.skip and b.drop_rate]
+        if idx:
+            key = (id(cfg), str(dev))
+            if key not in _keep_cache:
+                _keep_cache[key] = torch.tensor([1.0 - cfg.blocks[i].drop_rate for i in idx], dtype=torch.float32).to(dev).view(-1, 1)
+            keep = _keep_cache[key]
+            rs = torch.floor(keep + torch.rand(len(idx), N, device=dev)) / keep
+            drop_scales = {i: rs[j] for j, i in enumerate(idx)}
     x, x_st, h, w = tape.stem_raw, tape.stem_bn, H0, W0
     for b in cfg.blocks:
         m = _blk(backbone, b.index)
@@ -136,9 +149,11 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
             t.p_raw, st2 = t.p_raw
         t.bn2 = ops.bn_finalize(st2, Mo, m._bn2, training)
         if b.skip and training and b.drop_rate:
-            keep = 1.0 - b.drop_rate
-            u = drop_u[b.index].to(dev, torch.float32) if drop_u is not None else torch.rand(N, device=dev)
-            t.row_scale = torch.floor(keep + u) / keep
+            if drop_u is not None:                      # recorded draws (parity tests)
+                keep = 1.0 - b.drop_rate
+                t.row_scale = torch.floor(keep + drop_u[b.index].to(dev, torch.float32)) / keep
+            else:
+                t.row_scale = drop_scales[b.index]
         res = None
         if b.skip:
             # the skip input is the activated block input; for the (never skipping) block 0 it would be raw
@@ -153,6 +168,7 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
                 tape.cols = tape.stem_raw = None
             if len(tape.blocks) >= 2 and tape.blocks[-2].cfg.index not in cfg.taps:
                 tape.blocks[-2].out = None
+    ops.flush_batch_counters()
     return tape
 
 

@@ -26,7 +26,19 @@ static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that o
                         int groups = 1 /*independent row ranges (samples) sharing the grid*/) {
   ColGeom g;
   g.rows = (int)rows; g.C = C; g.c4 = C / 4; g.rps = rps;
-  g.tcols = g.c4 < 256 ? g.c4 : 256;
+  // float4 columns per workgroup: the width that wastes the fewest of the 256 threads (both on the padded last column
+  // chunk and on 256 % tcols).  With a fixed 256, C = 1344 (336 float4) ran its second chunk at 31 % and C = 2304 its
+  // third at 25 % - the two most common widths of the network.
+  {
+    const int cand[] = {g.c4 <= 256 ? g.c4 : 256, 256, 192, 128, 96, 64, 48, 32};
+    double best = -1.0;
+    g.tcols = cand[0];
+    for (int tc : cand) {
+      if (tc > g.c4) continue;
+      const double util = (double)g.c4 / (double)(cdiv(g.c4, tc) * tc) * (double)(256 / tc * tc) / 256.0;
+      if (util > best + 1e-9) { best = util; g.tcols = tc; }
+    }
+  }
   g.rpp = 256 / g.tcols;
   int colchunks = cdiv(g.c4, g.tcols);
   long target_blocks = 2048 / ((long)colchunks * groups);
@@ -197,18 +209,25 @@ __global__ __launch_bounds__(256) void se_bn1_pool_kernel(const float* G, const 
   if (tid < used && c4 < g.c4) {
     const int c = 4 * c4;
     const float4 aa = ld4(a + c), bb = ld4(b + c);
-    for (long r = r0 + tr; r < r1; r += g.rpp) {
-      const float4 x = ld4(X + r * g.C + c), ga = ld4(G + r * g.C + c);
-#define SE1(f)                                                  \
+#define SE1(f, x, ga)                                          \
       {                                                           \
         float z = aa.f * x.f + bb.f, sg = sigmoidf_(z);           \
         float act = z * sg, sp = sg * (1.f + z * (1.f - sg));     \
         acc[0].f += ga.f * act; acc[1].f += ga.f * sp; acc[2].f += sp; \
         acc[3].f += ga.f * sp * x.f; acc[4].f += sp * x.f;        \
       }
-      SE1(x) SE1(y) SE1(z) SE1(w)
-#undef SE1
+    long r = r0 + tr;
+    for (; r + g.rpp < r1; r += 2 * g.rpp) {       // two rows (four loads) in flight
+      const float4 x0 = ld4(X + r * g.C + c), g0 = ld4(G + r * g.C + c);
+      const float4 x1 = ld4(X + (r + g.rpp) * g.C + c), g1 = ld4(G + (r + g.rpp) * g.C + c);
+      SE1(x, x0, g0) SE1(y, x0, g0) SE1(z, x0, g0) SE1(w, x0, g0)
+      SE1(x, x1, g1) SE1(y, x1, g1) SE1(z, x1, g1) SE1(w, x1, g1)
     }
+    for (; r < r1; r += g.rpp) {
+      const float4 x0 = ld4(X + r * g.C + c), g0 = ld4(G + r * g.C + c);
+      SE1(x, x0, g0) SE1(y, x0, g0) SE1(z, x0, g0) SE1(w, x0, g0)
+    }
+#undef SE1
   }
 #pragma unroll
   for (int i = 0; i < 5; ++i) sm[i][tid] = acc[i];

@@ -1,0 +1,51 @@
+"""Merge rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE, SQ_VALU_MFMA_BUSY_CYCLES; each run with --kernel-trace) into a
+per-kernel-family table: launches, mean duration, HBM-side bytes per launch (FETCH_SIZE x2 per the gfx950 correction for
+16-B/lane reads, MI355X_MICROARCH.md 'HBM'), GB/s, MFMA pipe utilisation."""
+import csv, glob, json, os, re, sys, collections
+
+def load(d):
+    cc = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
+    kt = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
+    dur = {}
+    for r in csv.DictReader(open(kt)):
+        dur[r["Dispatch_Id"]] = (float(r["End_Timestamp"]) - float(r["Start_Timestamp"])) * 1e-9
+    out = collections.defaultdict(lambda: collections.defaultdict(float))
+    cnt = collections.Counter()
+    seen = set()
+    for r in csv.DictReader(open(cc)):
+        fam = family(r["Kernel_Name"])
+        out[fam][r["Counter_Name"]] += float(r["Counter_Value"])
+        key = (r["Dispatch_Id"], r["Counter_Name"])
+        if r["Dispatch_Id"] not in seen:
+            seen.add(r["Dispatch_Id"])
+            cnt[fam] += 1
+            out[fam]["_dur"] += dur.get(r["Dispatch_Id"], 0.0)
+    return out, cnt
+
+def family(n):
+    n = re.sub(r"\(.*", "", n).replace("void ", "")
+    if n.startswith("gemm_kernel"):
+        m = re.match(r"gemm_kernel<(\d)", n)
+        return "gemm_kernel<%s>" % {"0": "NT fwd", "1": "NN dgrad", "2": "TN wgrad"}[m.group(1)]
+    return re.sub(r"<.*", "", n)
+
+dirs = dict(a.split("=") for a in sys.argv[2:])
+res = {}
+fetch, cf = load(dirs["fetch"]); write, _ = load(dirs["write"]); mfma, cm = load(dirs["mfma"])
+for fam in sorted(cf, key=lambda f: -fetch[f]["_dur"]):
+    n = cf[fam]
+    d = fetch[fam]["_dur"] / n
+    fb = 2.0 * fetch[fam].get("FETCH_SIZE", 0.0) * 1024 / n          # KB -> B, x2 correction
+    wb = write[fam].get("WRITE_SIZE", 0.0) * 1024 / max(1, n)
+    dm = mfma[fam]["_dur"] / max(1, cm.get(fam, 1))
+    busy = mfma[fam].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / max(1, cm.get(fam, 1))
+    util = busy / (dm * 2.4e9 * 1024) if dm > 0 else 0.0             # 1024 SIMDs, 2.4 GHz
+    if fetch[fam]["_dur"] / sum(v["_dur"] for v in fetch.values()) < 0.004: continue
+    res[fam] = {"launches": n, "avg_us": round(d * 1e6, 1), "read_MB_per_launch": round(fb / 1e6, 1), "write_MB_per_launch": round(wb / 1e6, 1),
+                "hbm_side_GBps": round((fb + wb) / d / 1e9, 0) if d > 0 else None, "mfma_util": round(util, 3)}
+json.dump({"source": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES}, three passes over "
+           "bench.py --steps 2 --warmup 1 (kernels are serialised and slower under counter collection; durations are from the "
+           "FETCH pass); FETCH_SIZE doubled (gfx950: 128-B read requests tallied at 64 B); Infinity-Cache hits are counted "
+           "as HBM-side traffic by these counters; mfma_util = MFMA busy cycles / (duration x 1024 SIMDs x 2.4 GHz)",
+           "kernels": res}, open(sys.argv[1], "w"), indent=1)
+print(open(sys.argv[1]).read())

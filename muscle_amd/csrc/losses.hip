@@ -250,25 +250,47 @@ __global__ __launch_bounds__(256) void er_hist_kernel(const float* d, long row_l
     if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); unsafeAtomicAdd(&hsum[n * RBINS + i], ls[i]); }
 }
 
-// per row: pick the digit of the k-th largest; state = {krem (still to take), prefix, sum_gt, cnt_eq}
-__global__ void er_scan_kernel(const unsigned* hcnt, const float* hsum, int shift, int nbits, unsigned* krem, unsigned* prefix,
-                               float* sum_gt, unsigned* cnt_eq, int N) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
+// per row: pick the digit of the k-th largest; state = {krem (still to take), prefix, sum_gt, cnt_eq}.
+// One wave per row: lane l owns the l-th chunk of bins counted from the top; a wave scan of the chunk counts finds the
+// chunk in which the running count reaches k, and only that lane walks its bins.  (One thread per row walking up to
+// 2048 bins through dependent global loads took 340 us per pass, three passes per step.)
+__global__ __launch_bounds__(64) void er_scan_kernel(const unsigned* hcnt, const float* hsum, int shift, int nbits, unsigned* krem,
+                                                     unsigned* prefix, float* sum_gt, unsigned* cnt_eq, int N) {
+  const int n = blockIdx.x, lane = threadIdx.x;
   if (n >= N) return;
-  unsigned k = krem[n];
-  float s = sum_gt[n];
-  int nb = 1 << nbits;
-  int b = nb - 1;
-  for (; b > 0; --b) {
-    unsigned c = hcnt[n * RBINS + b];
+  const int nb = 1 << nbits, per = nb / 64;          // nbits is 10 or 11
+  const unsigned* hc = hcnt + (long)n * RBINS;
+  const float* hs = hsum + (long)n * RBINS;
+  const int top = nb - 1 - lane * per;               // this lane's bins: top, top-1, ..., top-per+1
+  unsigned cl = 0;
+  float sl = 0.f;
+  for (int i = 0; i < per; ++i) { cl += hc[top - i]; sl += hs[top - i]; }
+  unsigned incl = cl;                                // inclusive scan over lanes (from the top bin down)
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    unsigned t = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += t;
+  }
+  const unsigned k0 = krem[n];
+  const unsigned long long m = __ballot(incl >= k0);
+  const int L = m ? (__ffsll((long long)m) - 1) : 63;  // no chunk reaches k: the walk ends at bin 0, which lane 63 owns
+  const float s_above = wave_sum(lane < L ? sl : 0.f);
+  const unsigned k_above = __shfl(incl - cl, L, 64);
+  if (lane != L) return;
+  unsigned k = k0 - k_above;
+  float s = sum_gt[n] + s_above;
+  int b = top;
+  for (; b > 0 && b > top - per; --b) {
+    unsigned c = hc[b];
     if (c >= k) break;
     k -= c;
-    s += hsum[n * RBINS + b];
+    s += hs[b];
   }
+  if (b == top - per) b = top - per + 1;             // cannot happen when incl >= k0; keeps b inside the chunk
   krem[n] = k;
   sum_gt[n] = s;
   prefix[n] |= ((unsigned)b) << shift;
-  cnt_eq[n] = hcnt[n * RBINS + b];
+  cnt_eq[n] = hc[b];
 }
 
 // loss = sum_n (sum_gt[n] + krem[n] * tau[n]) / (N * k)
@@ -392,7 +414,7 @@ int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int
     hipMemsetAsync(hsum, 0, sizeof(float) * N * RBINS, st);
     hipLaunchKernelGGL(er_hist_kernel, dim3(chunks, N), dim3(256), 0, st, d, row_len, shifts[ps], bits[ps], himask[ps], prefix,
                        hcnt, hsum);
-    hipLaunchKernelGGL(er_scan_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
+    hipLaunchKernelGGL(er_scan_kernel, dim3(N), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
                        cnt_eq, N);
   }
   hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)k), loss);
@@ -574,7 +596,7 @@ int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, in
     hipMemsetAsync(hsum, 0, sizeof(float) * N * RBINS, st);
     hipLaunchKernelGGL(er_lr_hist_kernel, dim3(chunks, N), dim3(256), 0, st, cam, sgc, lwb, h, w, L, K, H, W, shifts[ps], bits[ps],
                        himask[ps], prefix, hcnt, hsum);
-    hipLaunchKernelGGL(er_scan_kernel, dim3(cdiv(N, 64)), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
+    hipLaunchKernelGGL(er_scan_kernel, dim3(N), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
                        cnt_eq, N);
   }
   hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)k), loss);

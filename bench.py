@@ -208,8 +208,8 @@ def main():
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
-        traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")
+    if os.path.exists(tpath) and (a.model, a.size, a.batch, full) == ("efficientnet-b7", 448, 32, False):
+        traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")     # measured for this workload only
     res = {
         "metric": "images/sec (whole node), MCL EfficientNet-B7 448x448 bs=32/GPU" if (a.model, a.size, a.batch) == ("efficientnet-b7", 448, 32)
         else f"images/sec (whole node), MCL {a.model} {a.size}x{a.size} bs={a.batch}/GPU",
@@ -223,7 +223,7 @@ def main():
                                f"MuSCLe({a.model}, last_pooling=False, 21 classes), random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
                    "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused"},
-        "losses": {k: (float(v) if torch.is_tensor(v) else v) for k, v in out.items()},
+        "losses": {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in out.items()},
         "roofline": {"bound": "mfma", "kernel": "gemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 pointwise convs: fwd+dgrad+wgrad, stem)",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": traffic,

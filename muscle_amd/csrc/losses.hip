@@ -574,6 +574,91 @@ __global__ __launch_bounds__(256) void er_lr_bwd_kernel(const float* cam, const 
   }
 }
 
+// The same gradient with every full-resolution pixel evaluated ONCE (the gather kernel above evaluates each pixel for
+// each of the up to four low-res cells it feeds).  One workgroup = a band of `ty` rows x 256 columns, thread = column.
+// ty is chosen so that a band spans less than one low-res row: its pixels touch at most three low-res rows, which are
+// three register slots per class; the column direction goes through LDS atomics, then one global atomic per touched
+// (cell, class).  gsgc must be zero-filled.
+template <int KT>
+__global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, const float* sgc, const float* lwb,
+                                                             const unsigned* prefix, const unsigned* krem, const unsigned* cnt_eq,
+                                                             const float* gup, float gscale, float* gsgc, int h, int w, int L,
+                                                             int H, int W, int ty) {
+  extern __shared__ float lacc[];                 // [3][ncx][KT]
+  const int n = blockIdx.z, Y0 = blockIdx.y * ty, X = blockIdx.x * 256 + threadIdx.x;
+  const int Y1 = min(H, Y0 + ty);
+  int cb, t1, xb, xe, t2;
+  float tw;
+  lr_coord(Y0, h, H, cb, t1, tw);
+  lr_coord(blockIdx.x * 256, w, W, xb, t2, tw);
+  lr_coord(min(W - 1, blockIdx.x * 256 + 255), w, W, t1, xe, tw);
+  const int ncx = xe - xb + 1;
+  for (int i = threadIdx.x; i < 3 * ncx * KT; i += 256) lacc[i] = 0.f;
+  __syncthreads();
+  if (gup) gscale *= gup[0];
+  float S[3][KT];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int k = 0; k < KT; ++k) S[r][k] = 0.f;
+  int x0 = 0, x1 = 0;
+  float wx = 0.f;
+  if (X < W) {
+    const unsigned tk = prefix[n];
+    const float tiew = cnt_eq[n] ? (float)krem[n] / (float)cnt_eq[n] : 0.f;
+    float m[KT];
+#pragma unroll
+    for (int k = 0; k < KT; ++k) m[k] = lwb[n * KT + k];
+    for (int Y = Y0; Y < Y1; ++Y) {
+      float a[KMAX], b[KMAX], g[KT], wy;
+      int y0, y1;
+      const int am = lr_pixel(cam, sgc, n, Y, X, h, w, L, KT, H, W, a, b, wy, wx, y0, y1, x0, x1);
+#pragma unroll
+      for (int k = 0; k < KT; ++k) {
+        float df = a[k] - b[k];
+        unsigned key = __float_as_uint(fabsf(df) * m[k]);
+        float ww = (key > tk) ? 1.f : ((key == tk) ? tiew : 0.f);
+        float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
+        g[k] = -sg * m[k] * ww * gscale;
+      }
+      float g0 = g[0];
+#pragma unroll
+      for (int k = 1; k < KT; ++k) g[k] -= (k == am) ? g0 : 0.f;
+      float dot = 0.f;
+#pragma unroll
+      for (int k = 1; k < KT; ++k) dot += g[k] * b[k];
+      const int s0 = y0 - cb, s1 = y1 - cb;       // uniform over the workgroup (same Y)
+      const float w0 = 1.f - wy, w1 = (y1 != y0) ? wy : 0.f;
+#pragma unroll
+      for (int k = 1; k < KT; ++k) {
+        const float v = b[k] * (g[k] - dot);
+        if (s0 == 0) S[0][k] += w0 * v; else if (s0 == 1) S[1][k] += w0 * v; else S[2][k] += w0 * v;
+        if (s1 == 0) S[0][k] += w1 * v; else if (s1 == 1) S[1][k] += w1 * v; else S[2][k] += w1 * v;
+      }
+    }
+    const float u0 = 1.f - wx, u1 = (x1 != x0) ? wx : 0.f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int k = 1; k < KT; ++k) {
+        const float v = S[r][k];
+        if (v != 0.f) {
+          atomicAdd(&lacc[(r * ncx + (x0 - xb)) * KT + k], u0 * v);
+          if (u1 != 0.f) atomicAdd(&lacc[(r * ncx + (x1 - xb)) * KT + k], u1 * v);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 3 * ncx * KT; i += 256) {
+    const float v = lacc[i];
+    if (v == 0.f) continue;
+    const int k = i % KT, cx = (i / KT) % ncx, r = i / (KT * ncx);
+    const int cy = cb + r;
+    if (cy < h) unsafeAtomicAdd(&gsgc[(((long)n * h + cy) * w + xb + cx) * L + k], v);
+  }
+}
+
 extern "C" {
 
 // ER loss from the low-res NHWC maps cam/sgc [N,h,w,L] for an H x W image (train_mcl.py:175-188 + MuSCLe.py:256-257 fused).
@@ -609,8 +694,25 @@ int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const uns
                  int W, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && prefix && krem && cnt_eq && gsgc, "er_lr_bwd: null pointer");
   MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L <= 256 && H > 0 && W > 0, "er_lr_bwd: bad extents");
-  hipLaunchKernelGGL(er_lr_bwd_kernel, dim3(h * w, N), dim3(256), 0, (hipStream_t)stream, cam, sgc, lwb, prefix, krem, cnt_eq, gup,
-                     gscale, gsgc, h, w, L, K, H, W);
+  if (K == 21) {
+    // rows per band: the largest count that keeps a band within one low-res row spacing (at most three low-res rows touched)
+    int ty = (h > 1) ? (H - 1) / (h - 1) : H;
+    if (ty < 1) ty = 1;
+    if (ty > 32) ty = 32;
+    int xb0, xe0, t;                                 // widest low-res column span of a 256-column segment (host copy of lr_coord)
+    (void)xb0; (void)t;
+    const double sx = (W > 1) ? (double)(w - 1) / (double)(W - 1) : 0.0;
+    xe0 = (int)(sx * 255.0) + 3;
+    if (xe0 > w) xe0 = w;
+    const size_t sh = (size_t)3 * (xe0 + 1) * 21 * sizeof(float);
+    MX_CHECK_ARG(sh <= 64 * 1024, "er_lr_bwd: low-res span per segment too wide (%d columns)", xe0);
+    hipMemsetAsync(gsgc, 0, sizeof(float) * (size_t)N * h * w * L, (hipStream_t)stream);
+    hipLaunchKernelGGL(er_lr_bwd_band_kernel<21>, dim3(cdiv(W, 256), cdiv(H, ty), N), dim3(256), sh, (hipStream_t)stream, cam, sgc,
+                       lwb, prefix, krem, cnt_eq, gup, gscale, gsgc, h, w, L, H, W, ty);
+  } else {
+    hipLaunchKernelGGL(er_lr_bwd_kernel, dim3(h * w, N), dim3(256), 0, (hipStream_t)stream, cam, sgc, lwb, prefix, krem, cnt_eq, gup,
+                       gscale, gsgc, h, w, L, K, H, W);
+  }
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -160,6 +160,12 @@ int mx_infer_accum(const float* src, float* acc, int h, int w, int lds, int K, i
  * v = (v - min - 1e-6) / (max - min + 1e-6) */
 int mx_infer_norm(float* acc, int channels, long HW, void* stream);
 
+/* ---- per-epoch rapid evaluation (train_mcl.py:286-318 + src/evaluation.py:19-52), one image:
+ * for each threshold t: predict = argmax_k [t, half(pred_k*label_k)] (first maximum wins); over pixels with gt < 255:
+ * counts[t][k][0..2] += (TP, P, T).  pred [K,H,W] fp32 (cam_maxnorm'ed), label [K], gt uint8 [H,W], counts int64 [nt][K][3]. */
+int mx_eval_confusion(const float* pred, const float* label, const unsigned char* gt, const float* thresholds, int nt, int K, int H,
+                      int W, long long* counts, void* stream);
+
 /* adjoint of mx_upsample_to_nchw: gsrc (=|+=) W^T gdst */
 int mx_upsample_to_nchw_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int lds, int K, int Hd, int Wd,
                             int accumulate, void* stream);

@@ -6,6 +6,7 @@
 // normalisation, the affinity column normalisation and their adjoints.  Low-resolution head tensors
 // are NHWC with the class dimension padded to a leading dimension that is a multiple of 4.
 #include "common.h"
+#include <hip/hip_fp16.h>
 
 // align_corners=True source coordinate (torch upsample_bilinear2d): src = dst * (in-1)/(out-1)
 __device__ __forceinline__ void bil_coord(int d, int in, int out, int& i0, int& i1, float& w1) {
@@ -267,6 +268,43 @@ __global__ __launch_bounds__(256) void infer_norm_kernel(float* acc, long HW) {
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Per-epoch rapid evaluation (train_mcl.py:286-318 + src/evaluation.py:19-52): for every threshold t,
+//   predict = argmax_k [t, half(pred_1*label_1), ..., half(pred_{K-1}*label_{K-1})]   (first maximum wins, as np.argmax)
+// and, over pixels with gt < 255:  P[predict]++, T[gt]++, TP[gt] += (predict == gt).
+// pred: one image, [K,H,W] fp32 (already cam_maxnorm'ed); label: [K] (entry 0 unused); gt: uint8 [H,W].
+// counts: int64 [nt][K][3] = (TP, P, T), accumulated across images.  The values go through fp16 exactly as the script's
+// np.half files do.  Per workgroup the counts are kept in LDS (nt*K*3 ints) and flushed once.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void eval_confusion_kernel(const float* pred, const float* label, const unsigned char* gt,
+                                                             const float* thr, int nt, int K, long HW, long long* counts) {
+  extern __shared__ int lc[];                   // [nt][K][3]
+  for (int i = threadIdx.x; i < nt * K * 3; i += 256) lc[i] = 0;
+  __syncthreads();
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < HW; p += (long)gridDim.x * 256) {
+    const int g = gt[p];
+    if (g >= 255) continue;
+    float best = -1.f;                          // values are >= 0; strict > keeps the first maximum
+    int bk = 0;
+    for (int k = 1; k < K; ++k) {
+      float v = __half2float(__float2half_rn(pred[(long)k * HW + p] * label[k]));
+      if (v > best) { best = v; bk = k; }
+    }
+    for (int t = 0; t < nt; ++t) {
+      const int pr = (thr[t] >= best) ? 0 : bk;  // channel 0 holds the threshold and precedes every other channel
+      atomicAdd(&lc[(t * K + pr) * 3 + 1], 1);
+      if (g < K) {
+        atomicAdd(&lc[(t * K + g) * 3 + 2], 1);
+        if (pr == g) atomicAdd(&lc[(t * K + g) * 3 + 0], 1);
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nt * K * 3; i += 256)
+    if (lc[i]) atomicAdd((unsigned long long*)&counts[i], (unsigned long long)lc[i]);
+}
+
 static int gs(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
 
 extern "C" {
@@ -358,6 +396,20 @@ int mx_infer_accum(const float* src, float* acc, int h, int w, int lds, int K, i
 int mx_infer_norm(float* acc, int channels, long HW, void* stream) {
   MX_CHECK_ARG(acc && channels > 0 && HW > 0, "infer_norm: bad args");
   hipLaunchKernelGGL(infer_norm_kernel, dim3(channels), dim3(256), 0, (hipStream_t)stream, acc, HW);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_eval_confusion(const float* pred, const float* label, const unsigned char* gt, const float* thresholds, int nt, int K, int H,
+                      int W, long long* counts, void* stream) {
+  MX_CHECK_ARG(pred && label && gt && thresholds && counts && nt > 0 && nt <= 64 && K >= 2 && K <= 256 && H > 0 && W > 0,
+               "eval_confusion: bad args");
+  const long HW = (long)H * W;
+  int blocks = (int)((HW + 256 * 8 - 1) / (256 * 8));
+  if (blocks < 1) blocks = 1;
+  if (blocks > 1024) blocks = 1024;
+  hipLaunchKernelGGL(eval_confusion_kernel, dim3(blocks), dim3(256), sizeof(int) * nt * K * 3, (hipStream_t)stream, pred, label, gt,
+                     thresholds, nt, K, HW, counts);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

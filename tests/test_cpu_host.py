@@ -182,3 +182,19 @@ def test_infer_oracle_semantics_and_file_format(tmp_path):
     infer.save_cam_dict(p, sgc)
     back = infer.load_cam_dict(p)
     assert sorted(back) == [1, 19] and np.array_equal(back[19], sgc[19])
+
+
+def test_eval_oracle_matches_hand_count():
+    """src/evaluation.py:27-68 restated in the oracle, on a 2x3 image counted by hand."""
+    from oracle import mcl_oracle as O
+    pd = {i: np.zeros((2, 3), np.half) for i in range(20)}
+    pd[0][:] = [[0.9, 0.1, 0.3], [0.3, 0.0, 0.6]]          # class 1
+    pd[4][:] = [[0.2, 0.4, 0.3], [0.1, 0.0, 0.6]]          # class 5
+    gt = np.array([[1, 5, 0], [255, 0, 1]], np.uint8)
+    TP, P, T_ = O.eval_compare(pd, gt, 0.3)
+    # fp16(0.3) = 0.30005 > 0.3, so at (0,2) class 1 beats the threshold channel and (first maximum) class 5:
+    # predict = [[1,5,1],[x,0,1]]
+    assert (TP[0], TP[1], TP[5]) == (1, 2, 1) and (P[0], P[1], P[5]) == (1, 3, 1) and (T_[0], T_[1], T_[5]) == (2, 2, 1)
+    m, per = O.eval_miou(TP, P, T_)
+    assert abs(per[0] - 50.0) < 1e-6 and abs(per[1] - 200.0 / 3) < 1e-6 and abs(per[5] - 100.0) < 1e-6
+    assert abs(m - (50.0 + 200.0 / 3 + 100.0) / 21) < 1e-6

@@ -160,6 +160,16 @@ int mx_infer_accum(const float* src, float* acc, int h, int w, int lds, int K, i
  * v = (v - min - 1e-6) / (max - min + 1e-6) */
 int mx_infer_norm(float* acc, int channels, long HW, void* stream);
 
+/* ---- IRN random-walk propagation (src/indexing.py:77-142 as called by infer_irn.py:76).
+ * mx_irn_affinity: dense[n4][ld] (zero-filled here) <- symmetric affinity 1 - max(edge along the straight path) for every
+ *   pixel pair joined by one of the nd search directions, unit diagonal; edge [h,w]; pcoord = int32 (dy,dx) pairs of all
+ *   paths back to back (farthest pixel first = the destination), poff[d] / plen[d] = first pair and length of path d.
+ * mx_irn_transition: dense <- dense^beta / column sums (to_transition_matrix :116-118); colsum[n4] is workspace.
+ * The matrix powers and the final product are mx_bgemm calls. */
+int mx_irn_affinity(const float* edge, int h, int w, int radius, const int* pcoord, const int* poff, const int* plen, int nd,
+                    float* dense, int ld, int n4, void* stream);
+int mx_irn_transition(float* dense, int n4, int ld, float beta, float* colsum, void* stream);
+
 /* ---- per-epoch rapid evaluation (train_mcl.py:286-318 + src/evaluation.py:19-52), one image:
  * for each threshold t: predict = argmax_k [t, half(pred_k*label_k)] (first maximum wins); over pixels with gt < 255:
  * counts[t][k][0..2] += (TP, P, T).  pred [K,H,W] fp32 (cam_maxnorm'ed), label [K], gt uint8 [H,W], counts int64 [nt][K][3]. */

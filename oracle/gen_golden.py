@@ -553,6 +553,25 @@ def gen_seg_forward(src, name, n, size, seed, fname):
     print(fname, "seg absmax", float(seg.abs().max()))
 
 
+def gen_irn_units(src, fname="irn_rw.npz"):
+    """src/indexing.py::propagate_to_edge (the IRN random walk, infer_irn.py:76) run as is on CPU: its three hard-wired
+    `.cuda()` calls (indexing.py:84, :110) are made no-ops for the duration of the call, nothing else is touched."""
+    import src.indexing as RI
+    out = {}
+    orig = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    try:
+        for tag, (h, w, radius, beta, times, seed) in {"a": (13, 17, 5, 10, 8, 0), "b": (9, 22, 5, 8, 4, 1), "c": (16, 12, 3, 10, 6, 2)}.items():
+            x = torch.from_numpy(synth.uniform(seed, f"irn_x_{tag}", (1, 20, h, w)).astype(np.float32))
+            edge = torch.from_numpy(synth.uniform(seed, f"irn_e_{tag}", (1, h, w)).astype(np.float32)) ** 2
+            rw = RI.propagate_to_edge(x.clone(), edge.clone(), radius=radius, beta=beta, exp_times=times)
+            out[f"{tag}_x"], out[f"{tag}_edge"], out[f"{tag}_rw"] = x.numpy(), edge.numpy(), rw.numpy()
+            out[f"{tag}_params"] = np.array([radius, beta, times], np.int64)
+    finally:
+        torch.Tensor.cuda = orig
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
 def main_config4(src):
     gen_field_units(src)
     gen_seg_forward(src, "efficientnet-b3", 2, 96, 21, "seg_forward_b3.npz")
@@ -581,6 +600,7 @@ def main():
     gen_step(src, tree, "efficientnet-b3", 4, 64, 64, 12, 6, "step_b3_ep12_lr0.npz", lr=0.0)
     gen_step(src, tree, "efficientnet-b7", 4, 64, 32, 4, 8, "step_b7_ep4.npz")
     main_config4(src)
+    gen_irn_units(src)
 
 
 if __name__ == "__main__":

@@ -291,3 +291,17 @@ def test_muscle_step(fname):
         scale = np.maximum(ref[live, :1], 1e-3 * ref[live, 0].max())
         assert np.all(np.abs(g[live] - ref[live]) <= 2e-3 * scale), np.abs((g[live] - ref[live]) / scale).max()
         close(_bn_summary(net), G["bn_after"], 2e-5)
+
+
+def test_irn_random_walk_matches_reference():
+    """oracle restatement of src/indexing.py::propagate_to_edge against the fixture the reference's own functions wrote
+    (oracle/gen_golden.py::gen_irn_units): three sizes / radii / beta / exp_times."""
+    import os
+    from oracle import mcl_oracle as O
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "irn_rw.npz"))
+    for tag in ("a", "b", "c"):
+        radius, beta, times = (int(v) for v in z[f"{tag}_params"])
+        rw = O.irn_propagate_to_edge(torch.from_numpy(z[f"{tag}_x"]), torch.from_numpy(z[f"{tag}_edge"]), radius, beta, times)
+        ref = z[f"{tag}_rw"]
+        assert rw.shape == ref.shape
+        assert float(np.abs(rw.numpy() - ref).max()) <= 1e-6 * float(np.abs(ref).max())

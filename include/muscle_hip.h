@@ -169,6 +169,11 @@ int mx_infer_norm(float* acc, int channels, long HW, void* stream);
 int mx_irn_affinity(const float* edge, int h, int w, int radius, const int* pcoord, const int* poff, const int* plen, int nd,
                     float* dense, int ld, int n4, void* stream);
 int mx_irn_transition(float* dense, int n4, int ld, float beta, float* colsum, void* stream);
+/* infer_irn.py:78-94 after the walk: rw [C,h,w] -> 4x bilinear (half-pixel) upsample, top-left HxW crop, / global max,
+ * label[H,W] (uint8) = argmax over [bg_thres, maps] (first maximum wins); soft_half (optional, fp16 [H,W,C+1]) = the
+ * values themselves as the script's --soft_output writes them.  max_scratch: one uint32. */
+int mx_irn_finish(const float* rw, int C, int h, int w, int H, int W, float bg_thres, unsigned* max_scratch, unsigned char* label,
+                  void* soft_half, void* stream);
 
 /* ---- per-epoch rapid evaluation (train_mcl.py:286-318 + src/evaluation.py:19-52), one image:
  * for each threshold t: predict = argmax_k [t, half(pred_k*label_k)] (first maximum wins); over pixels with gt < 255:

@@ -78,3 +78,15 @@ def propagate_to_edge(x: torch.Tensor, edge: torch.Tensor, radius: int = 5, beta
     rw = torch.empty(C4, n4, dtype=torch.float32, device=dev)
     ops.bgemm(1, xp.view(1, C4, n4), A.view(1, n4, n4), rw.view(1, C4, n4), C4, n4, n4)
     return rw[:C, :n].reshape(C, 1, h, w)
+
+
+def finish_semseg(rw: torch.Tensor, H: int, W: int, bg_thres: float, soft_output: bool = False):
+    """infer_irn.py:78-94: rw [C,1,h,w] -> uint8 label map [H,W] (argmax over [bg_thres, upsampled rw / max]); with
+    soft_output also the fp16 [H,W,C+1] array the script saves."""
+    C, _, h, w = rw.shape
+    r = rw.reshape(C, h, w).contiguous().float()
+    label = torch.empty(H, W, dtype=torch.uint8, device=rw.device)
+    soft = torch.empty(H, W, C + 1, dtype=torch.float16, device=rw.device) if soft_output else None
+    scratch = torch.empty(1, dtype=torch.int32, device=rw.device)
+    call("mx_irn_finish", ptr(r), C, h, w, H, W, float(bg_thres), ptr(scratch), ptr(label), ptr(soft), stream())
+    return (label, soft) if soft_output else label

@@ -36,3 +36,19 @@ def test_propagate_to_edge_vs_oracle_larger():
     # a transition matrix is column-stochastic: propagating an all-ones map with edge = 0 returns all ones
     one = indexing.propagate_to_edge(torch.ones(1, 1, h, w, device=DEV), torch.zeros(1, h, w, device=DEV), exp_times=3)
     assert float((one - 1).abs().max()) <= 1e-4
+
+
+def test_finish_semseg_matches_oracle():
+    from oracle import mcl_oracle as O
+    from muscle_amd import indexing, synth
+    h, w, H, W = 19, 23, 74, 90                       # (H, W) crops the 4x upsampled 76 x 92 maps, as orig_img_size does
+    rw = torch.from_numpy(synth.uniform(9, "rw", (20, 1, h, w)).astype(np.float32)) ** 2
+    rw[3] *= 0.0                                       # an absent class
+    lab_ref, soft_ref = O.irn_finish(rw, H, W, 0.25)
+    lab, soft = indexing.finish_semseg(rw.to(DEV), H, W, 0.25, soft_output=True)
+    lab, soft = lab.cpu().numpy(), soft.cpu().numpy()
+    assert lab.dtype == np.uint8 and lab.shape == (H, W) and soft.dtype == np.float16 and soft.shape == (H, W, 21)
+    assert float(np.abs(soft.astype(np.float32) - soft_ref.astype(np.float32)).max()) <= 1e-3      # one fp16 ulp near 1.0
+    # labels: identical except where the two best values are within fp32 round-off of each other
+    diff = lab != lab_ref
+    assert diff.mean() <= 2e-3, float(diff.mean())

@@ -1,4 +1,6 @@
-"""Bottleneck isolation for the GEMM main loop (temporary MX_GEMM_DEBUG bits: 1 no global loads, 2 no LDS stores, 4 no barrier)."""
+"""Per-shape timing of the three pointwise GEMM kinds on the B7 layer shapes (`child` mode).  The parent mode re-runs the
+child under MX_GEMM_DEBUG values; those bits only exist in throw-away builds used for the bottleneck isolation recorded
+in DESIGN.md section 3 (no global loads / no LDS stores / no barrier / no epilogue) and are not in the committed kernel."""
 import sys, os, subprocess
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -335,7 +335,9 @@ __device__ float emd_distance(const float* xs, const float* ys, const float* u, 
   return t / ((float)n1 * (float)n2);
 }
 
-__global__ __launch_bounds__(256) void emd_score_kernel(const float* feat, const int* pairs, float* score) {
+// 1024 threads: the operands of one pair fill the CU's LDS (up to 150 KB), so one workgroup per CU is all there is; with 256
+// threads the CU ran 4 waves and the row loops were latency-bound.
+__global__ __launch_bounds__(1024) void emd_score_kernel(const float* feat, const int* pairs, float* score) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int* t = pairs + blockIdx.x * 6;
   const int n1 = t[1], n2 = t[3];
@@ -361,7 +363,8 @@ __global__ void emd_best_kernel(const float* score, const int* pairs, int npairs
 
 // backward through the 10 iterations for the best pair of each sample: gx[best crop1 pixels, 24] = d dist / d x * gscale
 // traj: per block (EMD_ITERS+1) * (n1 + n2) floats of (u_t, v_t), in global scratch
-__global__ __launch_bounds__(256) void emd_grad_kernel(const float* feat, const int* pairs, const int* best, float* traj,
+template <int BLOCK>
+__global__ __launch_bounds__(BLOCK) void emd_grad_kernel(const float* feat, const int* pairs, const int* best, float* traj,
                                                        long traj_stride, const float* gup, float gscale, float* gx) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int bi = best[blockIdx.x];
@@ -384,8 +387,9 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(const float* feat, const 
   __syncthreads();
   const float ir = 1.f / EMD_REG, inv12 = 1.f / ((float)n1 * (float)n2);
   // per-thread gradient accumulators for the rows it owns
-  float gxl[(EMD_MAXP + 255) / 256][FP];
-  for (int q = 0; q < (EMD_MAXP + 255) / 256; ++q)
+  constexpr int RPT = (EMD_MAXP + BLOCK - 1) / BLOCK;      // rows per thread
+  float gxl[RPT][FP];
+  for (int q = 0; q < RPT; ++q)
     for (int k = 0; k < FP; ++k) gxl[q][k] = 0.f;
   // final stage: Mbar_ij = pi_ij * Cd_ij / (n1 n2); Cbar += -Mbar/reg (the explicit Cd factor is detached); ubar_i = sum_j Mbar/reg ...
   {
@@ -435,7 +439,7 @@ __global__ __launch_bounds__(256) void emd_grad_kernel(const float* feat, const 
       }
       tmp[i] = nu_;
     }
-    float vnew[(EMD_MAXP + 255) / 256];
+    float vnew[RPT];
     int c2 = 0;
     for (int j = threadIdx.x; j < n2; j += blockDim.x, ++c2) {
       F24 yj = ld24(ys + j * FP);
@@ -519,7 +523,7 @@ int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, in
   size_t sh = emd_lds(maxn1 < 2 * FP ? 2 * FP : maxn1, maxn2 < 2 * FP ? 2 * FP : maxn2, 0);
   MX_CHECK_ARG(sh <= 160 * 1024, "emd_scores: LDS need %zu exceeds 160 KiB", sh);
   if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  hipLaunchKernelGGL(emd_score_kernel, dim3(npairs), dim3(256), sh, (hipStream_t)stream, feat, pairs, score);
+  hipLaunchKernelGGL(emd_score_kernel, dim3(npairs), dim3(1024), sh, (hipStream_t)stream, feat, pairs, score);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -538,9 +542,9 @@ int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsampl
   MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_grad: crop larger than %d pixels", EMD_MAXP);
   size_t sh = emd_lds(maxn1 < 2 * FP ? 2 * FP : maxn1, maxn2 < 2 * FP ? 2 * FP : maxn2, 1);
   MX_CHECK_ARG(sh <= 160 * 1024, "emd_grad: LDS need %zu exceeds 160 KiB", sh);
-  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
-  hipLaunchKernelGGL(emd_grad_kernel, dim3(nsamples), dim3(256), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
+  hipLaunchKernelGGL(emd_grad_kernel<512>, dim3(nsamples), dim3(512), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
                      gx);
   MX_LAUNCH_CHECK();
   return MX_OK;

@@ -141,3 +141,51 @@ def test_fused_adam_matches_torch_on_the_b7_arena():
         opt_ref.step()
     worst = max(float((p.detach() - r.detach()).abs().max()) for p, r in zip(ps, ref))
     assert worst <= 2e-6, worst
+
+
+def test_b7_decoder_448_bs16_scale_invariance_identity():
+    """BASELINE.json configs[3] size (decoder mode, B7, 448x448, batch 16): the same identity over the backbone's conv -> BN
+    pairs and the BiFPN's Conv2d(+bias) -> BatchNorm2d pairs (for a biased conv the invariant scaling is of (W, b) jointly:
+    <dW[c], W[c]> + db[c]*b[c] = eps * rstd[c]^2 * gamma[c] * dgamma[c]), on one train_muscle.py step (cross entropy)."""
+    import muscle_amd
+    from muscle_amd import arch, synth
+    name, N, size = "efficientnet-b7", 16, 448
+    cfg = arch.net_cfg(name, True)
+    torch.manual_seed(0)
+    model = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=True, mode="dec").to(DEV)
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.momentum = 1.0
+    opt = muscle_amd.FusedAdam(model.parameters(), lr=0.0, weight_decay=0.0)
+    label = synth.synth_labels(N, 7)
+    batch = {"img": torch.from_numpy(synth.normal(7, "img", (N, 3, size, size)).astype(np.float32)).to(DEV),
+             "label": torch.from_numpy(label).to(DEV),
+             "mask": torch.from_numpy(synth.synth_soft_mask(label, size, 7)).to(DEV)}
+    out = muscle_amd.muscle_step(model, opt, batch, lamb=0.0)
+    assert np.isfinite(float(out["loss_seg"].detach()))
+    pairs = [(w, None, bn, n) for w, bn, n in _pairs(model, cfg, N, size)]
+    for i in range(3, 8):
+        seq = getattr(model.BIFPN, f"inp{i}")
+        pairs.append((seq[0].weight, seq[0].bias, seq[1], None))
+    for layer in model.BIFPN.BIFPN_Layers:
+        for nm in ("out4", "out5", "out6", "out7"):
+            seq = getattr(layer, nm)
+            pairs.append((seq[0].weight, seq[0].bias, seq[1], None))
+    checked = 0
+    for w, b, bn, n in pairs:
+        if w.grad is None:                               # dead branches of the last BiFPN layer (as in the reference)
+            assert bn.weight.grad is None
+            continue
+        W, G = w.detach().double().flatten(1), w.grad.double().flatten(1)
+        lhs = (W * G).sum(1)
+        if b is not None:
+            lhs = lhs + b.detach().double() * b.grad.double()
+        # BiFPN maps (n is None): the unbiased -> biased factor (n-1)/n is within 2e-3 of 1 (n >= 16*7*7) and is absorbed
+        # by the looser tolerance below
+        var_b = bn.running_var.double() * ((n - 1) / n if n is not None else 1.0)
+        rhs = bn.eps / (var_b + bn.eps) * bn.weight.detach().double() * bn.weight.grad.double()
+        scale = W.norm(dim=1) * G.norm(dim=1) + (0 if b is None else (b.detach().double() * b.grad.double()).abs()) + 1e-30
+        err = ((lhs - rhs).abs() / scale).max().item()
+        assert err <= (5e-5 if n is not None else 2e-3), (tuple(w.shape), err)
+        checked += W.shape[0]
+    assert checked > 60000

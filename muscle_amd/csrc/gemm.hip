@@ -32,6 +32,8 @@ struct GemmArgs {
   int relu;
   float* stats;             // partial statistics [Mtiles][2][N] or null
   int ksplit;               // TN: rows of R per z-slice
+  int xcd_nt;               // > 0: 1-D grid, the xcd_nt N tiles of an M tile run back to back on one XCD (see kernel)
+  int mt;                   // M tiles (for the 1-D grid)
 };
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
@@ -119,12 +121,21 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, h = lane >> 5;
   const int wm = wave / WN, wn = wave % WN;
-  // Rasterisation: M tiles fastest.  Tried and measured on MI355X (profiles/r01_pmc_fetch_write_per_kernel.json shows
-  // FETCH_SIZE ~3-4x the algorithmic bytes: every N tile re-streams A from beyond L2): an XCD-aware N-fastest order
-  // (the N tiles of an M tile back to back on one XCD) left NT/NN unchanged and made the weight gradient 1.5x slower;
-  // binding reduction slices to XCDs cost 13 %.  The re-reads are served by the 256 MiB Infinity Cache and are not
-  // what limits these kernels.
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // Rasterisation.  Default: M tiles fastest.  For the big layers (30 N tiles) an XCD-aware N-fastest order was measured
+  // twice: unchanged for fwd/dgrad (the re-streamed A rows come from the 256 MiB Infinity Cache, and the per-XCD window
+  // of 128 resident workgroups bounds what L2 can capture), 1.5x slower for the weight gradient, and binding reduction
+  // slices to XCDs cost 13 %.  The one case where it pays is below: few N tiles over a long, HBM-bound A operand.
+  // With few N tiles (2..16) and a streamed A operand the forward / data-gradient grid is 1-D and remapped: workgroup L
+  // runs on XCD L % 8 (round-robin dispatch), and the N tiles of one M tile are given to consecutive workgroups OF THE
+  // SAME XCD, so the A rows are fetched from beyond L2 once instead of once per N tile (N = 224 on 128x32 tiles: 7x).
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (g.xcd_nt > 0) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    tile_n = j % g.xcd_nt;
+    tile_m = (j / g.xcd_nt) * 8 + xcd;
+    if (tile_m >= g.mt) return;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int z = blockIdx.z;
 
   const float* A = g.a.p;
@@ -254,7 +265,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
       }
     }
     __syncthreads();
-    float* prow = g.stats + (long)blockIdx.x * 2 * g.N;
+    float* prow = g.stats + (long)tile_m * 2 * g.N;
     for (int i = tid; i < 2 * BN; i += 256) {
       const int which = i / BN, col = i - which * BN;
       float v = 0.f;
@@ -271,8 +282,19 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
 template <int LAYOUT, int WM, int WN, int TM, int TN, int BK = 16>
 static void launch(const GemmArgs& g, int batch_or_splits, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-  dim3 grid(cdiv(g.M, BM), cdiv(g.N, BN), batch_or_splits);
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, g);
+  const int mt = cdiv(g.M, BM), nt = cdiv(g.N, BN);
+  static const int xcd_mode = getenv("MX_GEMM_XCD") ? atoi(getenv("MX_GEMM_XCD")) : 1;
+  if (LAYOUT != L_TN && xcd_mode && nt >= 2 && nt <= 16 && mt >= 64) {
+    GemmArgs a = g;
+    a.xcd_nt = nt; a.mt = mt;
+    dim3 grid(8 * cdiv(mt, 8) * nt, 1, batch_or_splits);
+    hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
+    return;
+  }
+  GemmArgs a = g;
+  a.xcd_nt = 0; a.mt = mt;
+  dim3 grid(mt, nt, batch_or_splits);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
 }
 
 // Tile configurations (block tile BM x BN; 4 waves).  EfficientNet's channel counts (48, 80, 160, 224, 288, 480,

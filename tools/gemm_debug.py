@@ -14,7 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
         for _ in range(n): fn()
         e1.record(); torch.cuda.synchronize()
         return e0.elapsed_time(e1) / n * 1e-3
-    for (M, K, N) in [(25088, 640, 3840), (25088, 3840, 640), (25088, 384, 2304), (25088, 2304, 384), (25088, 224, 1344), (25088, 1344, 224), (100352, 80, 480), (401408, 48, 288), (1605632, 32, 192)]:
+    for (M, K, N) in [(25088, 640, 3840), (25088, 3840, 640), (25088, 384, 2304), (25088, 2304, 384), (25088, 224, 1344), (25088, 1344, 224), (25088, 160, 960), (25088, 960, 160), (100352, 80, 480), (100352, 480, 80), (401408, 48, 288), (401408, 288, 48), (401408, 192, 48), (1605632, 32, 192)]:
         A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.05
         fl = 2.0 * M * K * N
         t = timeit(lambda: ops.pw_fwd(A, W, N, want_stats=True))

@@ -66,8 +66,8 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* ggate, const
 
 // (B) thread = channel c, block row = chunk of SE_JB squeeze units: dW2[c,j] += sum_n ge[n,c] r[n,j];
 //     dW1[j,c] += sum_n gh[n,j] s[n,c] (both owned, no atomics); add[n,c] += inv_hw * sum_{j in chunk} gh[n,j] W1[j,c]
-//     (fp32 atomics across the <= 20 chunks; `add` is zero-filled by the entry point); db2 by chunk 0.
-constexpr int SE_NB = 32, SE_JB = 8;
+//     (fp32 atomics across the <= 40 chunks of 4 squeeze units; `add` is zero-filled by the entry point); db2 by chunk 0.
+constexpr int SE_NB = 32, SE_JB = 4;
 __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* ggate, const float* gate, const float* s, const float* h,
                                                        const float* gh, const float* W1, float inv_hw, float* add, float* dW1,
                                                        float* dW2, float* db2, int N, int C, int SQ) {

@@ -284,7 +284,7 @@ static void launch(const GemmArgs& g, int batch_or_splits, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int mt = cdiv(g.M, BM), nt = cdiv(g.N, BN);
   static const int xcd_mode = getenv("MX_GEMM_XCD") ? atoi(getenv("MX_GEMM_XCD")) : 1;
-  if (LAYOUT != L_TN && xcd_mode && nt >= 2 && nt <= 16 && mt >= 64) {
+  if (LAYOUT != L_TN && xcd_mode && nt >= 2 && nt <= 16 && mt >= 64) {     // 17..32 N tiles measured: 1-5 % slower
     GemmArgs a = g;
     a.xcd_nt = nt; a.mt = mt;
     dim3 grid(8 * cdiv(mt, 8) * nt, 1, batch_or_splits);

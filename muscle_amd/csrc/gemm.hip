@@ -33,7 +33,7 @@ struct GemmArgs {
   float* stats;             // partial statistics [Mtiles][2][N] or null
   int ksplit;               // TN: rows of R per z-slice
   int xcd_nt;               // > 0: 1-D grid, the xcd_nt N tiles of an M tile run back to back on one XCD (see kernel)
-  int mt;                   // M tiles (for the 1-D grid)
+  int mt, zt;               // M tiles, reduction slices (for the 1-D grids)
 };
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
@@ -129,14 +129,23 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
   // runs on XCD L % 8 (round-robin dispatch), and the N tiles of one M tile are given to consecutive workgroups OF THE
   // SAME XCD, so the A rows are fetched from beyond L2 once instead of once per N tile (N = 224 on 128x32 tiles: 7x).
   int tile_m = blockIdx.x, tile_n = blockIdx.y;
-  if (g.xcd_nt > 0) {
+  int zz = blockIdx.z;
+  if (LAYOUT == L_TN && g.xcd_nt > 0) {
+    // weight gradient: all output tiles of one reduction slice on one XCD, back to back (they read the same rows)
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int tiles = g.mt * g.xcd_nt;
+    const int t = j % tiles;
+    zz = (j / tiles) * 8 + xcd;
+    if (zz >= g.zt) return;
+    tile_m = t % g.mt; tile_n = t / g.mt;
+  } else if (g.xcd_nt > 0) {
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
     tile_n = j % g.xcd_nt;
     tile_m = (j / g.xcd_nt) * 8 + xcd;
     if (tile_m >= g.mt) return;
   }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  const int z = blockIdx.z;
+  const int z = zz;
 
   const float* A = g.a.p;
   const float* B = g.b.p;
@@ -291,8 +300,17 @@ static void launch(const GemmArgs& g, int batch_or_splits, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
     return;
   }
+  // weight gradient: measured win only for the stage-2 layers (401 408 rows, 2-6 output tiles: 277 -> 236, 331 -> 255 us);
+  // 5-13 % slower on the 25 088-row layers and 3 % slower at 1.6 M rows, where it stays off
+  if (LAYOUT == L_TN && xcd_mode && batch_or_splits >= 8 && mt * nt >= 2 && mt * nt <= 8 && g.K >= 200000 && g.K < 1000000) {
+    GemmArgs a = g;
+    a.xcd_nt = nt; a.mt = mt; a.zt = batch_or_splits;
+    dim3 grid(8 * cdiv(batch_or_splits, 8) * mt * nt, 1, 1);
+    hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
+    return;
+  }
   GemmArgs a = g;
-  a.xcd_nt = 0; a.mt = mt;
+  a.xcd_nt = 0; a.mt = mt; a.zt = batch_or_splits;
   dim3 grid(mt, nt, batch_or_splits);
   hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
 }

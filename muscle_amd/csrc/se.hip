@@ -42,9 +42,34 @@ __global__ __launch_bounds__(256) void se_fwd_expand_kernel(const float* h, cons
 }
 
 // ---- backward --------------------------------------------------------------------------------------
-// (A) ge[n,c] = ggate*gate*(1-gate) (written to `add` as scratch); g_r[n,j] = sum_c ge[n,c] W2[c,j];
-//     gh[n,j] = g_r * swish'(h); db1[j] += gh.   One wave per (n,j).
+// (A) g_r[n,j] = sum_c ge[n,c] W2[c,j] with ge = ggate*gate*(1-gate);  gh[n,j] = g_r * swish'(h);  db1[j] += gh.
+//     One wave per (n, four consecutive j): W2 is [C,SQ] row-major, so a lane's load is one 16-byte piece of row c
+//     (a wave per single j fetched 4 useful bytes per 64-byte request).  SQ is a multiple of 4 for every EfficientNet width.
 __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* ggate, const float* gate, const float* h, const float* W2,
+                                                       float* gh, float* db1, int C, int SQ) {
+  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int j = (blockIdx.y * 4 + wave) * 4;
+  if (j >= SQ) return;
+  const float* gg = ggate + (long)n * C;
+  const float* gt = gate + (long)n * C;
+  float4 acc = make_float4(0, 0, 0, 0);
+  for (int c = lane; c < C; c += 64) {
+    const float g = gt[c];
+    const float ge = gg[c] * g * (1.f - g);
+    const float4 w = ld4(W2 + (long)c * SQ + j);
+    acc.x += ge * w.x; acc.y += ge * w.y; acc.z += ge * w.z; acc.w += ge * w.w;
+  }
+  acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
+  if (lane < 4) {
+    const float a = lane == 0 ? acc.x : lane == 1 ? acc.y : lane == 2 ? acc.z : acc.w;
+    const float v = a * swish_gradf_(h[(long)n * SQ + j + lane]);
+    gh[(long)n * SQ + j + lane] = v;
+    unsafeAtomicAdd(db1 + j + lane, v);
+  }
+}
+
+// the same with one squeeze unit per wave, for widths whose SQ is not a multiple of 4 (B0 ... B6)
+__global__ __launch_bounds__(256) void se_bwd_a1_kernel(const float* ggate, const float* gate, const float* h, const float* W2,
                                                        float* gh, float* db1, int C, int SQ) {
   const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.y * 4 + wave;
@@ -165,11 +190,16 @@ int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float
   MX_CHECK_ARG(ggate && gate && s && h && W1 && W2 && add && dW1 && db1 && dW2 && db2, "se_bwd: null pointer");
   MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd: bad extents N=%d C=%d SQ=%d", N, C, SQ);
   MX_CHECK_ARG(gh_scratch != nullptr, "se_bwd: gh_scratch [N*SQ] required");
+
   size_t shb = (size_t)2 * N * SE_JB * sizeof(float);
   MX_CHECK_ARG(shb <= 48 * 1024, "se_bwd: N=%d too large for LDS staging", N);
   hipMemsetAsync(add, 0, sizeof(float) * (size_t)N * C, (hipStream_t)stream);
-  hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
-                     C, SQ);
+  if (SQ % 4 == 0 && ((uintptr_t)W2 & 15) == 0)
+    hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 16)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
+                       C, SQ);
+  else
+    hipLaunchKernelGGL(se_bwd_a1_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
+                       C, SQ);
   hipLaunchKernelGGL(se_bwd_b_kernel, dim3(cdiv(C, 256), cdiv(SQ, SE_JB)), dim3(256), shb, (hipStream_t)stream, ggate, gate, s, h, gh_scratch, W1,
                      inv_hw, add, dW1, dW2, db2, N, C, SQ);
   MX_LAUNCH_CHECK();

@@ -572,6 +572,41 @@ def gen_irn_units(src, fname="irn_rw.npz"):
     np.savez_compressed(os.path.join(OUT, fname), **out)
 
 
+def gen_eval_units(src, fname="eval_rapid.npz"):
+    """src/evaluation.py::do_python_eval run as is (its 8 worker processes, files and all) on synthetic prediction dicts and
+    ground-truth pngs written to a temporary directory; the fixture keeps the inputs and the returned loglists."""
+    import tempfile
+    from PIL import Image
+    from src.evaluation import do_python_eval
+    rng = np.random.default_rng(12)
+    out = {}
+    with tempfile.TemporaryDirectory() as td:
+        pred_dir, gt_dir = os.path.join(td, "pred"), os.path.join(td, "gt")
+        os.makedirs(pred_dir); os.makedirs(gt_dir)
+        names = []
+        for i in range(5):
+            H, W = 30 + 7 * i, 41 + 5 * i
+            present = sorted(rng.choice(20, 3, replace=False).tolist())
+            d = {c: (rng.random((H, W)).astype(np.float32) * (1.0 if c in present else 0.0)).astype(np.half) for c in range(20)}
+            gt = rng.integers(0, 21, size=(H // 6 + 1, W // 6 + 1)).astype(np.uint8)
+            gt = np.kron(gt, np.ones((6, 6), np.uint8))[:H, :W].copy()
+            gt[rng.random((H, W)) < 0.07] = 255
+            name = f"img{i}"
+            names.append(name)
+            np.save(os.path.join(pred_dir, name + ".npy"), d)
+            Image.fromarray(gt).save(os.path.join(gt_dir, name + ".png"))
+            out[f"pred{i}"] = np.stack([d[c] for c in range(20)])
+            out[f"gt{i}"] = gt
+        thr = [t / 100.0 for t in range(20, 52, 2)]
+        rows = []
+        for t in thr:
+            ll = do_python_eval(pred_dir, gt_dir, names, 21, "npy", t, printlog=False)
+            rows.append([ll[k] for k in list(ll.keys())])          # 21 category IoUs (percent) + mIoU
+        out["thresholds"] = np.array(thr, np.float64)
+        out["loglists"] = np.array(rows, np.float64)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+
+
 def main_config4(src):
     gen_field_units(src)
     gen_seg_forward(src, "efficientnet-b3", 2, 96, 21, "seg_forward_b3.npz")
@@ -601,6 +636,7 @@ def main():
     gen_step(src, tree, "efficientnet-b7", 4, 64, 32, 4, 8, "step_b7_ep4.npz")
     main_config4(src)
     gen_irn_units(src)
+    gen_eval_units(src)
 
 
 if __name__ == "__main__":

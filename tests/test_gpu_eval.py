@@ -80,3 +80,18 @@ def test_rapid_eval_end_to_end():
     for ti in range(len(RAPID_THRESHOLDS)):
         m, _ = O.eval_miou(ref[ti, :, 0], ref[ti, :, 1], ref[ti, :, 2])
         assert abs(ev.loglist(ti)['mIoU'] - m) <= 0.05                    # percent
+
+
+def test_rapid_eval_matches_reference_fixture():
+    """RapidEval against what src/evaluation.py::do_python_eval itself returned (tests/golden/eval_rapid.npz)."""
+    import os
+    from muscle_amd.evaluation import RapidEval, categories
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_rapid.npz"))
+    ev = RapidEval(DEV, thresholds=[float(t) for t in z["thresholds"]])
+    for i in range(5):
+        pred = np.concatenate([np.zeros((1,) + z[f"pred{i}"].shape[1:], np.float32), z[f"pred{i}"].astype(np.float32)])
+        ev.add_prediction(T(pred).to(DEV), torch.ones(21), T(z[f"gt{i}"]))
+    for ti in range(len(z["thresholds"])):
+        ll = ev.loglist(ti)
+        got = np.array([ll[c] for c in categories] + [ll["mIoU"]])
+        assert np.allclose(got, z["loglists"][ti], rtol=0, atol=1e-9), ti

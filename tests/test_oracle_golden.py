@@ -305,3 +305,20 @@ def test_irn_random_walk_matches_reference():
         ref = z[f"{tag}_rw"]
         assert rw.shape == ref.shape
         assert float(np.abs(rw.numpy() - ref).max()) <= 1e-6 * float(np.abs(ref).max())
+
+
+def test_rapid_eval_matches_reference():
+    """oracle eval_compare / eval_miou against the loglists src/evaluation.py::do_python_eval itself returned for the same
+    prediction dicts and ground-truth pngs (oracle/gen_golden.py::gen_eval_units): all 16 thresholds."""
+    import os
+    from oracle import mcl_oracle as O
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "eval_rapid.npz"))
+    for ti, t in enumerate(z["thresholds"]):
+        TP = P = T_ = 0
+        for i in range(5):
+            pd = {c: z[f"pred{i}"][c] for c in range(20)}
+            tp, p, tt = O.eval_compare(pd, z[f"gt{i}"], float(t))
+            TP, P, T_ = TP + tp, P + p, T_ + tt
+        m, per = O.eval_miou(TP, P, T_)
+        assert np.allclose(per, z["loglists"][ti, :21], rtol=0, atol=1e-9)
+        assert abs(m - z["loglists"][ti, 21]) <= 1e-9

@@ -198,3 +198,17 @@ def test_eval_oracle_matches_hand_count():
     m, per = O.eval_miou(TP, P, T_)
     assert abs(per[0] - 50.0) < 1e-6 and abs(per[1] - 200.0 / 3) < 1e-6 and abs(per[5] - 100.0) < 1e-6
     assert abs(m - (50.0 + 200.0 / 3 + 100.0) / 21) < 1e-6
+
+
+def test_irn_search_paths_table():
+    """The path table the HIP affinity kernel consumes (muscle_amd.indexing.search_paths) lists exactly the oracle's /
+    the reference's search paths (src/indexing.py:13-47): same directions, same pixels, farthest pixel first."""
+    from oracle import mcl_oracle as O
+    from muscle_amd import indexing
+    for radius in (3, 5):
+        mine = [tuple(map(tuple, p)) for p in indexing.search_paths(radius)]
+        ref = [tuple(map(tuple, p)) for g in O.irn_search_paths(radius) for p in g]
+        assert mine == ref and len(mine) == len(set(p[0] for p in mine))      # one path per destination
+        for p in mine:
+            assert p[-1] == (0, 0) and abs(p[0][0]) + abs(p[0][1]) == max(abs(y) + abs(x) for y, x in p)
+    assert len(indexing.search_paths(5)) == 34      # 4 + 9 + 9 + 7 + 5 directions inside the radius-5 half disc

@@ -542,9 +542,9 @@ int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsampl
   MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_grad: crop larger than %d pixels", EMD_MAXP);
   size_t sh = emd_lds(maxn1 < 2 * FP ? 2 * FP : maxn1, maxn2 < 2 * FP ? 2 * FP : maxn2, 1);
   MX_CHECK_ARG(sh <= 160 * 1024, "emd_grad: LDS need %zu exceeds 160 KiB", sh);
-  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
-  hipLaunchKernelGGL(emd_grad_kernel<512>, dim3(nsamples), dim3(512), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
+  hipLaunchKernelGGL(emd_grad_kernel<1024>, dim3(nsamples), dim3(1024), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
                      gx);
   MX_LAUNCH_CHECK();
   return MX_OK;

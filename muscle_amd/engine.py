@@ -61,7 +61,7 @@ class Tape:
 
 
 _keep_cache: Dict[tuple, torch.Tensor] = {}
-MATERIALISE_ABOVE = 128      # project convs with Cout above this use a materialised activated input
+MATERIALISE_ABOVE = int(os.environ.get("MUSCLE_MATERIALISE_ABOVE", "128"))      # project convs with Cout above this use a materialised activated input
 
 
 def _blk(backbone, i):

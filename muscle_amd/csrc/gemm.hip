@@ -418,7 +418,10 @@ static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
     // split the pixel reduction so the grid fills the chip (>= ~1024 blocks), >= 512 rows per split
     const TileCfg tc = kCfgs[pick_cfg(L_TN, g.M, g.N, g.K)];
     long tiles = (long)cdiv(g.M, tc.bm) * cdiv(g.N, tc.bn);
-    int splits = (int)((2048 + tiles - 1) / tiles);
+    // workgroup target of the split (tuning override MX_GEMM_SPLIT_TARGET; swept 1024/1536/2048/3072/4096 on the final
+    // code: 150.7 / 149.6 / 148.9 / 149.8 / 149.6 ms per step)
+    static const long split_target = getenv("MX_GEMM_SPLIT_TARGET") ? atol(getenv("MX_GEMM_SPLIT_TARGET")) : 2048;
+    int splits = (int)((split_target + tiles - 1) / tiles);
     int maxs = cdiv(g.K, 512);
     if (splits > maxs) splits = maxs;
     if (splits < 1) splits = 1;

@@ -552,7 +552,11 @@ static void dw_fused_geom(int N, int H, int Wd, int C, int* tiles_x, int* tiles_
   *tiles_x = cdiv(Wd, 16); *tiles_y = cdiv(H, 8);
   long ntiles = (long)N * (*tiles_x) * (*tiles_y);
   int chunks = cdiv(C, CB);
-  long g = 4096 / chunks;
+  // workgroups per launch ~ this target (tuning override MX_DW_GROUPS).  Fewer, longer-lived workgroups amortise the
+  // per-workgroup prologue / partial-row epilogue: A/B/A/B on one box 4096 -> 1024: 150.6, 153.7 -> 148.7, 151.6 ms per step;
+  // 8192 / 16384 cost another 1.5 / 3.5 ms.
+  static const long group_target = getenv("MX_DW_GROUPS") ? atol(getenv("MX_DW_GROUPS")) : 1024;
+  long g = group_target / chunks;
   if (g < 1) g = 1;
   if (g > ntiles) g = ntiles;
   *tpb = (int)((ntiles + g - 1) / g);

@@ -41,7 +41,10 @@ static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that o
   }
   g.rpp = 256 / g.tcols;
   int colchunks = cdiv(g.c4, g.tcols);
-  long target_blocks = 2048 / ((long)colchunks * groups);
+  // workgroups per reduction launch (tuning override MX_COLREDUCE_BLOCKS), swept twice on one box, ms per step:
+  // 256: 153.3  512: 150.1/150.5  1024: 147.7/147.9  2048: 149.4/150.0  4096: 150.3/151.7
+  static const long block_target = getenv("MX_COLREDUCE_BLOCKS") ? atol(getenv("MX_COLREDUCE_BLOCKS")) : 1024;
+  long target_blocks = block_target / ((long)colchunks * groups);
   if (target_blocks < 1) target_blocks = 1;
   long rpb = (rows_limit + target_blocks - 1) / target_blocks;
   if (rpb < 4L * g.rpp) rpb = 4L * g.rpp;

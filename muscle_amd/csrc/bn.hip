@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc,
 // Up to FUSED_FINALIZE_MAX_ROWS partial rows: reduction and finalisation in ONE launch (one workgroup = 32 channels x 8 row
 // lanes walks all rows).  The memset + reduce + finalise triple costs three ~5 us launches per BatchNorm per direction:
 // 324 BatchNorm finalisations per B7 step.
-constexpr int FUSED_FINALIZE_MAX_ROWS = 1024;
+static const int FUSED_FINALIZE_MAX_ROWS = getenv("MX_BN_FUSED_ROWS") ? atoi(getenv("MX_BN_FUSED_ROWS")) : 1024;
 template <bool BWD>
 __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* part, int P, int C, BnFwdFin f, BnBwdFin b) {
   __shared__ double sh[2][8][32];

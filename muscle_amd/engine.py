@@ -101,9 +101,10 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
         # an add, a floor and a div kernel, ~190 five-microsecond launches per B7 step
         idx = [b.index for b in cfg.blocks if b.skip and b.drop_rate]
         if idx:
-            key = (id(cfg), str(dev))
+            rates = tuple(1.0 - cfg.blocks[i].drop_rate for i in idx)
+            key = (rates, str(dev))                     # by value: a cfg object's id can be reused after it is collected
             if key not in _keep_cache:
-                _keep_cache[key] = torch.tensor([1.0 - cfg.blocks[i].drop_rate for i in idx], dtype=torch.float32).to(dev).view(-1, 1)
+                _keep_cache[key] = torch.tensor(rates, dtype=torch.float32).to(dev).view(-1, 1)
             keep = _keep_cache[key]
             rs = torch.floor(keep + torch.rand(len(idx), N, device=dev)) / keep
             drop_scales = {i: rs[j] for j, i in enumerate(idx)}

@@ -122,7 +122,7 @@ int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift,
  * gX = dwconv^T(dd) [* swish'(a0*X+b0) when a0] [+ residual]; dW += sum dd*act(X); when a0 is given,
  * part[mx_dwconv_bwd_fused_parts()][2][C] = BatchNorm-0 backward partial sums (sum g, sum g*X) of the written gX.
  * dw_scratch[mx_dwconv_bwd_fused_parts()][C*K*K] is workspace (per-workgroup dW rows, summed into dW by a second launch). */
-int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C);
+int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C, int K);
 int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
                         const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
                         const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,

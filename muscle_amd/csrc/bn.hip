@@ -220,6 +220,16 @@ __global__ __launch_bounds__(256) void se_bn1_pool_kernel(const float* G, const 
         acc[3].f += ga.f * sp * x.f; acc[4].f += sp * x.f;        \
       }
     long r = r0 + tr;
+    for (; r + 3 * g.rpp < r1; r += 4 * g.rpp) {   // four rows (eight loads) in flight
+      const float4 x0 = ld4(X + r * g.C + c), g0 = ld4(G + r * g.C + c);
+      const float4 x1 = ld4(X + (r + g.rpp) * g.C + c), g1 = ld4(G + (r + g.rpp) * g.C + c);
+      const float4 x2 = ld4(X + (r + 2 * g.rpp) * g.C + c), g2 = ld4(G + (r + 2 * g.rpp) * g.C + c);
+      const float4 x3 = ld4(X + (r + 3 * g.rpp) * g.C + c), g3 = ld4(G + (r + 3 * g.rpp) * g.C + c);
+      SE1(x, x0, g0) SE1(y, x0, g0) SE1(z, x0, g0) SE1(w, x0, g0)
+      SE1(x, x1, g1) SE1(y, x1, g1) SE1(z, x1, g1) SE1(w, x1, g1)
+      SE1(x, x2, g2) SE1(y, x2, g2) SE1(z, x2, g2) SE1(w, x2, g2)
+      SE1(x, x3, g3) SE1(y, x3, g3) SE1(z, x3, g3) SE1(w, x3, g3)
+    }
     for (; r + g.rpp < r1; r += 2 * g.rpp) {       // two rows (four loads) in flight
       const float4 x0 = ld4(X + r * g.C + c), g0 = ld4(G + r * g.C + c);
       const float4 x1 = ld4(X + (r + g.rpp) * g.C + c), g1 = ld4(G + (r + g.rpp) * g.C + c);

@@ -548,14 +548,15 @@ __global__ __launch_bounds__(256) void dw_parts_reduce_kernel(const float* __res
   unsafeAtomicAdd(dW + i, (s0 + s1) + (s2 + s3));
 }
 
-static void dw_fused_geom(int N, int H, int Wd, int C, int* tiles_x, int* tiles_y, int* tpb, int* groups) {
+static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int* tiles_y, int* tpb, int* groups) {
   *tiles_x = cdiv(Wd, 16); *tiles_y = cdiv(H, 8);
   long ntiles = (long)N * (*tiles_x) * (*tiles_y);
   int chunks = cdiv(C, CB);
-  // workgroups per launch ~ this target (tuning override MX_DW_GROUPS).  Fewer, longer-lived workgroups amortise the
-  // per-workgroup prologue / partial-row epilogue: A/B/A/B on one box 4096 -> 1024: 150.6, 153.7 -> 148.7, 151.6 ms per step;
-  // 8192 / 16384 cost another 1.5 / 3.5 ms.
-  static const long group_target = getenv("MX_DW_GROUPS") ? atol(getenv("MX_DW_GROUPS")) : 1024;
+  // workgroups per launch ~ this target (tuning override MX_DW_GROUPS).  The 5x5 kernel (2 workgroups per CU, heavy
+  // per-workgroup prologue / partial-row epilogue) wants few long-lived workgroups: 11.0 -> 9.8 ms per step at 1024
+  // instead of 4096; the 3x3 kernel (3 per CU) wants the opposite: 6.8 ms at 4096, 8.0 ms at 1024.
+  static const long override_target = getenv("MX_DW_GROUPS") ? atol(getenv("MX_DW_GROUPS")) : 0;
+  const long group_target = override_target > 0 ? override_target : (K == 5 ? 1024 : 4096);
   long g = group_target / chunks;
   if (g < 1) g = 1;
   if (g > ntiles) g = ntiles;
@@ -653,10 +654,10 @@ int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift,
 }
 
 // number of partial rows mx_dwconv_bwd_fused writes (BN0 sums [rows][2][C] and dW scratch [rows][C*K*K])
-int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C) {
-  if (N <= 0 || H <= 0 || Wd <= 0 || C <= 0) return MX_EARG;
+int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C, int K) {
+  if (N <= 0 || H <= 0 || Wd <= 0 || C <= 0 || (K != 3 && K != 5)) return MX_EARG;
   int tx, ty, tpb, groups;
-  dw_fused_geom(N, H, Wd, C, &tx, &ty, &tpb, &groups);
+  dw_fused_geom(N, H, Wd, C, K, &tx, &ty, &tpb, &groups);
   return groups;
 }
 
@@ -676,7 +677,7 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
   a.x = X; a.a0 = a0; a.b0 = b0; a.w = W; a.res = residual; a.gx = gX; a.dwpart = dw_scratch; a.part = a0 ? part : nullptr;
   a.N = N; a.H = H; a.W = Wd; a.C = C; a.pad = pad_lo;
   int groups;
-  dw_fused_geom(N, H, Wd, C, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups);
+  dw_fused_geom(N, H, Wd, C, K, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups);
   dim3 grid(groups, cdiv(C, CB), 1);
   if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);

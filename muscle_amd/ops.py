@@ -167,7 +167,7 @@ def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNStat
     """Stride-1 fused backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> gate; returns (gX, BN0 partial sums or None)."""
     N, H, Wd, C = X.shape
     gX = _f32(N, H, Wd, C, device=X.device)
-    P = lib().mx_dwconv_bwd_fused_parts(N, H, Wd, C)
+    P = lib().mx_dwconv_bwd_fused_parts(N, H, Wd, C, K)
     part = _f32(P, 2, C, device=X.device) if st0 is not None else None
     scratch = _f32(P, C * K * K, device=X.device)
     call("mx_dwconv_bwd_fused", ptr(dA), ptr(D), ptr(gate), ptr(add), ptr(st1.scale), ptr(st1.shift), ptr(c1[0]), ptr(c1[1]),

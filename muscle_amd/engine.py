@@ -8,8 +8,17 @@ Per block, forward (NHWC, M = N*H*W rows in, M' rows out):
     x --pw_fwd--> e_raw (+BN0 stats) --dwconv_fwd[BN0+SiLU on load]--> d_raw (+BN1 stats)
       --pool_sum[BN1+SiLU on load]--> squeeze --se_fwd--> gate
     d_raw --pw_fwd[BN1+SiLU+gate on load]--> p_raw (+BN2 stats) --bn_apply[+drop_connect, +skip]--> out
-Only e_raw, d_raw, p_raw and out ever exist in HBM (the activated tensors never do); they are also
-exactly what backward needs, so nothing else is saved.
+    (project convs wider than MATERIALISE_ABOVE channels read a materialised a = swish(bn1(d_raw))*gate instead: with
+    several N tiles the prologue recompute costs more than the extra pass, measured)
+e_raw, d_raw, p_raw, out (and `a` where materialised) are what exists in HBM; they are also exactly what backward needs.
+
+Per block, backward:
+    g_out --BN2 bwd (reduce, finalise, apply)--> dp --pw_wgrad / pw_dgrad--> dA
+    (dA, d_raw) --se_bn1_pool (one pass: SE gate gradient + BN1 backward sums per sample)--> se_bwd --> add, c1..c3
+    stride 1: dwconv_bwd_fused[BN1 data gradient on the fly; dW, dX, *swish'(bn0), BN0 sums] --> gz
+    stride 2: bn_bwd_apply --> dwconv_bwd_weight, dwconv_bwd_data --> ge --BN0 bwd reduce
+    gz --BN0 finalise + apply--> de --pw_wgrad / pw_dgrad (+skip gradient)--> g_in
+With save=False (no backward will follow) every tensor only backward would read is released as the forward goes.
 """
 from __future__ import annotations
 

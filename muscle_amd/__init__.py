@@ -1,8 +1,10 @@
 """muscle_amd — MI355X-native MCL / MuSCLe training hot path.
 
-Public names mirror the reference's `src/__init__.py:1-6` for the path that is built
-(MuSCLe model in CAM-encoder mode, the MCL loss callables) plus the loop body (`mcl_step`)
-and the fused optimiser.  Importing the package never needs a GPU; running anything does.
+Public names mirror the reference's `src/__init__.py:1-6` for the path that is built: the MuSCLe model (CAM-encoder
+and decoder modes), the MCL loss callables, `edge.FieldLoss`, the loop bodies (`mcl_step`, `muscle_step`) and the fused
+optimiser; `muscle_amd.infer` (CAM generation), `muscle_amd.evaluation` (per-epoch mIoU sweep) and
+`muscle_amd.indexing` (IRN random walk) cover the scripts around the training loop.  Importing the package never needs
+a GPU; running anything does.
 """
 from .MuSCLe import MuSCLe  # noqa: F401
 from .loss_multilabel import (FocalLoss, Log_Sum_Exp_Pairwise_Loss, MultiLabelSoftMarginLoss,  # noqa: F401

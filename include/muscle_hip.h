@@ -31,6 +31,7 @@ extern "C" {
 #endif
 
 int mx_version(void);
+int mx_abi_hash(void);        /* hash of this header the library was built against (muscle_amd/_lib.py checks it) */
 const char* mx_last_error(void);
 
 /* ---- pointwise (1x1) convolutions on fp32 MFMA: model.py:44,63,77,86 ------------------------------ */

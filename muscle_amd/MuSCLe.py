@@ -48,6 +48,29 @@ class _ArenaSink(engine.GradSink):
         self.touched.add(id(p))
         return self.bufs[id(p)]
 
+    def publish(self, touched_only: bool = True):
+        """Make p.grad a view of this arena for every parameter that received a gradient.  A gradient left from an earlier
+        backward (no zero_grad in between) is added INTO the arena first, so that p.grad always aliases the arena the
+        data-parallel average (dist.GradAverager), the clip (edge.clip_grad_norm_) and FusedAdam work on."""
+        for p in self.params:
+            if touched_only and id(p) not in self.touched:
+                continue
+            g = self.bufs[id(p)]
+            if p.grad is not None and p.grad.data_ptr() != g.data_ptr():
+                g.add_(p.grad)
+            p.grad = g
+
+    def check_aliases(self, model):
+        """Raise if some parameter's gradient lives outside this arena (it would silently miss the all-reduce / clip)."""
+        lo = self.arena.data_ptr()
+        hi = lo + 4 * self.arena.numel()
+        for k, p in model.named_parameters():
+            if p.grad is not None and not (lo <= p.grad.data_ptr() < hi):
+                raise MuscleHipError(
+                    f"gradient of {k} is not a view of model.last_grad_sink.arena (a backward of another forward mode "
+                    "left it behind, or it was assigned by hand): call zero_grad() before the backward whose gradients "
+                    "are averaged / clipped")
+
 
 class _Forward(torch.autograd.Function):
     @staticmethod
@@ -213,10 +236,7 @@ class MuSCLe(nn.Module):
                     tap_grads[i] = g
             # backbone parameters are always touched once a gradient reaches the chain
             engine.backbone_backward(self.backbone, cfg, tape, tap_grads, sink)
-        for p in sink.params:
-            if id(p) in sink.touched:
-                g = sink.bufs[id(p)]
-                p.grad = g if p.grad is None else p.grad + g
+        sink.publish()
         self.last_grad_sink = sink
 
     def _run_forward(self, x, mode, drop_u):
@@ -352,10 +372,7 @@ class MuSCLe(nn.Module):
             ops.bcast_add(g_p7, g_e, 1.0 / hw, hw)                                          # GAP backward
         if g_p7 is not None:
             engine.backbone_backward(self.backbone, cfg, tape, {cfg.taps[6]: g_p7.view(N, h, w, C7)}, sink)
-        for p in sink.params:
-            g = sink.bufs[id(p)]
-            if p.grad is None:
-                p.grad = g
-            else:
-                p.grad = p.grad + g
+        # only parameters a kernel wrote a gradient for get one (a head whose output was unused keeps grad None, as under
+        # autograd: torch.optim.Adam / FusedAdam skip it, no weight decay, no step count)
+        sink.publish()
         self.last_grad_sink = sink

@@ -13,6 +13,16 @@ ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-munsafe-fp-atomics", "-Wno-unused-value"]
 
 
+HEADER = os.path.join(os.path.dirname(HERE), "include", "muscle_hip.h")
+
+
+def abi_hash(path: str = HEADER) -> int:
+    """31-bit hash of the public header's text; compiled into the library (mx_abi_hash) and re-derived by _lib.lib()."""
+    import hashlib
+    with open(path, "rb") as f:
+        return int.from_bytes(hashlib.sha256(f.read()).digest()[:4], "little") & 0x7FFFFFFF
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp")))
 
@@ -29,6 +39,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
+    flags = FLAGS + [f"-DMX_ABI_HASH={abi_hash()}"]
+    # the flag list (incl. the header hash) is a staleness input: a changed flag or ABI rebuilds everything
+    stamp = os.path.join(objdir, "flags.txt")
+    if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):
+        force = True
     jobs = []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
@@ -37,7 +52,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def cc(job):
         src, obj = job
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", src, "-o", obj]
+        cmd = [hipcc, *flags, "-x", "hip", "-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stderr}")
@@ -54,6 +69,8 @@ def build(force: bool = False, verbose: bool = True) -> str:
             raise RuntimeError(f"link failed:\n{r.stderr}")
         if verbose:
             print(f"[muscle_amd] linked {LIB}", file=sys.stderr)
+    with open(stamp, "w") as f:
+        f.write(" ".join(flags))
     return LIB
 
 

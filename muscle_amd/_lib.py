@@ -57,6 +57,16 @@ def lib() -> ctypes.CDLL:
         L = ctypes.CDLL(LIB_PATH)
         L.mx_last_error.restype = ctypes.c_char_p
         L.mx_version.restype = ctypes.c_int
+        from ._build import abi_hash
+        try:
+            L.mx_abi_hash.restype = ctypes.c_int
+            built = L.mx_abi_hash()
+        except AttributeError:
+            built = -1
+        if built != abi_hash(HEADER_PATH):
+            raise MuscleHipError(
+                f"{LIB_PATH} was built against a different include/muscle_hip.h (ABI hash {built} != {abi_hash(HEADER_PATH)}): "
+                "rebuild it with `python -m muscle_amd._build` (or __graft_entry__.build())")
         for name, codes in parse_header().items():
             fn = getattr(L, name)
             fn.restype = ctypes.c_int

@@ -34,7 +34,15 @@ struct GemmArgs {
   int ksplit;               // TN: rows of R per z-slice
   int xcd_nt;               // > 0: 1-D grid, the xcd_nt N tiles of an M tile run back to back on one XCD (see kernel)
   int mt, zt;               // M tiles, reduction slices (for the 1-D grids)
+  unsigned long long* stamps;   // diagnostic builds only (tools/hip/gemm_lab.hip); null in the library
 };
+
+// Diagnostic hook: tools/hip/gemm_lab.hip compiles this file with MX_GEMM_STAMP defined to record s_memtime stamps per
+// workgroup (prologue / main loop / epilogue shares, in-kernel clock).  In the library build it expands to nothing.
+#ifndef MX_GEMM_STAMP
+#define MX_GEMM_STAMP(g, slot)
+#endif
+static unsigned long long* mx_gemm_stamps = nullptr;
 
 enum { L_NT = 0, L_NN = 1, L_TN = 2 };
 
@@ -176,6 +184,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
     else sb.load(g.b, B, g.ldb, n0, g.N, k0, kend, tid);
   };
 
+  MX_GEMM_STAMP(g, 0);
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk > 0) {
     load(kbeg);
@@ -184,6 +193,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
     if (nk > 1) load(kbeg + BK);
   }
   __syncthreads();
+  MX_GEMM_STAMP(g, 1);
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     // The register slab holds K tile kt+1, requested a whole iteration ago.  It goes to the other LDS buffer right after
@@ -229,6 +239,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
   }
 
   // ---- epilogue ------------------------------------------------------------------
+  MX_GEMM_STAMP(g, 2);
   float csum[TN], csq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) csum[j] = csq[j] = 0.f;
@@ -283,6 +294,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
       if (n0 + col < g.N) prow[which * g.N + n0 + col] = v;
     }
   }
+  MX_GEMM_STAMP(g, 3);
 }
 
 // ---------------------------------------------------------------------------
@@ -406,6 +418,7 @@ static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
   MX_CHECK_ARG(g.M > 0 && g.N > 0 && g.K > 0, "gemm: bad extents M=%d N=%d K=%d", g.M, g.N, g.K);
   MX_CHECK_ARG(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: leading dims must be multiples of 4 (lda=%d ldb=%d)", g.lda, g.ldb);
   MX_CHECK_ARG(batch >= 1, "gemm: batch must be >= 1");
+  g.stamps = mx_gemm_stamps;
   if (layout == L_NT) {
     MX_CHECK_ARG(g.K % 4 == 0, "gemm NT: K=%d must be a multiple of 4", g.K);
     dispatch<L_NT>(g, batch, st);

@@ -23,6 +23,9 @@ class GradAverager:
     def __call__(self, model, phase: int):
         if self.world == 1:
             return
+        check = getattr(model.last_grad_sink, "check_aliases", None)
+        if check is not None:
+            check(model)                 # a gradient outside the arena would silently miss the average
         arena = model.last_grad_sink.arena
         if dist.get_backend(self.group) == "nccl":
             dist.all_reduce(arena, op=dist.ReduceOp.AVG, group=self.group)         # RCCL over xGMI

@@ -159,6 +159,9 @@ def cross_entropy_argmax(seg_map, soft_mask):
 def clip_grad_norm_(model, max_norm: float):
     """torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) on the model's flat gradient arena
     (train_muscle.py:202).  Returns the total norm as a 0-dim device tensor (no host synchronisation)."""
+    check = getattr(model.last_grad_sink, "check_aliases", None)
+    if check is not None:
+        check(model)                     # a gradient outside the arena would silently escape the clip
     arena = model.last_grad_sink.arena
     sq = torch.empty(1, dtype=torch.float64, device=arena.device)
     norm = torch.empty(1, dtype=torch.float32, device=arena.device)

@@ -39,6 +39,63 @@ class FusedAdam(torch.optim.Optimizer):
         group["_steps"] = [0] * len(ps)
         group["_dev"] = dev
 
+    # ---- checkpointing: torch.optim.Adam's layout (state[idx] = {step, exp_avg, exp_avg_sq}), never the arenas ------
+    _PRIVATE = ("_arena", "_offs", "_sizes", "_m", "_v", "_steps", "_dev")
+
+    def state_dict(self):
+        """{'state': {param index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} - the same shape
+        torch.optim.Adam produces, so a resumed run keeps its moments, step counts and bias correction.  The flat
+        arenas (a full copy of the parameters) are not serialised."""
+        state, groups, base = {}, [], 0
+        for group in self.param_groups:
+            n = len(group["params"])
+            if group.get("_arena") is not None:
+                for i, p in enumerate(group["params"]):
+                    if group["_steps"][i] == 0:
+                        continue
+                    o, k = group["_offs"][i], p.numel()
+                    state[base + i] = {"step": int(group["_steps"][i]),
+                                       "exp_avg": group["_m"][o:o + k].view(p.shape).clone(),
+                                       "exp_avg_sq": group["_v"][o:o + k].view(p.shape).clone()}
+            g = {k: v for k, v in group.items() if k != "params" and k not in self._PRIVATE}
+            g["params"] = list(range(base, base + n))
+            groups.append(g)
+            base += n
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        groups = sd["param_groups"]
+        if len(groups) != len(self.param_groups):
+            raise ValueError("loaded state dict has a different number of parameter groups")
+        base = 0
+        self._pending = {}
+        for group, saved in zip(self.param_groups, groups):
+            if len(saved["params"]) != len(group["params"]):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            for k, v in saved.items():
+                if k != "params" and k not in self._PRIVATE:
+                    group[k] = v
+            for k in self._PRIVATE:
+                group.pop(k, None)                      # re-flatten on the next step, then apply the pending moments
+            for i in range(len(group["params"])):
+                st = sd["state"].get(base + i, sd["state"].get(str(base + i)))
+                if st is not None:
+                    self._pending[(id(group), i)] = st
+            base += len(group["params"])
+
+    def _apply_pending(self, group):
+        pend = getattr(self, "_pending", None)
+        if not pend:
+            return
+        for i, p in enumerate(group["params"]):
+            st = pend.pop((id(group), i), None)
+            if st is None:
+                continue
+            o, k = group["_offs"][i], p.numel()
+            group["_m"][o:o + k].copy_(torch.as_tensor(st["exp_avg"]).reshape(-1).to(group["_m"].device, torch.float32))
+            group["_v"][o:o + k].copy_(torch.as_tensor(st["exp_avg_sq"]).reshape(-1).to(group["_v"].device, torch.float32))
+            group["_steps"][i] = int(st["step"])
+
     def _is_flat(self, group):
         a = group.get("_arena")
         if a is None or group["params"][0].device != group["_dev"]:
@@ -55,6 +112,7 @@ class FusedAdam(torch.optim.Optimizer):
                 raise RuntimeError("FusedAdam runs on the HIP kernel only: move the model to the GPU first")
             if not self._is_flat(group):
                 self._flatten(group)
+                self._apply_pending(group)
             b1, b2 = group["betas"]
             ps, offs, sizes, steps = group["params"], group["_offs"], group["_sizes"], group["_steps"]
             arena, m, v = group["_arena"], group["_m"], group["_v"]

@@ -171,7 +171,7 @@ class RecordingAdam:
         self.records.append((g, d))
 
 
-def gen_step(src, tree, name, n, size, view, ep, seed, fname, torch_seed=11, lr=1e-4):
+def gen_step(src, tree, name, n, size, view, ep, seed, fname, torch_seed=11, lr=1e-4, cam_stride=4):
     cfg = net_cfg(name, False)
     sd = synth.synth_state_dict(cfg, seed)
     batch = synth.synth_batch(n, size, view, seed)
@@ -231,8 +231,9 @@ def gen_step(src, tree, name, n, size, view, ep, seed, fname, torch_seed=11, lr=
                                     ("loss_imc", "loss_pixpro", "loss_emd")]),
         "emb": ns["emb"].detach().numpy(),
         "logits": ns["logits"].detach().numpy(),
-        "raw_cams_s4": ns["raw_cams"].detach().numpy()[:, :, ::4, ::4].copy(),
-        "raw_sgcs_s4": ns["raw_sgcs"].detach().numpy()[:, :, ::4, ::4].copy(),
+        "cam_stride": np.array(cam_stride, dtype=np.int64),
+        "raw_cams_s4": ns["raw_cams"].detach().numpy()[:, :, ::cam_stride, ::cam_stride].copy(),
+        "raw_sgcs_s4": ns["raw_sgcs"].detach().numpy()[:, :, ::cam_stride, ::cam_stride].copy(),
         "raw_cams_stats": np.array([float(ns["raw_cams"].double().sum()), float(ns["raw_cams"].double().pow(2).sum())]),
         "raw_sgcs_stats": np.array([float(ns["raw_sgcs"].double().sum()), float(ns["raw_sgcs"].double().pow(2).sum())]),
         "param_keys": np.array([k for k, _ in model.named_parameters()]),
@@ -242,8 +243,8 @@ def gen_step(src, tree, name, n, size, view, ep, seed, fname, torch_seed=11, lr=
         out[f"grad{i + 1}"] = g
         out[f"delta{i + 1}"] = d
     if ep >= 8:
-        out["sgcs_vw1_s4"] = ns["sgcs_vw1"].detach().numpy()[:, :, ::4, ::4].copy()
-        out["cams_vw2_s4"] = ns["cams_vw2"].detach().numpy()[:, :, ::4, ::4].copy()
+        out["sgcs_vw1_s4"] = ns["sgcs_vw1"].detach().numpy()[:, :, ::cam_stride, ::cam_stride].copy()
+        out["cams_vw2_s4"] = ns["cams_vw2"].detach().numpy()[:, :, ::cam_stride, ::cam_stride].copy()
     np.savez_compressed(os.path.join(OUT, fname), **out)
     print(fname, "losses", out["losses"], "steps", len(rec.records), "crop draws", len(geom_log))
 
@@ -614,6 +615,39 @@ def main_config4(src):
     gen_muscle_step(src, "efficientnet-b3", 2, 128, 23, "muscle_step_b3_beacon.npz", lamb=0.05, k=8, step=3)
 
 
+def gen_forward_eval(src, name, n, H, W, seed, fname, stride=16):
+    """config 5 (infer_mcl.py:107-125): eval-mode forwards of a BN-calibrated model at a non-square, odd size.
+    'cam' (what infer_mcl.py calls), 'pix', 'logits'."""
+    cfg = net_cfg(name, False)
+    sd = synth.synth_state_dict(cfg, seed)
+    model = build_model(src, name, sd)
+    x = torch.from_numpy(synth.normal(seed, "fwd.x", (n, 3, H, W)).astype(np.float32))
+    calibrate_bn(model, x)
+    model.eval()
+    with torch.no_grad():
+        cams, sgc, emb, logits = model(x, cam="cam")
+        cams_p, sgc_p = model(x, cam="pix")
+        emb_l, logits_l = model(x, cam="logits")
+    assert torch.equal(cams, cams_p) and torch.equal(emb, emb_l)
+
+    def st(t):
+        return np.array([float(t.double().sum()), float(t.double().pow(2).sum()), float(t.abs().max())])
+    out = {"meta": np.array([n, H, W, seed, stride], dtype=np.int64), "name": np.array(name),
+           "cams_s": cams.numpy()[:, :, ::stride, ::stride].copy(), "sgc_s": sgc.numpy()[:, :, ::stride, ::stride].copy(),
+           "cams_stats": st(cams), "sgc_stats": st(sgc), "emb": emb.numpy(), "logits": logits.numpy(),
+           "bn_calibrated": bn_summary(model)}
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, "cams max", float(cams.max()), "sgc max", float(sgc.max()), "emb", tuple(emb.shape))
+
+
+def main_fullsize(src, tree):
+    """Reference-pinned fixtures at the headline size (B7 / 448x448 scalars + summaries)."""
+    gen_step(src, tree, "efficientnet-b7", 4, 448, 224, 4, 31, "step_b7_448_ep4.npz", cam_stride=16)
+    gen_step(src, tree, "efficientnet-b7", 4, 448, 224, 12, 31, "step_b7_448_ep12_lr0.npz", lr=0.0, cam_stride=16)
+    gen_forward_eval(src, "efficientnet-b7", 2, 563, 750, 32, "forward_b7_eval_563x750.npz")   # 375x500 x 1.5
+    gen_forward_eval(src, "efficientnet-b7", 2, 448, 448, 33, "forward_b7_eval_448.npz")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -637,7 +671,12 @@ def main():
     main_config4(src)
     gen_irn_units(src)
     gen_eval_units(src)
+    main_fullsize(src, tree)
 
 
 if __name__ == "__main__":
-    main()
+    if "--fullsize" in sys.argv:
+        torch.set_num_threads(8)
+        main_fullsize(load_reference(), train_script_ast())
+    else:
+        main()

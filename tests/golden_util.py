@@ -14,6 +14,11 @@ def load(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 
 
+def cam_stride(G):
+    """Spatial stride of the stored CAM / SGC samples (4 in the small fixtures, 16 at 448x448)."""
+    return int(G["cam_stride"]) if "cam_stride" in G.files else 4
+
+
 def tensor_summary(named, seed=123):
     """[l2, probe-dot] per tensor, same convention as oracle/gen_golden.py."""
     rows = []

@@ -16,6 +16,13 @@ from muscle_amd import _lib, arch, synth
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_library_exports_every_declared_symbol():
     sigs = _lib.parse_header()
     assert len(sigs) >= 40
@@ -31,6 +38,52 @@ def test_library_exports_every_declared_symbol():
     LL = _lib.lib()
     rc = LL.mx_colstats(None, 0, 0, None, None)
     assert rc < 0 and b"colstats" in LL.mx_last_error()
+
+
+def test_abi_hash_guards_against_a_stale_library(monkeypatch):
+    """The library carries the hash of the header it was built from; _lib.lib() refuses a library built from another one
+    (ctypes signatures come from the header on disk, so a stale .so would be called with a shifted argument layout)."""
+    from muscle_amd import _build
+    L = _lib.lib()
+    assert L.mx_abi_hash() == _build.abi_hash() != 0
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_build, "abi_hash", lambda path=None: 12345)
+    with pytest.raises(_lib.MuscleHipError, match="rebuild"):
+        _lib.lib()
+
+
+def test_fused_adam_state_dict_round_trip():
+    """Checkpointing keeps the moments and step counts (torch.optim.Adam layout), not the arenas."""
+    import muscle_amd
+    ps = [torch.nn.Parameter(torch.randn(5, 3)), torch.nn.Parameter(torch.randn(7)), torch.nn.Parameter(torch.randn(2, 2))]
+    opt = muscle_amd.FusedAdam(ps, lr=1e-3, weight_decay=5e-5)
+    g = opt.param_groups[0]
+    opt._flatten(g)                                          # the arena bookkeeping itself is device independent
+    g["_m"].copy_(torch.arange(g["_m"].numel(), dtype=torch.float32))
+    g["_v"].copy_(torch.arange(g["_v"].numel(), dtype=torch.float32) * 2)
+    g["_steps"][:] = [3, 0, 5]
+    sd = opt.state_dict()
+    assert sorted(sd["state"]) == [0, 2] and sd["state"][2]["step"] == 5
+    assert not any(k.startswith("_") for k in sd["param_groups"][0]) and sd["param_groups"][0]["params"] == [0, 1, 2]
+    assert sd["state"][0]["exp_avg"].shape == (5, 3)
+    import io
+    buf = io.BytesIO()
+    torch.save(sd, buf)
+    buf.seek(0)
+    sd2 = torch.load(buf)
+    ps2 = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt2 = muscle_amd.FusedAdam(ps2, lr=1.0)
+    opt2.load_state_dict(sd2)
+    g2 = opt2.param_groups[0]
+    assert g2["lr"] == 1e-3 and g2["weight_decay"] == 5e-5
+    opt2._flatten(g2)
+    opt2._apply_pending(g2)
+    assert g2["_steps"] == [3, 0, 5]
+    o0, o2 = g2["_offs"][0], g2["_offs"][2]
+    assert torch.equal(g2["_m"][o0:o0 + 15], g["_m"][g["_offs"][0]:g["_offs"][0] + 15])
+    assert torch.equal(g2["_v"][o2:o2 + 4], g["_v"][g["_offs"][2]:g["_offs"][2] + 4])
+    o1 = g2["_offs"][1]
+    assert float(g2["_m"][o1:o1 + 7].abs().sum()) == 0.0     # the parameter that never stepped has no state
 
 
 def test_header_cites_reference_lines():
@@ -149,7 +202,7 @@ dist.destroy_process_group(); print("ok", r)
 def test_dp_hook_two_ranks_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_DP_WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", WORLD_SIZE="2")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
     procs = [subprocess.Popen([sys.executable, str(script), ROOT], env=dict(env, RANK=str(r)), stdout=subprocess.PIPE,
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=120)[0].decode() for p in procs]

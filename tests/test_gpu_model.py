@@ -55,7 +55,8 @@ def check_grads(model, net32, net64, keys_live, tol=2e-3):
 
 @pytest.mark.parametrize("name,n,size,mode,training", [
     ("efficientnet-b0", 3, 64, "cam", True), ("efficientnet-b0", 2, 96, "pix", False),
-    ("efficientnet-b3", 2, 72, "cam", True), ("efficientnet-b7", 2, 64, "cam", True)])
+    ("efficientnet-b3", 2, 72, "cam", True), ("efficientnet-b7", 2, 64, "cam", True),
+    ("efficientnet-b0", 3, 64, "logits", True)])
 def test_model_forward_backward(name, n, size, mode, training):
     from oracle import mcl_oracle as O
     seed = 23
@@ -172,7 +173,7 @@ def test_adam_golden():
 
 
 # ---- the loop body against the reference's own step outputs ---------------------------------------------
-PHASE1 = ["step_b0_ep0.npz", "step_b0_ep4.npz", "step_b0_ep4_imc0.npz", "step_b7_ep4.npz"]
+PHASE1 = ["step_b0_ep0.npz", "step_b0_ep4.npz", "step_b0_ep4_imc0.npz", "step_b7_ep4.npz", "step_b7_448_ep4.npz"]
 
 
 def test_er_lowres_matches_fullres():
@@ -243,3 +244,54 @@ def test_mcl_step_phase1_golden(fname, imc_sync):
     bn = np.array([[float(v.double().sum()), float(model.state_dict()[k.replace("running_mean", "running_var")].double().sum())]
                    for k, v in model.state_dict().items() if k.endswith("running_mean")])
     close(bn, G["bn_after"], 1e-4)
+
+
+def test_gradient_accumulation_keeps_arena_aliasing():
+    """Two backward calls without zero_grad(): p.grad must hold the sum AND stay a view of model.last_grad_sink.arena,
+    because the data-parallel average and the clip act on the arena only; a head whose output is unused keeps grad None
+    (autograd semantics); a gradient left outside the arena makes GradAverager / clip raise instead of silently skipping it."""
+    import muscle_amd
+    from muscle_amd.dist import GradAverager
+    cfg, sd, model = build("efficientnet-b0", 3)
+    n, size = 2, 64
+    x = T(synth.normal(3, "x", (n, 3, size, size)).astype(np.float32)).to(DEV)
+    du = {k: v.to(DEV) for k, v in gu.drop_draws(cfg, n, 5).items()}
+    model.train()
+
+    def one_backward(mode="cam"):
+        outs = model(x, cam=mode, drop_u=du)
+        sum((o * o).sum() for o in outs).backward()
+
+    one_backward()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+    one_backward()                                            # accumulate
+    arena = model.last_grad_sink.arena
+    lo, hi = arena.data_ptr(), arena.data_ptr() + 4 * arena.numel()
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            assert k not in g1
+            continue
+        assert lo <= p.grad.data_ptr() < hi, k
+        sc = float(g1[k].abs().max()) + 1e-30
+        # BN batch statistics / atomics reorder sums between two runs: 2x up to fp32 round-off
+        assert float((p.grad - 2 * g1[k]).abs().max()) <= 2e-3 * sc, k
+    model.last_grad_sink.check_aliases(model)
+    # single-output loss: the untouched heads keep grad None, like autograd
+    model.zero_grad(set_to_none=True)
+    cams, sgc, emb, logits = model(x, cam="cam", drop_u=du)
+    (cams * cams).sum().backward()
+    assert model.fc.weight.grad is None and model.fuse.weight.grad is None and model.fuse.bias.grad is None
+    assert model.backbone._conv_stem.weight.grad is not None
+    # a stale gradient from another forward mode sits outside the new arena -> the hook refuses to average
+    model.zero_grad(set_to_none=True)
+    one_backward("cam")                                       # fc.weight gets a gradient here ...
+    keep = model.fc.weight.grad
+    for k, p in model.named_parameters():
+        if p is not model.fc.weight:
+            p.grad = None
+    one_backward("pix")                                       # ... but not here: it stays in the old arena
+    assert model.fc.weight.grad is keep
+    h = GradAverager()
+    h.world = 2
+    with pytest.raises(muscle_amd._lib.MuscleHipError, match="zero_grad"):
+        h(model, 1)

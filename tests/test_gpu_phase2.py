@@ -66,7 +66,8 @@ def test_dynamic_crops_and_emd_golden():
     close(l, U["emd"], 1e-4); close(x1.grad, U["emd_dx1"], 2e-3)
 
 
-PHASE2 = [("step_b0_ep12_lr0.npz", 1e-4), ("step_b3_ep12_lr0.npz", 1e-4), ("step_b0_ep12.npz", 5e-3), ("step_b3_ep12.npz", 5e-3)]
+PHASE2 = [("step_b0_ep12_lr0.npz", 1e-4), ("step_b3_ep12_lr0.npz", 1e-4), ("step_b0_ep12.npz", 5e-3), ("step_b3_ep12.npz", 5e-3),
+          ("step_b7_448_ep12_lr0.npz", 1e-4)]       # the headline size: 448x448 image, 224x224 views
 
 
 @pytest.mark.parametrize("fname,ptol", PHASE2)

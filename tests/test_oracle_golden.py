@@ -168,8 +168,31 @@ def test_forward(fname):
     close(ce[:, :, ::4, ::4], G["cams_eval_s4"], 1e-4); close(se[:, :, ::4, ::4], G["sgc_eval_s4"], 1e-4)
 
 
+@pytest.mark.parametrize("fname", ["forward_b7_eval_448.npz", "forward_b7_eval_563x750.npz"])
+def test_forward_eval_b7(fname):
+    """BASELINE.json configs[4] (infer_mcl.py:107-125): eval-mode 'cam' / 'pix' / 'logits' of a BN-calibrated B7, square
+    and at a non-square odd size (375x500 x 1.5), against the reference's outputs."""
+    G = gu.load(fname)
+    name = str(G["name"]); n, H, W, seed, st = (int(v) for v in G["meta"])
+    net = O.OracleNet(name, synth.synth_state_dict(net_cfg(name, False), seed))
+    x = T(synth.normal(seed, "fwd.x", (n, 3, H, W)).astype(np.float32))
+    _calibrate(net, x)
+    close(_bn_summary(net), G["bn_calibrated"], 2e-5)
+    net.eval()
+    with torch.no_grad():
+        cams, sgc, emb, logits = net.forward(x, "cam")
+        emb_l, logits_l = net.forward(x, "logits")
+    close(cams[:, :, ::st, ::st], G["cams_s"], 1e-4); close(sgc[:, :, ::st, ::st], G["sgc_s"], 1e-4)
+    close([float(cams.double().sum()), float(cams.double().pow(2).sum()), float(cams.abs().max())], G["cams_stats"], 1e-4)
+    close([float(sgc.double().sum()), float(sgc.double().pow(2).sum()), float(sgc.abs().max())], G["sgc_stats"], 1e-4)
+    close(emb, G["emb"], 5e-5); close(logits, G["logits"], 5e-5)
+    close(emb_l, G["emb"], 5e-5); close(logits_l, G["logits"], 5e-5)
+
+
 STEP_FILES = ["step_b0_ep0.npz", "step_b0_ep4.npz", "step_b0_ep4_imc0.npz", "step_b0_ep12.npz",
-              "step_b0_ep12_lr0.npz", "step_b3_ep12.npz", "step_b3_ep12_lr0.npz", "step_b7_ep4.npz"]
+              "step_b0_ep12_lr0.npz", "step_b3_ep12.npz", "step_b3_ep12_lr0.npz", "step_b7_ep4.npz",
+              # the headline size (B7, 448x448 image, 224x224 views): pins the oracle where bench.py times it
+              "step_b7_448_ep4.npz", "step_b7_448_ep12_lr0.npz"]
 
 
 @pytest.mark.parametrize("fname", STEP_FILES)
@@ -195,8 +218,9 @@ def test_step(fname):
     assert np.all(np.abs(got - G["losses"]) <= tol * np.maximum(np.abs(G["losses"]), 1e-3)), (got, G["losses"])
     assert [torch.is_tensor(out[k]) for k in names[4:]] == G["loss_is_tensor"].tolist()
     close(cap["emb"], G["emb"], 2e-5); close(cap["logits"], G["logits"], 2e-5)
-    close(cap["raw_cams"][:, :, ::4, ::4], G["raw_cams_s4"], 2e-5)
-    close(cap["raw_sgcs"][:, :, ::4, ::4], G["raw_sgcs_s4"], 2e-5)
+    cs = gu.cam_stride(G)
+    close(cap["raw_cams"][:, :, ::cs, ::cs], G["raw_cams_s4"], 2e-5)
+    close(cap["raw_sgcs"][:, :, ::cs, ::cs], G["raw_sgcs_s4"], 2e-5)
     keys = [str(k) for k in G["param_keys"]]
     assert keys == [k for k, _ in net.named_parameters()]
     for i, tag in ((1, "grads1"), (2, "grads2")):

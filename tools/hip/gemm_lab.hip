@@ -1,0 +1,147 @@
+// GEMM laboratory (diagnostic build, not part of the library): compiles muscle_amd/csrc/gemm.hip with the stamp hook
+// enabled and times / dissects the pointwise GEMMs on the B7 layer shapes without PyTorch.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics tools/hip/gemm_lab.hip -o gpurun_out/gemm_lab
+//   gemm_lab time            per-shape time / TFLOP/s of fwd, dgrad, wgrad (production dispatch)
+//   gemm_lab stamps M K N    per-workgroup phase shares of the forward GEMM (prologue / main loop / epilogue) and clock
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include <algorithm>
+
+#define MX_GEMM_STAMP(g, slot)                                                                         \
+  do {                                                                                                 \
+    if ((g).stamps && threadIdx.x == 0) {                                                              \
+      const long wg__ = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);    \
+      (g).stamps[wg__ * 8 + (slot)] = __builtin_amdgcn_s_memtime();                                    \
+      if ((slot) == 0) {                                                                               \
+        (g).stamps[wg__ * 8 + 4] = __builtin_amdgcn_s_memrealtime();                                   \
+        (g).stamps[wg__ * 8 + 6] = __builtin_amdgcn_s_getreg((31 << 11) | 4) |                         \
+                                   ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); \
+      }                                                                                                \
+      if ((slot) == 3) (g).stamps[wg__ * 8 + 5] = __builtin_amdgcn_s_memrealtime();                    \
+    }                                                                                                  \
+  } while (0)
+
+#include "../../muscle_amd/csrc/gemm.hip"
+#include "../../muscle_amd/csrc/api.cpp"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_kernel(float* p, long n, unsigned seed, float scale) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    unsigned h = (unsigned)i * 2654435761u ^ seed;
+    h ^= h >> 15; h *= 2246822519u; h ^= h >> 13; h *= 3266489917u; h ^= h >> 16;
+    p[i] = ((int)(h & 0xffffff) - 0x800000) * (scale / 0x800000);
+  }
+}
+static float* dalloc(long n, unsigned seed, float scale) {
+  float* p; CK(hipMalloc(&p, n * sizeof(float)));
+  hipLaunchKernelGGL(fill_kernel, dim3(2048), dim3(256), 0, 0, p, n, seed, scale);
+  return p;
+}
+template <class F> static float time_us(F f, int reps = 7) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  f(); f(); CK(hipDeviceSynchronize());
+  std::vector<float> t;
+  for (int r = 0; r < reps; ++r) {
+    CK(hipEventRecord(e0)); f(); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); t.push_back(ms * 1e3f);
+  }
+  std::sort(t.begin(), t.end());
+  return t[t.size() / 2];
+}
+
+struct Shape { int M, K, N; };
+static const Shape kShapes[] = {{25088, 640, 3840}, {25088, 3840, 640}, {25088, 384, 2304}, {25088, 2304, 384}, {25088, 224, 1344},
+                                {25088, 1344, 224}, {25088, 160, 960}, {25088, 960, 160}, {100352, 80, 480}, {100352, 480, 80},
+                                {401408, 48, 288}, {401408, 288, 48}, {401408, 192, 48}, {1605632, 32, 192}, {1605632, 32, 32}};
+
+static void run_time() {
+  for (const Shape& s : kShapes) {
+    float* A = dalloc((long)s.M * s.K, 1, 1.f); float* W = dalloc((long)s.N * s.K, 2, 0.05f);
+    float* G = dalloc((long)s.M * s.N, 3, 1.f); float* C = dalloc((long)s.M * s.N, 4, 0.f);
+    float* dX = dalloc((long)s.M * s.K, 5, 0.f); float* dW = dalloc((long)s.N * s.K, 6, 0.f);
+    const int parts = mx_pw_fwd_parts(s.M, s.N, s.K);
+    float* st = dalloc((long)parts * 2 * s.N, 7, 0.f);
+    const double fl = 2.0 * s.M * s.K * s.N;
+    float t1 = time_us([&] { mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C, s.M, s.K, s.N, s.K, s.N, nullptr, nullptr, 0, st, nullptr); });
+    float t2 = time_us([&] { mx_pw_dgrad(G, W, dX, s.M, s.N, s.K, s.N, s.K, nullptr, nullptr); });
+    float t3 = time_us([&] { mx_pw_wgrad(G, A, 0, nullptr, nullptr, nullptr, 1, dW, s.M, s.N, s.K, s.N, s.K, nullptr); });
+    printf("  M=%d K=%d N=%d: fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF\n", s.M, s.K, s.N, t1,
+           fl / t1 / 1e6, t2, fl / t2 / 1e6, t3, fl / t3 / 1e6);
+    fflush(stdout);
+    for (float* p : {A, W, G, C, dX, dW, st}) CK(hipFree(p));
+  }
+}
+
+static void run_stamps(int M, int K, int N, int which) {
+  float* A = dalloc((long)M * K, 1, 1.f); float* W = dalloc((long)N * K, 2, 0.05f);
+  float* G = dalloc((long)M * N, 3, 1.f); float* C = dalloc((long)M * N, 4, 0.f);
+  float* dX = dalloc((long)M * K, 5, 0.f); float* dW = dalloc((long)N * K, 6, 0.f);
+  const int parts = mx_pw_fwd_parts(M, N, K);
+  float* st = dalloc((long)parts * 2 * N, 7, 0.f);
+  const long maxwg = 1 << 20;
+  unsigned long long* stamps; CK(hipMalloc(&stamps, maxwg * 8 * sizeof(unsigned long long)));
+  auto call = [&] {
+    if (which == 0) mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C, M, K, N, K, N, nullptr, nullptr, 0, st, nullptr);
+    else if (which == 1) mx_pw_dgrad(G, W, dX, M, N, K, N, K, nullptr, nullptr);
+    else mx_pw_wgrad(G, A, 0, nullptr, nullptr, nullptr, 1, dW, M, N, K, N, K, nullptr);
+  };
+  float t_plain = time_us(call);
+  CK(hipMemset(stamps, 0, maxwg * 8 * sizeof(unsigned long long)));
+  mx_gemm_stamps = stamps;
+  float t_st = time_us(call, 3);
+  CK(hipMemset(stamps, 0, maxwg * 8 * sizeof(unsigned long long)));
+  call();
+  CK(hipDeviceSynchronize());
+  mx_gemm_stamps = nullptr;
+  std::vector<unsigned long long> h(maxwg * 8);
+  CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+  long nwg = 0;
+  double pro = 0, loop = 0, epi = 0, clk = 0;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  std::vector<double> starts, ends;
+  for (long w = 0; w < maxwg; ++w) {
+    const unsigned long long* s = &h[w * 8];
+    if (!s[0] || !s[3]) continue;
+    ++nwg;
+    pro += (double)(s[1] - s[0]); loop += (double)(s[2] - s[1]); epi += (double)(s[3] - s[2]);
+    if (s[5] > s[4]) clk += (double)(s[3] - s[0]) / (double)(s[5] - s[4]) * 100.0;   // MHz (memrealtime = 100 MHz)
+    t0 = std::min(t0, s[4]); t1 = std::max(t1, s[5]);
+    starts.push_back((double)s[4]); ends.push_back((double)s[5]);
+  }
+  const char* nm[] = {"fwd", "dgrad", "wgrad"};
+  printf("%s M=%d K=%d N=%d: %.1f us plain, %.1f us stamped; %ld workgroups stamped\n", nm[which], M, K, N, t_plain, t_st, nwg);
+  if (nwg) {
+    const double tot = pro + loop + epi;
+    printf("  per-workgroup cycles: prologue %.0f (%.1f%%)  main loop %.0f (%.1f%%)  epilogue %.0f (%.1f%%)  total %.0f; in-kernel clock %.0f MHz\n",
+           pro / nwg, 100 * pro / tot, loop / nwg, 100 * loop / tot, epi / nwg, 100 * epi / tot, tot / nwg, clk / nwg);
+    printf("  first start -> last end (realtime): %.1f us\n", (double)(t1 - t0) / 100.0);
+    // concurrency histogram: how many workgroups are alive over time (20 buckets)
+    const int NB = 20;
+    for (int b = 0; b < NB; ++b) {
+      const double t = (double)t0 + ((double)(t1 - t0)) * (b + 0.5) / NB;
+      long alive = 0;
+      for (size_t i = 0; i < starts.size(); ++i) alive += (starts[i] <= t && ends[i] >= t);
+      printf("%s%ld", b ? " " : "  alive: ", alive);
+    }
+    printf("\n");
+    // start-time rounds: sort starts, print deciles in us
+    std::sort(starts.begin(), starts.end());
+    printf("  start deciles (us):");
+    for (int d = 0; d <= 10; ++d) printf(" %.0f", (starts[std::min(starts.size() - 1, starts.size() * d / 10)] - (double)t0) / 100.0);
+    printf("\n");
+  }
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "time")) { run_time(); return 0; }
+  if (argc >= 5 && !strcmp(argv[1], "stamps")) {
+    for (int which = 0; which < 3; ++which) run_stamps(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), which);
+    return 0;
+  }
+  printf("usage: gemm_lab time | stamps M K N\n");
+  return 1;
+}

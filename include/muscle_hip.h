@@ -43,6 +43,9 @@ int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_s
               int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,
               const float* bias, const float* residual, int relu, float* stats, void* stream);
 
+/* dst[cols,rows] = src[rows,cols]^T (conv weights): the data gradient runs as mx_pw_fwd against the transposed weight. */
+int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream);
+
 /* dX[M,N] = G[M,K] * W[K,N] (+residual): data gradient of the 1x1 conv with weight W[K=Cout, N=Cin]. */
 int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, int ldg, int ldx,
                 const float* residual, void* stream);

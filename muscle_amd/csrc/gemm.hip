@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct GemmArgs {
   MxOperand a, b;
@@ -400,6 +401,310 @@ static void dispatch(const GemmArgs& g, int zdim, hipStream_t st) {
   }
 }
 
+// =====================================================================================================================
+// NT GEMM, second generation: C[M,N] = A'[M,K] * W[N,K]^T with ROW-MAJOR LDS images and 16-byte operand reads.
+//
+// Both operands of the forward GEMM have K contiguous, so a [rows][16] slab is a plain copy: one 16-byte global load and
+// ONE ds_write_b128 per 4 values (the k-major image above needs four scalar ds_write_b32 for them), and the MFMA operand
+// fetch is ONE ds_read_b128 per 16-row tile and K step: lane (l15, q) takes k = 4q..4q+3 of its row and feeds them to four
+// consecutive v_mfma_f32_16x16x4_f32 (the hardware sums over the four lane groups; which actual k a group carries is
+// free as long as A and B agree).  Row stride 20 floats: conflict-free for the 16 rows a b128 read group touches.
+// Measured on the bare loop (tools/hip/mfma_loops.hip, 3 workgroups per CU): 149-152 TFLOP/s against 147 for the
+// k-major / ds_read_b32 loop.  The 16x16 MFMA also gives 16-column granularity: N = 48 / 80 / 160 / 224 need no padded
+// columns (a 32-wide tile computes 33 % / 20 % / 0 / 14 % zeros there).
+// The operand prologue (BN affine + SiLU + SE gate) is applied when the slab moves from registers to LDS, one K step
+// after its load was issued: the raw load no longer has to be waited for in the same step.
+// The data gradient runs through the same kernel against the transposed weight (mx_transpose).
+// Built and measured, not kept (gpurun_out/r2_lab3..8): (i) a persistent stream-K schedule of the 128x128 tile (partial
+// tiles handed between workgroups through slabs + agent-scope flags; perfectly balanced, deterministic): 3-8 % SLOWER
+// than the plain grid on every MFMA-bound layer (K = 384 -> N = 2304: 429-436 vs 403 us) although in-kernel stamps show
+// the plain grid's rounds in lockstep - under this load the chip runs at ~2.0 GHz, and what the schedule gains in
+// matrix-pipe occupancy it gives back in clock; (ii) persistent short-K workgroups (whole K in one slab, next tile
+// prefetched into registers during MFMA + store): 173 registers, 2 workgroups per CU, 205 vs 163 us on K = 48 -> N = 288.
+// More resident workgroups of the simple structure beat software pipelining inside one workgroup here.
+
+// ---- epilogue of the NT kernel: accumulator (lane = column 16j + l15, registers = rows 4q + r) -> bias / residual
+// / relu / statistics in that layout, then through a per-wave LDS patch to 16-byte row stores.  Every wave must be out of
+// the main loop (operand images are overwritten).  `smem` needs 4*16*(TN*16+4) + WM*2*BN floats.
+template <int WM, int WN, int TM, int TN>
+static __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, float* C, int tile_m, int m0, int n0, f32x4 (&acc)[TM][TN],
+                                                   float* smem, int tid) {
+  constexpr int BN = WN * TN * 16, PS = TN * 16 + 4;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  float* patch = smem + wave * (16 * PS);
+  float* red = smem + 4 * 16 * PS;                           // [WM][2][BN]
+  const bool early = !g.residual || g.stats;                 // residual needed before the statistics: scalar loads here
+  const bool vec = ((g.ldc | g.N) & 3) == 0;
+  float cs[TN], cq[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int rbase = m0 + wm * TM * 16 + 16 * i;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn * TN * 16 + 16 * j + l15;
+      const bool cok = col < g.N;
+      const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = rbase + 4 * q + r;
+        float v = acc[i][j][r] + bias;
+        if (early) {
+          if (g.residual && cok && row < g.M) v += g.residual[(long)row * g.ldc + col];
+          if (g.relu) v = fmaxf(v, 0.f);
+          if (cok && row < g.M) { cs[j] += v; cq[j] += v * v; }
+        }
+        patch[(4 * q + r) * PS + 16 * j + l15] = v;
+      }
+    }
+    // rows of the patch: 16 rows x TN*4 float4
+#pragma unroll
+    for (int t = 0; t < TN; ++t) {
+      const int f = lane + 64 * t;
+      const int rl = f / (4 * TN), c4 = (f - rl * (4 * TN)) * 4;
+      const int row = rbase + rl, colb = n0 + wn * TN * 16 + c4;
+      float4 v4 = ld4(patch + rl * PS + c4);
+      if (row < g.M && colb < g.N) {
+        const long idx = (long)row * g.ldc + colb;
+        float v[4] = {v4.x, v4.y, v4.z, v4.w};
+        const bool full = vec && colb + 3 < g.N;
+        if (!early) {
+          if (full) {
+            const float4 r4 = ld4(g.residual + idx);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (colb + e < g.N) v[e] += g.residual[idx + e];
+          }
+          if (g.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+          }
+        }
+        if (full) {
+          f32x4 o = {v[0], v[1], v[2], v[3]};
+          __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + idx));
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (colb + e < g.N) C[idx + e] = v[e];
+        }
+      }
+    }
+  }
+  if (g.stats) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      float s = cs[j], sq = cq[j];
+      s += __shfl_xor(s, 16, 64); sq += __shfl_xor(sq, 16, 64);
+      s += __shfl_xor(s, 32, 64); sq += __shfl_xor(sq, 32, 64);
+      if (lane < 16) {
+        red[(wm * 2 + 0) * BN + wn * TN * 16 + 16 * j + l15] = s;
+        red[(wm * 2 + 1) * BN + wn * TN * 16 + 16 * j + l15] = sq;
+      }
+    }
+    __syncthreads();
+    float* prow = g.stats + (long)tile_m * 2 * g.N;
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, col = i - which * BN;
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < WM; ++w) v += red[(w * 2 + which) * BN + col];
+      if (n0 + col < g.N) prow[which * g.N + n0 + col] = v;
+    }
+  }
+}
+
+// one 16-byte chunk of an A' slab through the operand prologue
+template <int AMODE>
+static __device__ __forceinline__ float4 nt_prologue(float4 v, float4 sc, float4 sh, float4 gt) {
+  if (AMODE == MX_PLAIN) return v;
+  v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
+  if (AMODE == MX_BNACT) {
+    v.x = swishf_(v.x) * gt.x; v.y = swishf_(v.y) * gt.y; v.z = swishf_(v.z) * gt.z; v.w = swishf_(v.w) * gt.w;
+  }
+  return v;
+}
+
+constexpr int gemm_nt_waves(int acc) { return acc <= 48 ? 4 : acc <= 64 ? 3 : 2; }
+
+// ---- streaming kernel: one tile per workgroup, K in 16-wide slabs, double-buffered -----------------------------------
+template <int WM, int WN, int TM, int TN, int AMODE>
+__global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kernel(GemmArgs g) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16, LS = 20;
+  constexpr int PA = (BM * 4 + 255) / 256, PB = (BN * 4 + 255) / 256;
+  constexpr int SMEM = 2 * (BM + BN) * LS;
+  static_assert(WM * WN == 4, "four waves");
+  static_assert(4 * 16 * (TN * 16 + 4) + WM * 2 * BN <= SMEM, "epilogue staging does not fit the operand buffers");
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wm = wave / WN, wn = wave % WN;
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (g.xcd_nt > 0) {        // N tiles of one M tile back to back on one XCD (see gemm_kernel)
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    tile_n = j % g.xcd_nt;
+    tile_m = (j / g.xcd_nt) * 8 + xcd;
+    if (tile_m >= g.mt) return;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const long zb = blockIdx.z;
+  const float* A = g.a.p + zb * g.sa;
+  const float* B = g.b.p + zb * g.sb;
+  float* C = g.c + zb * g.sc;
+  const int K = g.K;
+
+  // slab movers: thread t owns rows (t + 256 i) / 4, 16-byte column chunk t % 4
+  const int ck = (tid & 3) * 4;
+  float4 ra[PA], rb[PB];
+  float4 gt[AMODE == MX_BNACT ? PA : 1];                    // SE gate of the row's sample, this thread's 4 channels
+  float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;  // BN scale / shift of this thread's 4 channels
+  long ga_off[AMODE == MX_BNACT ? PA : 1];
+  const float* pa[PA];
+  const float* pb[PB];
+  bool oka[PA], okb[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int row = (tid + 256 * i) >> 2;
+    oka[i] = (tid + 256 * i) < BM * 4 && m0 + row < g.M;
+    pa[i] = A + (long)(m0 + row) * g.lda + ck;
+    if (AMODE == MX_BNACT) ga_off[i] = g.a.rowp ? (long)((m0 + row) / g.a.rps) * K + ck : -1;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int row = (tid + 256 * i) >> 2;
+    okb[i] = (tid + 256 * i) < BN * 4 && n0 + row < g.N;
+    pb[i] = B + (long)(n0 + row) * g.ldb + ck;
+  }
+  auto load = [&](int k0) {
+    const bool kin = k0 + ck < K;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      ra[i] = (oka[i] && kin) ? ld4(pa[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AMODE == MX_BNACT) gt[i] = (oka[i] && kin && ga_off[i] >= 0) ? ld4(g.a.rowp + ga_off[i] + k0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+    if (AMODE != MX_PLAIN) {
+      sc4 = kin ? ld4(g.a.c1 + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sh4 = kin ? ld4(g.a.c2 + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) rb[i] = (okb[i] && kin) ? ld4(pb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+  };
+  auto store = [&](float* As, float* Bs, int k0) {
+    const bool kin = k0 + ck < K;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+      if ((tid + 256 * i) < BM * 4) {
+        float4 v = ra[i];
+        if (AMODE != MX_PLAIN && oka[i] && kin) v = nt_prologue<AMODE>(v, sc4, sh4, gt[AMODE == MX_BNACT ? i : 0]);
+        st4(As + ((tid + 256 * i) >> 2) * LS + ck, v);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      if ((tid + 256 * i) < BN * 4) st4(Bs + ((tid + 256 * i) >> 2) * LS + ck, rb[i]);
+  };
+
+  f32x4 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  float* As0 = smem;
+  float* Bs0 = smem + 2 * BM * LS;
+  MX_GEMM_STAMP(g, 0);
+  const int nk = (K + 15) / 16;
+  load(0);
+  store(As0, Bs0, 0);
+  if (nk > 1) load(16);
+  __syncthreads();
+  MX_GEMM_STAMP(g, 1);
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      store(As0 + (cur ^ 1) * BM * LS, Bs0 + (cur ^ 1) * BN * LS, (kt + 1) * 16);
+      if (kt + 2 < nk) load((kt + 2) * 16);
+    }
+    const float* as = As0 + cur * BM * LS + (wm * TM * 16 + l15) * LS + 4 * q;
+    const float* bs = Bs0 + cur * BN * LS + (wn * TN * 16 + l15) * LS + 4 * q;
+    f32x4 av[TM], bv[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const f32x4*>(as + 16 * LS * i);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(bs + 16 * LS * j);
+#pragma unroll
+    for (int st = 0; st < 4; ++st)
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][st], bv[j][st], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+  MX_GEMM_STAMP(g, 2);
+  nt_epilogue<WM, WN, TM, TN>(g, C, tile_m, m0, n0, acc, smem, tid);
+  MX_GEMM_STAMP(g, 3);
+}
+
+// tile table of the second-generation NT kernel: {BM, BN}; every entry has 128 rows
+struct NtCfg { int bm, bn; };
+static const NtCfg kNtCfgs[] = {{128, 128}, {128, 96}, {128, 64}, {128, 48}, {128, 80}, {128, 32}, {128, 160}};
+constexpr int kNumNtCfgs = sizeof(kNtCfgs) / sizeof(kNtCfgs[0]);
+
+template <int WM, int WN, int TM, int TN>
+static void launch_nt(const GemmArgs& g, int batch, hipStream_t st) {
+  constexpr int BM = WM * TM * 16, BN = WN * TN * 16;
+  const int mt = cdiv(g.M, BM), nt = cdiv(g.N, BN);
+  GemmArgs a = g;
+  a.mt = mt;
+  a.xcd_nt = 0;
+  dim3 grid(mt, nt, batch);
+  if (nt >= 2 && nt <= 16 && mt >= 64) { a.xcd_nt = nt; grid = dim3(8 * cdiv(mt, 8) * nt, 1, batch); }
+  switch (g.a.mode) {
+    case MX_PLAIN: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, MX_PLAIN>), grid, dim3(256), 0, st, a); break;
+    case MX_BNACT: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, MX_BNACT>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, MX_AFFINE>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+// Choice among the NT tiles: fewest padded columns first (16-column granularity), then the widest tile whose grid still
+// gives every CU at least ~2 workgroups.
+static int pick_nt_cfg(int M, int N) {
+  if (const char* e = getenv("MX_GEMM_NT_CFG")) {
+    int forced = atoi(e);
+    if (forced >= 0 && forced < kNumNtCfgs) return forced;
+  }
+  int best = 0;
+  double best_score = -1.0;
+  for (int c = 0; c < kNumNtCfgs; ++c) {
+    const NtCfg t = kNtCfgs[c];
+    const long nt = cdiv(N, t.bn), tiles = (long)cdiv(M, t.bm) * nt;
+    const double pad = (double)N / (double)(nt * t.bn);
+    const double per_cu = (double)tiles / 256.0;
+    const double balance = per_cu / (double)(long)(per_cu + 0.999999);
+    double eff = t.bn >= 128 ? 1.0 : t.bn >= 96 ? 0.98 : t.bn >= 64 ? 0.95 : t.bn >= 48 ? 0.92 : 0.88;
+    double score = eff * pad * balance;
+    if (per_cu < 2.0) score *= 0.85;
+    if (score > best_score + 1e-9) { best_score = score; best = c; }
+  }
+  return best;
+}
+
+static void dispatch_nt(const GemmArgs& g, int batch, hipStream_t st) {
+  switch (pick_nt_cfg(g.M, g.N)) {
+    case 0: launch_nt<2, 2, 4, 4>(g, batch, st); break;     // 128 x 128
+    case 1: launch_nt<2, 2, 4, 3>(g, batch, st); break;     // 128 x 96
+    case 2: launch_nt<2, 2, 4, 2>(g, batch, st); break;     // 128 x 64
+    case 3: launch_nt<4, 1, 2, 3>(g, batch, st); break;     // 128 x 48
+    case 4: launch_nt<4, 1, 2, 5>(g, batch, st); break;     // 128 x 80
+    case 5: launch_nt<4, 1, 2, 2>(g, batch, st); break;     // 128 x 32
+    default: launch_nt<2, 2, 4, 5>(g, batch, st); break;    // 128 x 160
+  }
+}
+
 static int check_operand(const MxOperand& o, const char* nm) {
   MX_CHECK_ARG(o.p != nullptr, "gemm: operand %s is null", nm);
   MX_CHECK_ARG(((uintptr_t)o.p & 15) == 0, "gemm: operand %s not 16-byte aligned", nm);
@@ -421,7 +726,9 @@ static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
   g.stamps = mx_gemm_stamps;
   if (layout == L_NT) {
     MX_CHECK_ARG(g.K % 4 == 0, "gemm NT: K=%d must be a multiple of 4", g.K);
-    dispatch<L_NT>(g, batch, st);
+    static const int nt_v2 = getenv("MX_GEMM_NT_V2") ? atoi(getenv("MX_GEMM_NT_V2")) : 1;
+    if (nt_v2 && g.b.mode == MX_PLAIN) dispatch_nt(g, batch, st);
+    else dispatch<L_NT>(g, batch, st);
   } else if (layout == L_NN) {
     MX_CHECK_ARG(g.K % 4 == 0 && g.N % 4 == 0, "gemm NN: K=%d and N=%d must be multiples of 4", g.K, g.N);
     dispatch<L_NN>(g, batch, st);
@@ -447,15 +754,43 @@ static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
   return MX_OK;
 }
 
+// dst[cols][rows] = src[rows][cols]^T (weights only: a few MB at most), 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int cols) {
+  __shared__ float t[32][33];
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int r = by + ty + i, c = bx + tx;
+    if (r < rows && c < cols) t[ty + i][tx] = src[(long)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int c = bx + ty + i, r = by + tx;
+    if (r < rows && c < cols) dst[(long)c * rows + r] = t[tx][ty + i];
+  }
+}
+
 extern "C" {
 
-// C[M,N] = A'[M,K] * W[N,K]^T (+bias) (+residual) (relu); stats[2N] += column sum / sumsq.
-// A' = prologue(A; a_mode, a_scale, a_shift, a_gate, rows_per_sample).
+// dst[cols, rows] = src[rows, cols]^T.  The data gradient of a 1x1 convolution is run as a forward GEMM against the
+// transposed weight (mx_pw_fwd with W^T: both operands K-contiguous, 16-byte LDS traffic, 16-column tiles).
+int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream) {
+  MX_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose: bad arguments");
+  hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
 // number of partial-statistics rows mx_pw_fwd writes for an [M, N] output
 int mx_pw_fwd_parts(int M, int N, int K) {
   if (M <= 0 || N <= 0 || K <= 0) return MX_EARG;
-  return cdiv(M, kCfgs[pick_cfg(L_NT, M, N, K)].bm);
+  return cdiv(M, 128);                  // every forward tile configuration (both kernel generations) has 128 rows
 }
+
+// C[M,N] = A'[M,K] * W[N,K]^T (+bias) (+residual) (relu); stats = partial column sum / sumsq rows.
+// A' = prologue(A; a_mode, a_scale, a_shift, a_gate, rows_per_sample).
 
 int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_shift, const float* a_gate,
               int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,

@@ -42,11 +42,26 @@ def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None
     return (out, stats) if want_stats else out
 
 
+def transpose(W):
+    """[rows, cols] -> contiguous [cols, rows] (weights)."""
+    rows, cols = W.shape
+    out = _f32(cols, rows, device=W.device)
+    call("mx_transpose", ptr(W), ptr(out), rows, cols, stream())
+    return out
+
+
+DGRAD_AS_FORWARD = True      # dX = G W as a forward GEMM against W^T (row-major LDS images, 16-column tiles); False: NN kernel
+
+
 def pw_dgrad(G, W, N_in, *, residual=None, out=None):
     """G: [M, K=Cout]; W: [Cout, Cin] -> dX [M, Cin]."""
     M, K = G.shape
     if out is None:
         out = _f32(M, N_in, device=G.device)
+    if DGRAD_AS_FORWARD and K % 4 == 0:
+        call("mx_pw_fwd", ptr(G), PLAIN, None, None, None, 1, ptr(transpose(W)), ptr(out), M, K, N_in, G.stride(0), N_in,
+             None, ptr(residual), 0, None, stream())
+        return out
     call("mx_pw_dgrad", ptr(G), ptr(W), ptr(out), M, K, N_in, G.stride(0), N_in, ptr(residual), stream())
     return out
 

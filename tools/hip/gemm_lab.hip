@@ -9,6 +9,7 @@
 #include <string.h>
 #include <vector>
 #include <algorithm>
+#include <math.h>
 
 #define MX_GEMM_STAMP(g, slot)                                                                         \
   do {                                                                                                 \
@@ -136,7 +137,45 @@ static void run_stamps(int M, int K, int N, int which) {
   }
 }
 
+// forward GEMM (bias + residual + statistics) against a plain fp64 host reference on sampled rows, and the two kernel
+// generations against each other (MX_GEMM_NT_V2 is read once per process: the second generation is checked by default)
+static int run_check(int M, int K, int N) {
+  float* A = dalloc((long)M * K, 11, 1.f); float* W = dalloc((long)N * K, 12, 0.05f);
+  float* R = dalloc((long)M * N, 13, 1.f); float* bias = dalloc(N, 14, 1.f);
+  float* C1 = dalloc((long)M * N, 4, 0.f);
+  const int parts = mx_pw_fwd_parts(M, N, K);
+  float* st1 = dalloc((long)parts * 2 * N, 7, 0.f);
+  if (mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C1, M, K, N, K, N, bias, R, 0, st1, nullptr)) { printf("fwd failed: %s\n", mx_last_error()); return 1; }
+  CK(hipDeviceSynchronize());
+  std::vector<float> hA((long)M * K), hW((long)N * K), hR((long)M * N), hb(N), h1((long)M * N), s1((long)parts * 2 * N);
+  CK(hipMemcpy(hA.data(), A, hA.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hW.data(), W, hW.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hR.data(), R, hR.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), bias, hb.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(s1.data(), st1, s1.size() * 4, hipMemcpyDeviceToHost));
+  double worst_ref = 0;
+  for (int t = 0; t < 400; ++t) {
+    const long r = t < 8 ? (t < 4 ? t : M - 1 - (t - 4)) : ((long)t * 7919 + 13) % M;
+    for (int c = 0; c < N; c += (t < 8 ? 1 : 37)) {
+      double acc = (double)hb[c] + hR[r * N + c];
+      for (int k = 0; k < K; ++k) acc += (double)hA[r * K + k] * hW[(long)c * K + k];
+      worst_ref = std::max(worst_ref, fabs(acc - h1[r * N + c]));
+    }
+  }
+  // statistics: column sums over all partial rows against sums of the output itself
+  double worst_st = 0, scale_st = 0;
+  for (int c = 0; c < N; c += 5) {
+    double a = 0, a2 = 0, b = 0, b2 = 0;
+    for (int p = 0; p < parts; ++p) { a += s1[((long)p * 2 + 0) * N + c]; a2 += s1[((long)p * 2 + 1) * N + c]; }
+    for (long r = 0; r < M; ++r) { const double v = h1[r * N + c]; b += v; b2 += v * v; }
+    worst_st = std::max(worst_st, std::max(fabs(a - b) / (fabs(b) + 1.0), fabs(a2 - b2) / (fabs(b2) + 1.0)));
+    scale_st = std::max(scale_st, fabs(b2));
+  }
+  printf("check M=%d K=%d N=%d: vs fp64 reference max|d| %.3g, statistics rel err %.3g\n", M, K, N, worst_ref, worst_st);
+  for (float* p : {A, W, R, bias, C1, st1}) CK(hipFree(p));
+  return (worst_ref < 1e-3 && worst_st < 1e-4) ? 0 : 2;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 5 && !strcmp(argv[1], "check")) return run_check(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
   if (argc >= 2 && !strcmp(argv[1], "time")) { run_time(); return 0; }
   if (argc >= 5 && !strcmp(argv[1], "stamps")) {
     for (int which = 0; which < 3; ++which) run_stamps(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), which);

@@ -326,11 +326,20 @@ struct DwFusedArgs {
   int N, H, W, C, pad, tiles_x, tiles_y, tiles_per_block;
 };
 
+#ifndef DW_FUSED_K5_WAVES
+#define DW_FUSED_K5_WAVES 2
+#endif
 template <int K, int TH, int TW, int OX>
-__global__ __launch_bounds__(256, 2) void dw_bwd_fused_kernel(DwFusedArgs a) {
-  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256, CH = (K == 5) ? 8 : 3;
+__global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fused_kernel(DwFusedArgs a) {
+  // Only dd is staged with its halo.  The weight gradient is taken over INPUT pixels,
+  //     dW[ky,kx] = sum_q act(X)[q] * dd[q - (ky,kx) + pad],
+  // so the activated input is needed at the tile's centre pixels only: each thread reads its 2 channels x 8 pixels of X
+  // straight into registers (1.0x instead of the halo's 1.9x, no LDS), reuses the raw values for the swish'(bn0(x))
+  // factor and the BN0 sums of the epilogue, and the dW and dX loops walk the SAME shifted dd rows, so every LDS read
+  // feeds both.  One staged array instead of two: 30 KB instead of 61 KB for 5x5, 4 workgroups per CU instead of 2
+  // (round 1 PMC: the two-array kernel sat at SQ_WAIT_ANY 45-60 %, 1.5-1.9 TB/s).
+  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256, CH = (K == 5) ? 4 : 3;
   static_assert(PER % CH == 0, "staging chunks");
-  __shared__ float4 tx[TOT];     // act(X) with halo
   __shared__ float4 td[TOT];     // dd with halo
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
   __shared__ float red[K * K * CB];
@@ -373,12 +382,23 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_kernel(DwFusedArgs a) {
       int cc = tid % CB;
       cst[7 * CB + tid] = (c0 + cc < a.C) ? (tid < CB ? a.gate : a.add)[(long)n * a.C + c0 + cc] : 0.f;
     }
+    // this thread's centre pixels of X (raw), requested before the staging loop so they land under it
+    const int oy = oy0 + pyl;
+    float2 xr[PX];
+    {
+      const int oyc = min(oy, a.H - 1);
+#pragma unroll
+      for (int o = 0; o < PX; ++o) {
+        const int oxc = min(ox0 + pxl + o, a.W - 1);
+        xr[o] = *reinterpret_cast<const float2*>(a.x + (((long)n * a.H + oyc) * a.W + oxc) * a.C + (cok2 ? cc2 : 0));
+      }
+    }
     __syncthreads();
-    // stage both tiles, CH float4 triples in flight per thread (more would push the kernel under 2 waves/SIMD)
+    // stage dd, CH float4 pairs in flight per thread
 #pragma unroll 1
     for (int k0 = 0; k0 < PER; k0 += CH) {
       asm volatile("" ::: "memory");   // keep the constant reloads inside the loop
-      float4 vx[CH], vg[CH], vd[CH];
+      float4 vg[CH], vd[CH];
       unsigned okm = 0;
       // branch-free: out-of-image / out-of-range elements read a clamped (valid) address and are multiplied by 0
 #pragma unroll
@@ -388,78 +408,63 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_kernel(DwFusedArgs a) {
         okm |= (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cok) ? (1u << k) : 0u;
         iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1);
         const long off = (((long)n * a.H + iy) * a.W + ix) * a.C + (cok ? c : 0);
-        vx[k] = ld4(a.x + off); vg[k] = ld4(a.dA + off); vd[k] = ld4(a.d + off);
+        vg[k] = ld4(a.dA + off); vd[k] = ld4(a.d + off);
       }
       const float4 A1 = ld4(cst + 4 * c4), B1 = ld4(cst + CB + 4 * c4), C1 = ld4(cst + 2 * CB + 4 * c4),
-                   C2 = ld4(cst + 3 * CB + 4 * c4), C3 = ld4(cst + 4 * CB + 4 * c4), A0 = ld4(cst + 5 * CB + 4 * c4),
-                   B0 = ld4(cst + 6 * CB + 4 * c4), G = ld4(cst + 7 * CB + 4 * c4), AD = ld4(cst + 8 * CB + 4 * c4);
+                   C2 = ld4(cst + 3 * CB + 4 * c4), C3 = ld4(cst + 4 * CB + 4 * c4),
+                   G = ld4(cst + 7 * CB + 4 * c4), AD = ld4(cst + 8 * CB + 4 * c4);
 #pragma unroll
       for (int k = 0; k < CH; ++k) {
         const int i = min(tid + 256 * (k0 + k), TOT - 1);   // duplicates of the last element rewrite the same value
-        float4 xv = vx[k], dd;
+        float4 dd;
         const float okf = ((okm >> k) & 1u) ? 1.f : 0.f;
-        if (has_bn0) {
-          xv.x = swishf_(A0.x * xv.x + B0.x); xv.y = swishf_(A0.y * xv.y + B0.y);
-          xv.z = swishf_(A0.z * xv.z + B0.z); xv.w = swishf_(A0.w * xv.w + B0.w);
-        }
-#define DD1(f) dd.f = okf * (C1.f * ((vg[k].f * G.f + AD.f) * swish_gradf_(A1.f * vd[k].f + B1.f)) + C2.f * vd[k].f + C3.f); xv.f *= okf;
+#define DD1(f) dd.f = okf * (C1.f * ((vg[k].f * G.f + AD.f) * swish_gradf_(A1.f * vd[k].f + B1.f)) + C2.f * vd[k].f + C3.f);
         DD1(x) DD1(y) DD1(z) DD1(w)
 #undef DD1
-        tx[i] = xv;
         td[i] = dd;
       }
     }
     __syncthreads();
-    // Compute phases: a thread owns 2 channels x PX=8 consecutive pixels of one tile row.  (4 channels x 4 pixels needs 100
-    // accumulator VGPRs for K=5 and the allocator then spills; 2 x 8 needs 50 and keeps v_pk_fma_f32 over the channel pair.)
-    const float2* tx2 = reinterpret_cast<const float2*>(tx);
+    // Compute: a thread owns 2 channels x PX=8 consecutive pixels of one tile row (4 channels x 4 pixels needs 100
+    // accumulator VGPRs for K=5 and the allocator then spills; 2 x 8 needs 50 and keeps v_pk_fma_f32 over the channel pair).
+    // Row ky of the kernel pairs this pixel row with dd row pyl + K-1-ky of the halo tile, for the weight gradient
+    // (times act(X) of the centre pixel) and for the data gradient (times the flipped weight) alike.  The pixel loop is
+    // a real loop over halves (QX pixels each): fully unrolled, the scheduler hoists every LDS read to the top and the
+    // kernel drops below 4 waves/SIMD or spills.
     const float2* td2 = reinterpret_cast<const float2*>(td);
-    // weight gradient: dd at the thread's output pixels times the shifted activated input.  The pixel loop is a real
-    // loop over halves (QX pixels each): fully unrolled, the scheduler hoists every LDS read of the phase (K rows x
-    // (PX-1+K) float2) to the top and the kernel drops to 1 wave/SIMD or spills.
+    const float2 A0 = *reinterpret_cast<const float2*>(cst + 5 * CB + 2 * c2), B0 = *reinterpret_cast<const float2*>(cst + 6 * CB + 2 * c2);
     constexpr int QX = PX / 2;
-#pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      const int px = pxl + h * QX;
-      float2 g[QX];
-#pragma unroll
-      for (int o = 0; o < QX; ++o) g[o] = td2[((pyl + a.pad) * IW + px + o + a.pad) * C2B + c2];
-#pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        float2 in[QX - 1 + K];
-#pragma unroll
-        for (int j = 0; j < QX - 1 + K; ++j) in[j] = tx2[((pyl + ky) * IW + px + j) * C2B + c2];
-#pragma unroll
-        for (int o = 0; o < QX; ++o) {
-#pragma unroll
-          for (int kx = 0; kx < K; ++kx) {
-            float2 v = in[o + kx];
-            float2& p = part[ky * K + kx];
-            p.x += g[o].x * v.x; p.y += g[o].y * v.y;
-          }
-        }
-      }
-    }
-    // data gradient at the same pixels (as input positions): correlation of dd with the flipped kernel
     float2 acc[PX];
 #pragma unroll 1
     for (int h = 0; h < 2; ++h) {
       const int px = pxl + h * QX;
-      float2 ah[QX];
+      const float* wlh = wl + 2 * c2;            // opaque per half: the 25 weight pairs are loop-invariant and would
+      asm volatile("" : "+v"(wlh));              // otherwise be hoisted out of this loop as 50 live registers
+      float2 xa[QX], ah[QX];
 #pragma unroll
-      for (int o = 0; o < QX; ++o) ah[o] = make_float2(0, 0);
+      for (int o = 0; o < QX; ++o) {
+        const float2 r = h == 0 ? xr[o] : xr[QX + o];
+        const bool in_img = cok2 && oy < a.H && ox0 + px + o < a.W;
+        float2 v = r;
+        if (has_bn0) { v.x = swishf_(A0.x * r.x + B0.x); v.y = swishf_(A0.y * r.y + B0.y); }
+        xa[o] = in_img ? v : make_float2(0.f, 0.f);
+        ah[o] = make_float2(0.f, 0.f);
+      }
 #pragma unroll
       for (int ky = 0; ky < K; ++ky) {
+        __builtin_amdgcn_sched_barrier(0);       // one kernel row's LDS reads at a time (hoisted together they spill)
         float2 in[QX - 1 + K];
 #pragma unroll
         for (int j = 0; j < QX - 1 + K; ++j) in[j] = td2[((pyl + K - 1 - ky) * IW + px + j) * C2B + c2];
 #pragma unroll
         for (int kx = 0; kx < K; ++kx) {
-          float2 w = *reinterpret_cast<const float2*>(wl + (ky * K + kx) * CB + 2 * c2);
+          const float2 w = *reinterpret_cast<const float2*>(wlh + (ky * K + kx) * CB);
+          float2& p = part[ky * K + kx];
 #pragma unroll
           for (int o = 0; o < QX; ++o) {
-            float2 v = in[o + K - 1 - kx];
+            const float2 v = in[o + K - 1 - kx];
             ah[o].x += w.x * v.x; ah[o].y += w.y * v.y;
+            p.x += xa[o].x * v.x; p.y += xa[o].y * v.y;
           }
         }
       }
@@ -471,9 +476,7 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_kernel(DwFusedArgs a) {
         for (int o = 0; o < QX; ++o) acc[QX + o] = ah[o];
       }
     }
-    const int oy = oy0 + pyl;
     if (cok2 && oy < a.H) {
-      const float2 A0 = *reinterpret_cast<const float2*>(cst + 5 * CB + 2 * c2), B0 = *reinterpret_cast<const float2*>(cst + 6 * CB + 2 * c2);
 #pragma unroll
       for (int o = 0; o < PX; ++o) {
         int ox = ox0 + pxl + o;
@@ -481,10 +484,10 @@ __global__ __launch_bounds__(256, 2) void dw_bwd_fused_kernel(DwFusedArgs a) {
           const long off = (((long)n * a.H + oy) * a.W + ox) * a.C + cc2;
           float2 v = acc[o];
           if (has_bn0) {
-            float2 xr = *reinterpret_cast<const float2*>(a.x + off);
-            v.x *= swish_gradf_(A0.x * xr.x + B0.x); v.y *= swish_gradf_(A0.y * xr.y + B0.y);
+            const float2 r = xr[o];
+            v.x *= swish_gradf_(A0.x * r.x + B0.x); v.y *= swish_gradf_(A0.y * r.y + B0.y);
             s0.x += v.x; s0.y += v.y;
-            s1.x += v.x * xr.x; s1.y += v.y * xr.y;
+            s1.x += v.x * r.x; s1.y += v.y * r.y;
           } else if (a.res) {
             float2 r = *reinterpret_cast<const float2*>(a.res + off);
             v.x += r.x; v.y += r.y;

@@ -24,6 +24,10 @@ from muscle_amd import arch, synth  # noqa: E402
 
 GEMM_CALLS = ("mx_pw_fwd", "mx_pw_dgrad", "mx_pw_wgrad")
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+HBM_PEAK_GBPS = 8000.0                # same guide: HBM3E spec; 6290 GB/s is what a float4 copy achieves
+# whole-step ceilings per GPU for B7 / 448x448 step-A: exact-fp32 MFMA and HBM (minimum-materialisation schedule)
+STEP_CEILING_MFMA_IMGS = 600.0
+STEP_CEILING_HBM_IMGS = 974.0
 
 
 def make_batch(n, size, view, seed, dev):
@@ -45,6 +49,7 @@ class GemmTimer:
 
     def __init__(self):
         self.pairs = []
+        self.dw = []          # (event, event, algorithmic bytes) of the fused depthwise backward: the slowest HBM-bound kernel
         self.on = False
 
     def install(self):
@@ -59,6 +64,14 @@ class GemmTimer:
                 inner(name, *a)
                 e1.record()
                 me.pairs.append((e0, e1))
+            elif me.on and name == "mx_dwconv_bwd_fused":
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                inner(name, *a)
+                e1.record()
+                n, h, w, c, k = a[18:23]
+                # algorithmic traffic: read dA, D, X once, write gX once (fp32)
+                me.dw.append((e0, e1, 4.0 * 4 * n * h * w * c, k))
             else:
                 inner(name, *a)
 
@@ -70,6 +83,16 @@ class GemmTimer:
     def total_ms(self):
         return sum(a.elapsed_time(b) for a, b in self.pairs), len(self.pairs)
 
+    def dw_summary(self):
+        """Per kernel size of the fused depthwise backward: launches, ms, GB/s of its algorithmic 4 passes."""
+        out = {}
+        for k in (3, 5):
+            sel = [(a.elapsed_time(b), by) for a, b, by, kk in self.dw if kk == k]
+            if sel:
+                ms = sum(t for t, _ in sel)
+                out[f"k{k}"] = {"launches": len(sel), "ms": ms, "GBps": sum(by for _, by in sel) / (ms * 1e-3) / 1e9}
+        return out
+
 
 def pointwise_flops_per_image(cfg, size):
     m = arch.forward_macs(cfg, size)
@@ -79,11 +102,8 @@ def pointwise_flops_per_image(cfg, size):
     return 6 * m["pointwise"] + 4 * stem
 
 
-def cpu_baseline(model_name, size, view, ep, seconds_budget=25.0):
-    """The oracle (a CPU port of the reference's loop body) on this host's cores; bounded sample."""
+def _cpu_steps(model_name, size, view, ep, n, warm, timed_n, seconds_budget):
     from oracle import mcl_oracle as O
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # the GPU box's CPU share for one GPU
-    n = 2
     cfg = arch.net_cfg(model_name, False)
     torch.manual_seed(0)
     net = O.OracleNet(model_name, synth.synth_state_dict(cfg, 0))
@@ -92,17 +112,28 @@ def cpu_baseline(model_name, size, view, ep, seconds_budget=25.0):
     b["label"][1] = b["label"][0]
     times = []
     t_start = time.time()
-    for i in range(4):
+    for i in range(warm + timed_n):
         t0 = time.time()
         O.mcl_step(net, opt, b, ep)
         times.append(time.time() - t0)
-        if i >= 1 and time.time() - t_start > seconds_budget:
+        if i >= warm and time.time() - t_start > seconds_budget:
             break
-    timed = times[1:] if len(times) > 1 else times
-    sec = sum(timed) / len(timed)
+    timed = times[warm:] if len(times) > warm else times[-1:]
+    return sum(timed) / len(timed), len(timed)
+
+
+def cpu_baseline(model_name, size, view, ep, seconds_budget=25.0):
+    """The oracle (a CPU port of the reference's loop body) on this host's cores; bounded sample: 2 warm-up + up to 5
+    timed steps of the headline model at batch 2, and BASELINE.json configs[0] (EfficientNet-B0, 2 images, 224x224)."""
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # the GPU box's CPU share for one GPU
+    n = 2
+    sec, cnt = _cpu_steps(model_name, size, view, ep, n, 2, 5, seconds_budget)
+    sec0, cnt0 = _cpu_steps("efficientnet-b0", 224, 112, ep, n, 2, 5, 10.0)
     return {"value": n / sec, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{len(timed)} timed steps (1 warm-up) of the same loop body, {model_name} {size}x{size}, batch {n}, "
-                      f"epoch-{ep} semantics, oracle/mcl_oracle.py on torch-CPU fp32, {sec:.2f} s/step"}
+            "sample": f"{cnt} timed steps (2 warm-up) of the same loop body, {model_name} {size}x{size}, batch {n}, "
+                      f"epoch-{ep} semantics, oracle/mcl_oracle.py on torch-CPU fp32, {sec:.2f} s/step",
+            "config1": {"value": n / sec0, "unit": "images/sec",
+                        "sample": f"{cnt0} timed steps (2 warm-up), efficientnet-b0 224x224, batch {n}, {sec0:.3f} s/step"}}
 
 
 def main():
@@ -147,7 +178,7 @@ def main():
     view = a.size // 2
     batch = make_batch(a.batch, a.size, view, 1000 + rank, dev)
     vc = int(batch["label"].sum().item())
-    hook = GradAverager() if world > 1 else None
+    hook = GradAverager().attach(model) if world > 1 else None     # chunks go out as backward fills the arena
     timer = GemmTimer()
     timer.install()
 
@@ -224,7 +255,7 @@ def main():
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
                    "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused"},
         "losses": {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in out.items()},
-        "roofline": {"bound": "mfma", "kernel": "gemm_kernel<*> (fp32 v_mfma_f32_32x32x2_f32 pointwise convs: fwd+dgrad+wgrad, stem)",
+        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> / gemm_kernel<*> (exact-fp32 MFMA pointwise convs: fwd + dgrad on v_mfma_f32_16x16x4_f32, wgrad on 32x32x2; stem)",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
                      "launches_per_step": gemm_launches // max(a.steps, 1),
@@ -232,6 +263,19 @@ def main():
                      "time_share_of_step": gemm_ms * 1e-3 / dt,
                      "algorithmic_gflop_per_image": flops_img / 1e9},
     }
+    if (a.model, a.size, full) == ("efficientnet-b7", 448, False):
+        # whole-step fractions of the two ceilings of SURVEY.md section 8(d) (per GPU), and the slowest HBM-bound kernel
+        per_gpu = imgs / dt / world
+        res["roofline"]["step_frac_mfma"] = per_gpu / STEP_CEILING_MFMA_IMGS
+        res["roofline"]["step_frac_hbm"] = per_gpu / STEP_CEILING_HBM_IMGS
+    dws = timer.dw_summary()
+    if dws:
+        worst = min(dws.items(), key=lambda kv: kv[1]["GBps"])
+        res["roofline"]["hbm_kernel"] = {"kernel": f"dw_bwd_fused_kernel<{worst[0][1:]}> (stride-1 depthwise backward, 3 reads + 1 write)",
+                                         "achieved": worst[1]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                         "frac": worst[1]["GBps"] / HBM_PEAK_GBPS,
+                                         "ms_per_step": worst[1]["ms"] / max(a.steps, 1),
+                                         "all": {k: {"GBps": round(v["GBps"], 1), "ms_per_step": round(v["ms"] / max(a.steps, 1), 3)} for k, v in dws.items()}}
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.size, view, a.epoch)
     print(json.dumps(res))

@@ -39,14 +39,26 @@ class _ArenaSink(engine.GradSink):
         total = sum((p.numel() + 3) // 4 * 4 for p in params)
         self.arena = torch.zeros(total, dtype=torch.float32, device=params[0].device)
         self.params = params
+        self.off = {}
+        self.on_ready = None          # callable(sink, lo): arena[lo:] is complete on the current stream (dist.GradAverager)
         off = 0
         for p in params:
             self.bufs[id(p)] = self.arena[off:off + p.numel()].view(p.shape)
+            self.off[id(p)] = off
             off += (p.numel() + 3) // 4 * 4
 
     def of(self, p):
         self.touched.add(id(p))
         return self.bufs[id(p)]
+
+    def ready_from(self, p):
+        """Everything from parameter p to the end of the arena has been written (parameters are laid out in forward order
+        and backward runs back to front): lets the data-parallel exchange start on that part while backward goes on."""
+        if self.on_ready is not None and id(p) in self.off:
+            self.on_ready(self, self.off[id(p)])
+
+    def block_done(self, block_module):
+        self.ready_from(next(block_module.parameters()))
 
     def publish(self, touched_only: bool = True):
         """Make p.grad a view of this arena for every parameter that received a gradient.  A gradient left from an earlier
@@ -114,6 +126,7 @@ class MuSCLe(nn.Module):
             self.BIFPN = dec.BIFPN(tc, layers, bifpn_channels)
         self.fuse_dec = nn.Conv2d(bifpn_channels, num_classes, 1)
         self.logits = None
+        self.grad_ready_callback = None     # dist.GradAverager.attach(): called as backward completes the arena back to front
         self._anchor = torch.zeros(1, requires_grad=True)      # makes autograd call our backward; not a parameter
         self.last_grad_sink: Optional[_ArenaSink] = None
         if weights is not None:
@@ -206,8 +219,7 @@ class MuSCLe(nn.Module):
         M3 = N * h * w
         dev = p3.device
         sink = _ArenaSink(self.live_parameters(mode))
-        for blk_p in sink.params[:0]:
-            pass
+        sink.on_ready = getattr(self, "grad_ready_callback", None)
         tp.sink = sink
         g_p3 = None
         if g_seg is not None:
@@ -235,6 +247,7 @@ class MuSCLe(nn.Module):
                 if g is not None:
                     tap_grads[i] = g
             # backbone parameters are always touched once a gradient reaches the chain
+            sink.ready_from(next(self.BIFPN.parameters()))                                  # decoder + fuse_dec gradients are in
             engine.backbone_backward(self.backbone, cfg, tape, tap_grads, sink)
         sink.publish()
         self.last_grad_sink = sink
@@ -313,6 +326,7 @@ class MuSCLe(nn.Module):
         hw, M7 = ht.hw, N * ht.hw
         dev = p7.device
         sink = _ArenaSink(self.live_parameters(mode))
+        sink.on_ready = getattr(self, "grad_ready_callback", None)
         if mode == "logits":
             g_cams = g_sgc = None
             g_emb, g_logits = gouts
@@ -371,6 +385,7 @@ class MuSCLe(nn.Module):
                 g_p7 = torch.zeros(M7, C7, dtype=torch.float32, device=dev)
             ops.bcast_add(g_p7, g_e, 1.0 / hw, hw)                                          # GAP backward
         if g_p7 is not None:
+            sink.ready_from(sink.params[-1] if mode == "logits" else self.fuse.weight)      # the head gradients are in
             engine.backbone_backward(self.backbone, cfg, tape, {cfg.taps[6]: g_p7.view(N, h, w, C7)}, sink)
         # only parameters a kernel wrote a gradient for get one (a head whose output was unused keeps grad None, as under
         # autograd: torch.optim.Adam / FusedAdam skip it, no weight decay, no step count)

@@ -3,40 +3,97 @@
 The reference is single-GPU; the semantics fixed in SURVEY.md §8(e) are: replica-local
 BatchNorm statistics, replica-local losses (IMC pairs, ER k, EMD matching), one gradient average per
 optimizer step.  MuSCLe's backward leaves all live gradients in ONE flat fp32 arena
-(`model.last_grad_sink.arena`), so the exchange is a single large all-reduce (248.8 MB for B7) with no
-bucketing logic and no unused-parameter bookkeeping: dead parameters are simply not in the arena.
+(`model.last_grad_sink.arena`, 248.8 MB for B7), laid out in forward order: stem, blocks 0..54, heads.  Backward
+fills it back to front, so the exchange is cut into fixed ~25 MB chunks and a chunk is handed to RCCL as soon as the
+backward of the blocks it covers has been enqueued (`async_op=True`: the collective runs on RCCL's stream behind the
+kernels enqueued so far and overlaps the rest of backward); the hook before the optimizer step launches what is left
+(the first chunk) and makes the compute stream wait for all of them.  No unused-parameter bookkeeping: dead
+parameters are not in the arena.  Chunk boundaries do not depend on timing and every element is reduced exactly once
+with the same operation, so the result is identical to one all-reduce of the whole arena.
 """
 from __future__ import annotations
+
+from typing import List, Optional
 
 import torch
 import torch.distributed as dist
 
+CHUNK_BYTES = 25 * 1024 * 1024
+
 
 class GradAverager:
-    """grad_hook for muscle_amd.mcl_step: averages the flat gradient arena across ranks."""
+    """grad_hook for muscle_amd.mcl_step: averages the flat gradient arena across ranks.
 
-    def __init__(self, group=None):
+    `attach(model)` additionally lets the model's backward report progress (arena[lo:] complete), which starts the
+    chunks early; without it everything is launched from the hook (same result, no overlap)."""
+
+    def __init__(self, group=None, chunk_bytes: int = CHUNK_BYTES):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.bytes_reduced = 0
+        self.chunk = max(1, chunk_bytes // 4)          # elements
+        self._sink = None
+        self._next = -1                                # highest chunk index not launched yet
+        self._works: List = []
+        self.launched_early = 0                        # chunks that went out before the hook (statistics / tests)
 
+    # ---- wiring ---------------------------------------------------------------------------------------------
+    def attach(self, model):
+        model.grad_ready_callback = self.on_ready
+        return self
+
+    def _nccl(self) -> bool:
+        return dist.get_backend(self.group) == "nccl"
+
+    def _begin(self, sink):
+        self._sink = sink
+        n = sink.arena.numel()
+        self._next = (n + self.chunk - 1) // self.chunk - 1
+        self._works = []
+
+    def _launch(self, k: int):
+        arena = self._sink.arena
+        part = arena[k * self.chunk: min((k + 1) * self.chunk, arena.numel())]
+        if self._nccl():
+            # RCCL over xGMI; async: its stream waits for the kernels enqueued so far, the compute stream goes on
+            self._works.append(dist.all_reduce(part, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+        else:
+            # gloo: CPU unit tests, and single-GPU rehearsals of the multi-process flow (no AVG, host staging)
+            buf = part.cpu() if part.is_cuda else part
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
+            buf.div_(self.world)
+            if part.is_cuda:
+                part.copy_(buf)
+        self.bytes_reduced += part.numel() * 4
+
+    # ---- progress from the backward: arena[lo:] is complete on the current stream ---------------------------------
+    def on_ready(self, sink, lo: int):
+        if self.world == 1:
+            return
+        if sink is not self._sink:
+            self._begin(sink)
+        while self._next >= 1 and self._next * self.chunk >= lo:     # chunk 0 always waits for the hook
+            self._launch(self._next)
+            self._next -= 1
+            self.launched_early += 1
+
+    # ---- the hook: after backward, before optimizer.step() ----------------------------------------------------------
     def __call__(self, model, phase: int):
         if self.world == 1:
             return
-        check = getattr(model.last_grad_sink, "check_aliases", None)
+        sink = model.last_grad_sink
+        check = getattr(sink, "check_aliases", None)
         if check is not None:
             check(model)                 # a gradient outside the arena would silently miss the average
-        arena = model.last_grad_sink.arena
-        if dist.get_backend(self.group) == "nccl":
-            dist.all_reduce(arena, op=dist.ReduceOp.AVG, group=self.group)         # RCCL over xGMI
-        else:
-            # gloo: CPU unit tests, and single-GPU rehearsals of the multi-process flow (no AVG, host staging)
-            buf = arena.cpu() if arena.is_cuda else arena
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-            buf.div_(self.world)
-            if arena.is_cuda:
-                arena.copy_(buf)
-        self.bytes_reduced += arena.numel() * 4
+        if sink is not self._sink:
+            self._begin(sink)
+        while self._next >= 0:
+            self._launch(self._next)
+            self._next -= 1
+        for w in self._works:
+            w.wait()                     # the compute stream waits for RCCL's stream; the host does not block
+        self._works = []
+        self._sink = None
 
 
 def broadcast_parameters(model, src: int = 0, group=None):
@@ -51,3 +108,19 @@ def broadcast_parameters(model, src: int = 0, group=None):
             t.data.copy_(buf)
         else:
             dist.broadcast(t.data, src=src, group=group)
+
+
+def sync_buffers_from_rank0(model, group=None):
+    """BatchNorm running statistics stay replica-local during training (no SyncBN); a checkpoint takes
+    rank 0's.  Call this before saving (or before an evaluation that must agree across ranks) to give every rank those
+    statistics, as torch DDP's broadcast_buffers would at each forward."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    gloo = dist.get_backend(group) != "nccl"
+    for t in model.buffers():
+        if gloo and t.is_cuda:
+            buf = t.data.cpu()
+            dist.broadcast(buf, src=0, group=group)
+            t.data.copy_(buf)
+        else:
+            dist.broadcast(t.data, src=0, group=group)

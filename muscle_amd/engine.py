@@ -324,5 +324,8 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
                 g_out = None
         else:
             g_out = gx
+        done = getattr(sink, "block_done", None)
+        if done is not None and not WGRAD_SIDE_STREAM:
+            done(m)                  # this block's (and every later block's) parameter gradients are enqueued
     lane.join()
     return

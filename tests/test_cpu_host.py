@@ -209,6 +209,24 @@ def test_dp_hook_two_ranks_gloo(tmp_path):
     assert all(p.returncode == 0 for p in procs), outs
 
 
+def test_chunked_exchange_equals_single_allreduce(tmp_path):
+    """muscle_amd.dist.GradAverager: the ~25 MB chunks launched as backward reports progress give exactly the arena one
+    all-reduce gives (two gloo ranks, CPU tensors)."""
+    worker = os.path.join(ROOT, "tests", "dp_worker.py")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE="2")
+    outs = [str(tmp_path / f"a{r}.npz") for r in range(2)]
+    procs = [subprocess.Popen([sys.executable, worker, ROOT, "cpu-arena", outs[r]], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(2)]
+    logs = [p.communicate(timeout=120)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    a0, a1 = np.load(outs[0]), np.load(outs[1])
+    want = (np.arange(1003, dtype=np.float32) * 1 + 0.0 + np.arange(1003, dtype=np.float32) * 2 + 0.25) / 2
+    for tag in ("single", "chunked", "chunked_late"):
+        assert np.array_equal(a0[tag], a1[tag]), tag
+        assert np.array_equal(a0[tag], a0["single"]), tag
+    np.testing.assert_allclose(a0["single"], want, rtol=1e-6)
+
+
 def test_infer_oracle_semantics_and_file_format(tmp_path):
     """infer_mcl.py:107-182 restated in the oracle: dict keys = positive labels, float32 [H,W] maps, the min-max rule
     with its 'below min + 1e-6 -> 0' quirk, un-flipping of odd passes, and the .npy dict layout evaluation.py reads."""

@@ -1,0 +1,42 @@
+"""Data-parallel path of mcl_step on real kernels (SURVEY.md section 8(e) validation: N ranks fed identical batches must
+reproduce the 1-GPU update): two fresh child processes share the one GPU and exchange gradients over gloo (the box has
+a single GPU; RCCL needs one device per rank), with the chunked / progress-driven exchange of muscle_amd.dist."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from test_cpu_host import _free_port, ROOT
+
+pytestmark = pytest.mark.gpu
+WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
+
+
+def _run(world, tmp_path, tag):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
+    outs = [str(tmp_path / f"{tag}_{r}.npz") for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, WORKER, ROOT, "step", outs[r]], env=dict(env, RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    logs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), logs
+    return [np.load(o) for o in outs]
+
+
+def test_two_ranks_same_batch_reproduce_single_process_update(tmp_path):
+    (single,) = _run(1, tmp_path, "w1")
+    r0, r1 = _run(2, tmp_path, "w2")
+    assert int(r0["early"]) > 0 and int(r1["early"]) > 0          # chunks went out while backward was still running
+    # both ranks hold the same averaged gradient and took the same update (bit for bit: same reduction, same order)
+    assert np.array_equal(r0["arena"], r1["arena"]) and np.array_equal(r0["params"], r1["params"])
+    np.testing.assert_allclose(r0["losses"], single["losses"], rtol=1e-5)
+    # averaged gradient == the single-process gradient up to the run-to-run noise of the fp32 atomics in backward
+    g, gs = r0["arena"].astype(np.float64), single["arena"].astype(np.float64)
+    scale = np.abs(gs).max()
+    assert np.abs(g - gs).max() <= 2e-3 * scale, np.abs(g - gs).max() / scale
+    cos = float(g @ gs / (np.linalg.norm(g) * np.linalg.norm(gs)))
+    assert cos >= 0.999999, cos
+    # parameters: Adam's first update is lr * sign(g): identical except where a round-off gradient changes sign
+    d = np.abs(r0["params"].astype(np.float64) - single["params"].astype(np.float64))
+    assert d.max() <= 2.05e-4 and (d > 1e-6).mean() < 0.02, (d.max(), (d > 1e-6).mean())

@@ -164,6 +164,12 @@ int mx_infer_accum(const float* src, float* acc, int h, int w, int lds, int K, i
  * v = (v - min - 1e-6) / (max - min + 1e-6) */
 int mx_infer_norm(float* acc, int channels, long HW, void* stream);
 
+/* ---- input stage (src/data.py:215-332, src/imutils.py:143-181,376-388) ------------------------------
+ * dst[n,3,Hd,Wd] (fp32, fully written) = RandomCrop container of color_norm(uint8 HWC crop n) at (top,left), CHW, zeros
+ * elsewhere; src = packed crops, jobs = n x 8 int32 {src_off, sh, sw, top, left, 0,0,0}, both on the device.
+ * Bit-exact with the numpy expressions (fp64 (x/255 - mean)/std, one rounding to fp32). */
+int mx_input_stage(const unsigned char* src, const int* jobs, float* dst, int n, int Hd, int Wd, void* stream);
+
 /* ---- IRN random-walk propagation (src/indexing.py:77-142 as called by infer_irn.py:76).
  * mx_irn_affinity: dense[n4][ld] (zero-filled here) <- symmetric affinity 1 - max(edge along the straight path) for every
  *   pixel pair joined by one of the nd search directions, unit diagonal; edge [h,w]; pcoord = int32 (dy,dx) pairs of all

@@ -640,6 +640,91 @@ def gen_forward_eval(src, name, n, H, W, seed, fname, stride=16):
     print(fname, "cams max", float(cams.max()), "sgc max", float(sgc.max()), "emb", tuple(emb.shape))
 
 
+def synth_photo(seed, h, w):
+    """Deterministic uint8 RGB test image with structure at several scales (smooth gradients + blocks + noise)."""
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    u = synth.uniform(seed, "photo", (h // 16 + 2, w // 16 + 2, 3))
+    blocks = np.kron(u, np.ones((16, 16, 1)))[:h, :w]
+    img = 0.45 * blocks + 0.35 * np.stack([np.sin(xx / 23.0 + c) * np.cos(yy / 17.0 - c) * 0.5 + 0.5 for c in range(3)], -1) \
+        + 0.2 * synth.uniform(seed, "photo.noise", (h, w, 3))
+    return np.clip(img * 255.0, 0, 255).astype(np.uint8)
+
+
+def gen_input_units(src, fname="input_views.npz"):
+    """the reference's own VOC12ImageViews.__getitem__ (src/data.py:306-315) with the train transform of
+    train_mcl.py:104-115 (written out here: that script cannot be imported), on synthetic JPEGs in a temporary VOC tree.
+    torchvision is not installed: its pieces on this path are supplied as what they do for PIL inputs -
+    Compose = call in order; F.hflip = transpose(FLIP_LEFT_RIGHT); F.crop(img,i,j,h,w) = img.crop((j,i,j+w,i+h));
+    F.resize(img,(448,448)) = img.resize((448,448), BILINEAR); ColorJitter and RandomErasing = IDENTITY (not pinned,
+    not reproduced by the build).  Everything else (get_views, get_inter, RandomResizeLong, color_norm, RandomCrop,
+    HWC_to_CHW) is the reference's code, run as is (Image.CUBIC, removed in Pillow 10, is re-aliased to Image.BICUBIC)."""
+    import random
+    import tempfile
+    import zlib
+    import PIL.Image
+    import src.data as ref_data
+    import src.imutils as ref_im
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class Identity:
+        def __init__(self, *a, **k):
+            pass
+
+        def __call__(self, x):
+            return x
+
+    tvt = sys.modules["torchvision.transforms"]
+    tvt.Compose, tvt.ColorJitter, tvt.RandomErasing = Compose, Identity, Identity
+    F_ = sys.modules["torchvision.transforms.functional"]
+    F_.hflip = lambda im: im.transpose(PIL.Image.FLIP_LEFT_RIGHT)
+    F_.crop = lambda im, i, j, h, w: im.crop((j, i, j + w, i + h))
+    F_.resize = lambda im, size: im.resize(size[::-1], PIL.Image.BILINEAR)
+    ref_data.transforms, ref_data.F = tvt, F_
+    if not hasattr(PIL.Image, "CUBIC"):
+        PIL.Image.CUBIC = PIL.Image.BICUBIC       # src/imutils.py:136 uses the alias Pillow 10 removed (same filter, value 3)
+    out = {}
+    sizes = [(375, 500), (500, 333), (300, 400), (480, 640), (460, 449), (448, 448)]
+    with tempfile.TemporaryDirectory() as td:
+        os.makedirs(os.path.join(td, "JPEGImages"))
+        names = []
+        for i, (h, w) in enumerate(sizes):
+            name = f"2007_{i:06d}"
+            PIL.Image.fromarray(synth_photo(40 + i, h, w)).save(os.path.join(td, "JPEGImages", name + ".jpg"), quality=92)
+            names.append(name)
+        lst = os.path.join(td, "list.txt")
+        open(lst, "w").write("\n".join(names) + "\n")
+        ds = ref_data.VOC12ImageViews(lst, td, transform=Compose([
+            ref_im.RandomResizeLong(448, 768), Identity(), np.asarray, ref_im.color_norm, ref_im.RandomCrop(448),
+            ref_im.HWC_to_CHW, torch.from_numpy, Identity()]), output_size=(224, 224))
+        torch.manual_seed(1234)
+        random.seed(4321)
+        for i, name in enumerate(names):
+            jpg = open(os.path.join(td, "JPEGImages", name + ".jpg"), "rb").read()
+            nm, img, v1, v2, c1, c2, oc = ds[i]
+            img, v1, v2 = img.numpy(), v1.numpy(), v2.numpy()
+            assert img.dtype == np.float32 and v1.dtype == np.float64
+            out[f"jpg{i}"] = np.frombuffer(jpg, dtype=np.uint8)
+            out[f"coords{i}"] = np.array([c1, c2, oc], dtype=np.int64)
+            # the full tensors would be 4 MB per item: bit-exact identity is pinned by CRC-32 of the fp32 bytes, values
+            # by strided samples and sums
+            v1f, v2f = v1.astype(np.float32), v2.astype(np.float32)              # train_mcl.py:163-165 .float()
+            out[f"crc{i}"] = np.array([zlib.crc32(img.tobytes()), zlib.crc32(v1f.tobytes()), zlib.crc32(v2f.tobytes())], dtype=np.int64)
+            out[f"img_s{i}"] = img[:, ::16, ::16].copy()
+            out[f"v1_s{i}"] = v1f[:, ::16, ::16].copy()
+            out[f"sums{i}"] = np.array([img.astype(np.float64).sum(), v1.sum(), v2.sum()])
+    out["seeds"] = np.array([1234, 4321], dtype=np.int64)
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, {k: v.shape for k, v in out.items() if k.startswith("coords")}, out["coords0"].tolist())
+
+
 def main_fullsize(src, tree):
     """Reference-pinned fixtures at the headline size (B7 / 448x448 scalars + summaries)."""
     gen_step(src, tree, "efficientnet-b7", 4, 448, 224, 4, 31, "step_b7_448_ep4.npz", cam_stride=16)
@@ -672,10 +757,13 @@ def main():
     gen_irn_units(src)
     gen_eval_units(src)
     main_fullsize(src, tree)
+    gen_input_units(src)
 
 
 if __name__ == "__main__":
-    if "--fullsize" in sys.argv:
+    if "--input" in sys.argv:
+        gen_input_units(load_reference())
+    elif "--fullsize" in sys.argv:
         torch.set_num_threads(8)
         main_fullsize(load_reference(), train_script_ast())
     else:

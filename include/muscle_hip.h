@@ -107,10 +107,12 @@ int mx_bn1_sums(const float* pooled5, const float* gate, const float* add, int N
 
 /* ---- depthwise k x k convolution, k in {3,5}, stride in {1,2}: model.py:50-52,78; utils.py:122-145 ---- */
 
-/* Y = dwconv(act(X)), act = swish(scale*x+shift) when scale != NULL; stats (optional) = partial (sum Y, sum Y^2)
- * rows part[mx_dwconv_fwd_parts(N,Ho,Wo,S)][2][C] */
+/* Y = dwconv(act(X)), act = swish(scale*x+shift) when scale != NULL; stats (optional, training) = partial (sum Y, sum Y^2)
+ * rows part[mx_dwconv_fwd_parts(N,Ho,Wo,S)][2][C]; pooled (optional, inference, excludes stats; zeroed by the caller):
+ * pooled[n][c] += sum_hw swish(pool_scale[c]*Y + pool_shift[c]), the SE squeeze of model.py:81-82 under eval-mode BN1 */
 int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S);
-int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats, int N,
+int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats,
+                  const float* pool_scale, const float* pool_shift, float* pooled, int N,
                   int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
 
 /* dX = dwconv^T(dY) (+residual): gradient w.r.t. the activated input */

@@ -133,6 +133,19 @@ class MuSCLe(nn.Module):
             sd = torch.load(weights, map_location="cpu")
             self.load_state_dict(sd.get("state_dict", sd), strict=False)
 
+    # ---- inference constants ------------------------------------------------------------------------------------------
+    def fold_eval_bn(self):
+        """Fold the eval-mode BatchNorms into the 1x1 convolution weights ONCE (CAM generation, infer_mcl.py:107-125: the
+        model is loaded and only ever run in eval mode).  Without this call the no-grad eval forward folds per forward.
+        The cache is dropped by train(); call again after loading other weights."""
+        self.backbone._eval_fold = engine.fold_eval_bn(self.backbone, self.cfg)
+        return self
+
+    def train(self, mode: bool = True):
+        if mode and getattr(self.backbone, "_eval_fold", None) is not None:
+            self.backbone._eval_fold = None
+        return super().train(mode)
+
     # ---- which parameters receive gradients (SURVEY.md §7 "DDP with unused parameters") ----------
     def live_parameters(self, cam_mode: str = "cam") -> List[nn.Parameter]:
         ps: List[nn.Parameter] = [self.backbone._conv_stem.weight, self.backbone._bn0.weight, self.backbone._bn0.bias]

@@ -24,6 +24,9 @@ struct DwArgs {
   const float* res;    // bwd_data: optional residual added to dX
   float* y;            // fwd: Y; bwd_data: dX; bwd_weight: dW [C,1,K,K] (+=)
   float* stats;        // fwd: partial statistics [N*tiles][2][C] or null
+  const float* ps;     // fwd, inference: BN1 scale / shift of the OUTPUT (running statistics) ...
+  const float* pb;
+  float* pooled;       // ... and the SE squeeze sums pooled[n][c] += sum_hw swish(ps*y + pb) (zeroed by the caller), or null
   int N, H, W, Ho, Wo, C, pad;
   int tiles_x, tiles_y;
   int tiles_per_block;   // bwd_weight
@@ -137,6 +140,31 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
         sq.x += acc[o].x * acc[o].x; sq.y += acc[o].y * acc[o].y; sq.z += acc[o].z * acc[o].z; sq.w += acc[o].w * acc[o].w;
       }
     }
+  }
+  if (a.pooled) {
+    // Inference (eval-mode BatchNorm: its affine is known before the batch is seen): the squeeze of the SE block,
+    // sum over the image of swish(bn1(y)), leaves with the tile instead of costing a second pass over d (model.py:81-82)
+    float4 p = make_float4(0, 0, 0, 0);
+    if (c < a.C && oy < a.Ho) {
+      const float4 sc = ld4(a.ps + c), sh = ld4(a.pb + c);
+#pragma unroll
+      for (int o = 0; o < OX; ++o) {
+        if (ox0 + oxl + o < a.Wo) {
+          p.x += swishf_(sc.x * acc[o].x + sh.x); p.y += swishf_(sc.y * acc[o].y + sh.y);
+          p.z += swishf_(sc.z * acc[o].z + sh.z); p.w += swishf_(sc.w * acc[o].w + sh.w);
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) {
+      p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64); p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
+    }
+    if ((tid & 63) < C4B) {
+      atomicAdd(&red[4 * c4 + 0], p.x); atomicAdd(&red[4 * c4 + 1], p.y); atomicAdd(&red[4 * c4 + 2], p.z); atomicAdd(&red[4 * c4 + 3], p.w);
+    }
+    __syncthreads();
+    if (tid < CB && c0 + tid < a.C) unsafeAtomicAdd(a.pooled + (long)n * a.C + c0 + tid, red[tid]);
+    return;
   }
   if (a.stats) {
     // lanes with equal c4 sit 8 apart: fold the wave first, then one LDS atomic per (wave, channel)
@@ -604,10 +632,13 @@ int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S) {
   return N * cdiv(Ho, 8) * cdiv(Wo, S == 1 ? 16 : 8);
 }
 
-int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats, int N,
+int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats,
+                  const float* pool_scale, const float* pool_shift, float* pooled, int N,
                   int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
   DwArgs a{};
   a.x = X; a.sc = scale; a.sh = shift; a.w = W; a.y = Y; a.stats = stats;
+  a.ps = pool_scale; a.pb = pool_shift; a.pooled = pooled;
+  MX_CHECK_ARG(!pooled || (pool_scale && pool_shift && !stats), "dwconv_fwd: pooled needs pool_scale/pool_shift and excludes stats");
   a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
   MX_CHECK_ARG(X && W && Y, "dwconv_fwd: null pointer");
   if (int e = dw_check(a, K, S, "dwconv_fwd")) return e;

@@ -84,6 +84,64 @@ def stem_weight28(backbone):
     return w28
 
 
+def _bn_affine(bn: torch.nn.BatchNorm2d):
+    """Eval-mode BatchNorm as y = s*z + t (running statistics)."""
+    s = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
+    return s, bn.bias.detach() - s * bn.running_mean
+
+
+def fold_eval_bn(backbone, cfg: NetCfg):
+    """Inference-only constants of every block (infer_mcl.py:107-125 runs the model in eval mode): BN0 folded into the
+    expand weight (+ bias), BN2 folded into the project weight (+ bias), BN1 as scale / shift for the depthwise kernel's
+    SE squeeze and the project GEMM's operand prologue.  A handful of tiny elementwise launches per block: done once per
+    model load by MuSCLe.fold_eval_bn(), or per forward when no cache is installed (always correct)."""
+    out = {}
+    for b in cfg.blocks:
+        m = _blk(backbone, b.index)
+        f = {}
+        if b.expand:
+            s0, t0 = _bn_affine(m._bn0)
+            f["We"] = (m._expand_conv.weight.detach().view(b.cexp, b.cin) * s0[:, None]).contiguous()
+            f["be"] = t0.contiguous()
+        s1, t1 = _bn_affine(m._bn1)
+        f["bn1"] = BNState(s1.contiguous(), t1.contiguous(), None, None)
+        s2, t2 = _bn_affine(m._bn2)
+        f["Wp"] = (m._project_conv.weight.detach().view(b.cout, b.cexp) * s2[:, None]).contiguous()
+        f["bp"] = t2.contiguous()
+        out[b.index] = f
+    dev = backbone._conv_stem.weight.device
+    cmax = max(b.cexp for b in cfg.blocks)
+    out["one"] = torch.ones(cmax, dtype=torch.float32, device=dev)
+    out["zero"] = torch.zeros(cmax, dtype=torch.float32, device=dev)
+    return out
+
+
+def _block_forward_eval(m, b: BlockCfg, f, ident, x, x_st, N, h, w, ho, wo):
+    """One MBConv block in inference form: no statistics, no p_raw / separate BN2 pass, the SE squeeze leaves the
+    depthwise kernel, BN2 + skip ride in the project GEMM's epilogue.  HBM: in + 2*exp + 2*dw + out (+ skip)."""
+    M, Mo = N * h * w, N * ho * wo
+    if b.expand:
+        e = ops.pw_fwd(x.view(M, b.cin), f["We"], b.cexp, bias=f["be"]).view(N, h, w, b.cexp)      # = bn0(conv(x))
+        dw_in, dw_st = e, BNState(ident[0][:b.cexp], ident[1][:b.cexp], None, None)                 # swish on load
+    else:
+        dw_in, dw_st = x, x_st
+    d, pooled = ops.dwconv_fwd(dw_in, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, ho, wo, st=dw_st, pool=f["bn1"][:2])
+    _, _, gate = ops.se_fwd(pooled, 1.0 / (ho * wo), m._se_reduce.weight.view(b.se, b.cexp), m._se_reduce.bias,
+                            m._se_expand.weight.view(b.cexp, b.se), m._se_expand.bias)
+    d2 = d.view(Mo, b.cexp)
+    res = x.view(M, b.cin) if b.skip else None
+    if b.cout > MATERIALISE_ABOVE:
+        a = ops.bn_apply(d2, f["bn1"], gate=gate, rows_per_sample=ho * wo, act=True)
+        out = ops.pw_fwd(a, f["Wp"], b.cout, bias=f["bp"], residual=res)
+    else:
+        out = ops.pw_fwd(d2, f["Wp"], b.cout, a_mode=ops.BNACT, a_scale=f["bn1"].scale, a_shift=f["bn1"].shift, a_gate=gate,
+                         rows_per_sample=ho * wo, bias=f["bp"], residual=res)
+    return out.view(N, ho, wo, b.cout)
+
+
+EVAL_FOLD = os.environ.get("MUSCLE_EVAL_FOLD", "1") == "1"
+
+
 def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
                      drop_u: Optional[Dict[int, torch.Tensor]] = None, save: bool = True) -> Tape:
     """img: NCHW fp32 CUDA.  Returns the tape; block outputs are tape.blocks[i].out (NHWC).
@@ -118,10 +176,24 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
             rs = torch.floor(keep + torch.rand(len(idx), N, device=dev)) / keep
             drop_scales = {i: rs[j] for j, i in enumerate(idx)}
     x, x_st, h, w = tape.stem_raw, tape.stem_bn, H0, W0
+    fold = None
+    if not training and not save and EVAL_FOLD:
+        fold = getattr(backbone, "_eval_fold", None) or fold_eval_bn(backbone, cfg)
     for b in cfg.blocks:
         m = _blk(backbone, b.index)
         ho, wo = b.out_size(h), b.out_size(w)
         t = BlockTape(cfg=b, H=h, W=w, Ho=ho, Wo=wo, x=x, x_st=x_st)
+        if fold is not None:
+            # inference-only path (BASELINE.json configs[4]): nothing is kept for a backward
+            t.out = _block_forward_eval(m, b, fold[b.index], (fold["one"], fold["zero"]), x, x_st, N, h, w, ho, wo)
+            t.x = None
+            tape.blocks.append(t)
+            if b.index == 0:
+                tape.cols = tape.stem_raw = None
+            if len(tape.blocks) >= 2 and tape.blocks[-2].cfg.index not in cfg.taps:
+                tape.blocks[-2].out = None
+            x, x_st, h, w = t.out, None, ho, wo
+            continue
         M, Mo = N * h * w, N * ho * wo
         if b.expand:
             assert x_st is None

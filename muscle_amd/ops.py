@@ -215,12 +215,17 @@ def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=
 
 
 # ---- depthwise ------------------------------------------------------------------------------------
-def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, want_stats=False):
+def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, want_stats=False, pool=None):
+    """pool=(scale, shift) (inference): also returns the SE squeeze sums [N, C] of swish(scale*Y + shift)."""
     N, H, Wd, C = X.shape
     Y = _f32(N, Ho, Wo, C, device=X.device)
     stats = _f32(lib().mx_dwconv_fwd_parts(N, Ho, Wo, S), 2, C, device=X.device) if want_stats else None
+    pooled = torch.zeros(N, C, dtype=torch.float32, device=X.device) if pool is not None else None
     call("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),
+         ptr(pool[0]) if pool is not None else None, ptr(pool[1]) if pool is not None else None, ptr(pooled),
          N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
+    if pool is not None:
+        return Y, pooled
     return (Y, stats) if want_stats else Y
 
 

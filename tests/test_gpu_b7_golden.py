@@ -91,6 +91,7 @@ def test_config5_b7_bs64_batch_invariance(size):
     x0 = T(synth.normal(seed, "fwd.x", (n0, 3, H0, W0)).astype(np.float32)).to(DEV)
     _calibrate(model, cfg, x0, n0)
     model.eval()
+    model.fold_eval_bn()                      # the CAM-generation setting: BatchNorms folded once per model load
     B = 64
     x = T(synth.normal(seed + 1, "cfg5.x", (B, 3, size, size)).astype(np.float32)).to(DEV)
     if size == H0:

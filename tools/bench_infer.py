@@ -14,6 +14,8 @@ a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = muscle_amd.MuSCLe(21, a.model, layers=3, last_pooling=False).to(dev).eval()
+if os.environ.get('MUSCLE_EVAL_FOLD', '1') == '1':
+    model.fold_eval_bn()          # BN folded into the conv weights once per model load
 cfg = arch.net_cfg(a.model, False)
 for size in (int(s) for s in a.sizes.split(",")):
     x = torch.randn(a.batch, 3, size, size, device=dev)

@@ -55,6 +55,14 @@ int mx_pw_wgrad(const float* G, const float* X, int x_mode, const float* x_scale
                 const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
                 void* stream);
 
+/* The same weight gradient for SMALL outputs and long reductions (Co*Ci <= 40960, R >= 65536: the first four stages): one
+ * workgroup owns the whole output over a contiguous range of rows, partial matrices are added in a fixed order -
+ * deterministic, both operands read once.  mx_pw_wgrad_small_ws: bytes of scratch needed, 0 = shape not taken. */
+long mx_pw_wgrad_small_ws(int R, int Co, int Ci, int x_mode);
+int mx_pw_wgrad_small(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
+                      const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
+                      void* ws, long ws_bytes, void* stream);
+
 /* batched plain GEMM for the PCM head (MuSCLe.py:213-223): layout 0: C=A*B^T (B [N,K]); 1: C=A*B (B [K,N]). */
 int mx_bgemm(int layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              long sa, long sb, long sc, int batch, int relu, void* stream);

@@ -17,6 +17,7 @@ LIB_PATH = os.path.join(_HERE, "libmuscle_hip.so")
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "muscle_hip.h")
 
+LONG_RETURNS = set()      # entry points declared `long mx_...` (byte counts)
 _C = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "d": ctypes.c_double}
 
 
@@ -26,8 +27,10 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, str]:
     import re
     text = re.sub(r"/\*.*?\*/", "", open(path).read(), flags=re.S)
     sigs: Dict[str, str] = {}
-    for m in re.finditer(r"\bint\s+(mx_\w+)\s*\(([^)]*)\)\s*;", text):
-        name, args = m.group(1), m.group(2).strip()
+    for m in re.finditer(r"\b(int|long)\s+(mx_\w+)\s*\(([^)]*)\)\s*;", text):
+        ret, name, args = m.group(1), m.group(2), m.group(3).strip()
+        if ret == "long":
+            LONG_RETURNS.add(name)
         codes = ""
         if args and args != "void":
             for a in args.split(","):
@@ -69,7 +72,7 @@ def lib() -> ctypes.CDLL:
                 "rebuild it with `python -m muscle_amd._build` (or __graft_entry__.build())")
         for name, codes in parse_header().items():
             fn = getattr(L, name)
-            fn.restype = ctypes.c_int
+            fn.restype = ctypes.c_long if name in LONG_RETURNS else ctypes.c_int
             fn.argtypes = [_C[c] for c in codes]      # incl. the pure-host mx_*_parts() helpers
         _lib = L
     return _lib

@@ -1,0 +1,286 @@
+// Weight gradient of the 1x1 convolutions with a SMALL output and a long pixel reduction (the first four stages of
+// EfficientNet: dW[Co,Ci] = sum_r G[r,Co]^T X'[r,Ci] with Co*Ci <= ~40k and R = 100k .. 1.6M rows).
+//
+// These are HBM-bound: both operands should cross the fabric exactly once.  The tiled TN GEMM (gemm.hip) cuts the output
+// into 128x32 tiles, so every row slab is read by several workgroups, and joins its reduction slices with fp32 atomics
+// (run-to-run different sums): 237-285 us for Co x Ci = 288 x 48 at R = 401 408, whose operands take ~90 us to stream.
+// Here ONE workgroup owns the WHOLE output: it walks a contiguous range of rows in 16-row slabs (both operands through
+// LDS, double buffered), keeps all Co/16 x Ci/16 MFMA tiles in registers (v_mfma_f32_16x16x4_f32, split over its waves)
+// and leaves one partial matrix; a second kernel adds the partials in a fixed order: deterministic, no atomics.
+#include "common.h"
+
+typedef float f32x4w __attribute__((ext_vector_type(4)));
+
+struct WgArgs {
+  const float* G;          // [R, ldg] upstream gradient (plain)
+  MxOperand X;             // [R, ldx] layer input through the operand prologue
+  float* part;             // [groups][Co*Ci]
+  int R, Co, Ci, ldg, ldx;
+  int rows_per_wg;         // multiple of 16
+  int WCO, WCI;            // wave grid over (Co tiles, Ci tiles): WCO * WCI = waves
+  int SG, SX;              // LDS row strides (floats), == 16 mod 32: the 4 rows of a fragment fall on disjoint banks
+};
+
+// GI / XI: 16-byte chunks of a G / X row per loader lane (a row is shared by NT/16 lanes); XMODE: operand prologue of X.
+template <int TCO, int TCI, int NW, int GI, int XI, int XMODE>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void wgrad_small_kernel(WgArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int RB = 16, NT = NW * 64, LPR = NT / RB;       // loader lanes per slab row
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wco = wave % a.WCO, wci = wave / a.WCO;
+  const int slab = RB * (a.SG + a.SX);
+  const int gch = a.Co >> 2, xch = a.Ci >> 2;               // 16-byte chunks per row
+  const long r_beg = (long)blockIdx.x * a.rows_per_wg;
+  const long r_end = min((long)a.R, r_beg + a.rows_per_wg);
+  const int lrow = tid / LPR, lc = tid - lrow * LPR;         // this lane's slab row and first chunk
+
+  float4 rg[GI], rx[XI], gt[XMODE == MX_BNACT ? XI : 1];
+  auto load = [&](long r0) {
+    const long r = r0 + lrow;
+    const bool rin = r < r_end;
+    const float* pg = a.G + r * a.ldg;
+    const float* px = a.X.p + r * a.ldx;
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+      const int c = lc + LPR * i;
+      rg[i] = (rin && c < gch) ? ld4(pg + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int c = lc + LPR * i;
+      rx[i] = (rin && c < xch) ? ld4(px + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (XMODE == MX_BNACT)
+        gt[i] = (rin && c < xch && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  };
+  auto store = [&](float* buf, long r0) {
+    const bool rin = r0 + lrow < r_end;
+#pragma unroll
+    for (int i = 0; i < GI; ++i) {
+      const int c = lc + LPR * i;
+      if (c < gch) st4(buf + lrow * a.SG + 4 * c, rg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+      const int c = lc + LPR * i;
+      if (c < xch) {
+        float4 v = rx[i];
+        if (XMODE != MX_PLAIN && rin) {
+          const float4 sc = ld4(a.X.c1 + 4 * c), sh = ld4(a.X.c2 + 4 * c);
+          v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
+          if (XMODE == MX_BNACT) {
+            const float4 g4 = gt[XMODE == MX_BNACT ? i : 0];
+            v.x = swishf_(v.x) * g4.x; v.y = swishf_(v.y) * g4.y; v.z = swishf_(v.z) * g4.z; v.w = swishf_(v.w) * g4.w;
+          }
+        }
+        st4(buf + RB * a.SG + lrow * a.SX + 4 * c, v);
+      }
+    }
+  };
+  // columns beyond Co / Ci (up to the wave grid's 16-column tiles) stay zero: fragments read them without a test
+  for (int i = tid; i < 2 * slab; i += NT) smem[i] = 0.f;
+  __syncthreads();
+
+  f32x4w acc[TCO][TCI];
+#pragma unroll
+  for (int i = 0; i < TCO; ++i)
+#pragma unroll
+    for (int j = 0; j < TCI; ++j) acc[i][j] = f32x4w{0.f, 0.f, 0.f, 0.f};
+
+  const int ns = (int)((r_end - r_beg + RB - 1) / RB);
+  if (ns > 0) {
+    load(r_beg);
+    store(smem, r_beg);
+    if (ns > 1) load(r_beg + RB);
+  }
+  __syncthreads();
+  for (int s = 0; s < ns; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < ns) {
+      store(smem + (cur ^ 1) * slab, r_beg + (long)(s + 1) * RB);
+      if (s + 2 < ns) load(r_beg + (long)(s + 2) * RB);
+    }
+    const float* gs = smem + cur * slab + q * a.SG + 16 * wco + l15;
+    const float* xs = smem + cur * slab + RB * a.SG + q * a.SX + 16 * wci + l15;
+    const int gstep = 16 * a.WCO, xstep = 16 * a.WCI;
+#pragma unroll
+    for (int qd = 0; qd < RB / 4; ++qd) {
+      float av[TCO], bv[TCI];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i) av[i] = gs[(4 * qd) * a.SG + gstep * i];
+#pragma unroll
+      for (int j = 0; j < TCI; ++j) bv[j] = xs[(4 * qd) * a.SX + xstep * j];
+#pragma unroll
+      for (int i = 0; i < TCO; ++i)
+#pragma unroll
+        for (int j = 0; j < TCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // partial matrix of this workgroup: acc[i][j][r] = dW[16 t_co + 4q + r][16 t_ci + l15]
+  float* out = a.part + (long)blockIdx.x * a.Co * a.Ci;
+#pragma unroll
+  for (int i = 0; i < TCO; ++i) {
+    const int tco = wco + a.WCO * i;
+#pragma unroll
+    for (int j = 0; j < TCI; ++j) {
+      const int col = 16 * (wci + a.WCI * j) + l15;
+      if (col < a.Ci) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * tco + 4 * q + r;
+          if (row < a.Co) out[(long)row * a.Ci + col] = acc[i][j][r];
+        }
+      }
+    }
+  }
+}
+
+// dW[e] += sum_g part[g][e]: 16 lanes per 4 consecutive elements walk the partial matrices (g = lane, lane + 16, ...; four
+// loads in flight each), then the 16 lane sums are added in a fixed tree: deterministic.
+__global__ __launch_bounds__(256) void wgrad_parts_reduce_kernel(const float* __restrict__ part, int groups, int n, float* __restrict__ dW) {
+  __shared__ float4 red[16][16];
+  const int el = threadIdx.x & 15, gl = threadIdx.x >> 4;
+  const int e4 = blockIdx.x * 16 + el;                       // float4 index
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0, s2 = s0, s3 = s0;
+  if (4 * e4 < n) {
+    const float* p = part + 4L * e4;
+    int g = gl;
+    for (; g + 48 < groups; g += 64) {
+      const float4 a0 = ld4(p + (long)g * n), a1 = ld4(p + (long)(g + 16) * n), a2 = ld4(p + (long)(g + 32) * n), a3 = ld4(p + (long)(g + 48) * n);
+      s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+      s1.x += a1.x; s1.y += a1.y; s1.z += a1.z; s1.w += a1.w;
+      s2.x += a2.x; s2.y += a2.y; s2.z += a2.z; s2.w += a2.w;
+      s3.x += a3.x; s3.y += a3.y; s3.z += a3.z; s3.w += a3.w;
+    }
+    for (; g < groups; g += 16) {
+      const float4 a0 = ld4(p + (long)g * n);
+      s0.x += a0.x; s0.y += a0.y; s0.z += a0.z; s0.w += a0.w;
+    }
+  }
+  red[gl][el] = make_float4((s0.x + s1.x) + (s2.x + s3.x), (s0.y + s1.y) + (s2.y + s3.y), (s0.z + s1.z) + (s2.z + s3.z), (s0.w + s1.w) + (s2.w + s3.w));
+  __syncthreads();
+  if (gl == 0 && 4 * e4 < n) {
+    float4 t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) { const float4 v = red[k][el]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+    float4 d = ld4(dW + 4L * e4);
+    d.x += t.x; d.y += t.y; d.z += t.z; d.w += t.w;
+    st4(dW + 4L * e4, d);
+  }
+}
+
+static int wg_pad16(int c) {           // smallest stride >= c (rounded to 16) that is 16 mod 32
+  int s = (c + 15) / 16 * 16;
+  return (s % 32 == 16) ? s : s + 16;
+}
+
+struct WgPlan { int nw, wco, wci, tco, tci, groups, rows_per_wg, SG, SX; long lds_bytes; };
+
+static bool wg_plan(int R, int Co, int Ci, WgPlan* p) {
+  const int cot = cdiv(Co, 16), cit = cdiv(Ci, 16);
+  if (Co % 4 || Ci % 4 || (long)Co * Ci > 40960 || R < 65536) return false;
+  // waves: 4, or 8 when the tiles of one wave would exceed 24 (96 accumulator registers)
+  int best_nw = 0, best_wco = 0, best_cost = 1 << 30;
+  for (int nw : {4, 8}) {
+    for (int wco = 1; wco <= nw; wco *= 2) {
+      const int wci = nw / wco;
+      const int tco = cdiv(cot, wco), tci = cdiv(cit, wci);
+      if (tco > 5 || tci > 5 || tco * tci > (nw == 4 ? 24 : 20)) continue;
+      const int cost = tco * tci * nw;                        // issued MFMA slots per 4 rows
+      if (cost < best_cost) { best_cost = cost; best_nw = nw; best_wco = wco; }
+    }
+    if (best_nw) break;                                       // 4 waves suffice
+  }
+  if (!best_nw) return false;
+  p->nw = best_nw; p->wco = best_wco; p->wci = best_nw / best_wco;
+  p->tco = cdiv(cot, p->wco); p->tci = cdiv(cit, p->wci);
+  p->SG = wg_pad16(16 * p->wco * p->tco); p->SX = wg_pad16(16 * p->wci * p->tci);
+  p->lds_bytes = 2L * 16 * (p->SG + p->SX) * 4;
+  if (p->lds_bytes > 80 * 1024) return false;
+  int per_cu = (int)(160 * 1024 / p->lds_bytes);
+  const int cap = best_nw == 8 ? 2 : 3;
+  if (per_cu > cap) per_cu = cap;
+  int rows = cdiv(cdiv(R, 256 * per_cu), 16) * 16;
+  if (rows < 64) rows = 64;
+  p->rows_per_wg = rows;
+  p->groups = cdiv(R, rows);
+  return true;
+}
+
+template <int TCO, int TCI, int NW, int GI, int XI, int XMODE>
+static void wg_launch_one(const WgArgs& a, const WgPlan& p, hipStream_t st) {
+  static bool big_lds_ok = false;                      // > 64 KB of dynamic LDS needs the attribute, once per kernel
+  if (p.lds_bytes > 64 * 1024 && !big_lds_ok) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_small_kernel<TCO, TCI, NW, GI, XI, XMODE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    big_lds_ok = true;
+  }
+  hipLaunchKernelGGL((wgrad_small_kernel<TCO, TCI, NW, GI, XI, XMODE>), dim3(p.groups), dim3(NW * 64), p.lds_bytes, st, a);
+}
+
+// The instantiations that exist: the (Co, Ci, prologue) combinations of EfficientNet-B7's first four stages (project convs
+// read d_raw through BN1 + SiLU + gate, expand convs and the stem read plain inputs).  Anything else falls back to the
+// tiled kernel of gemm.hip - including stage 3 (480 x 80 / 80 x 480 at 100 352 rows): its 150 tiles need 8 waves of 20
+// tiles each, which at the 128-register bound of two 512-thread workgroups per CU spilled 160-300 registers.            tiles/wave  waves  G chunks  X chunks  prologue       B7 layer
+#define WG_TABLE(V)                                                                                             \
+  V(2, 1, 4, 1, 1, MX_BNACT)  /* 32 x 64              project of block 0                                    */ \
+  V(3, 3, 4, 1, 3, MX_BNACT)  /* 48 x 192             project of block 4                                    */ \
+  V(3, 5, 4, 1, 5, MX_BNACT)  /* 48 x 288             project of stage 2                                    */ \
+  V(3, 2, 4, 3, 1, MX_PLAIN)  /* 192 x 32             expand of block 4                                     */ \
+  V(5, 3, 4, 5, 1, MX_PLAIN)  /* 288 x 48             expand of stage 2                                     */ \
+  V(2, 1, 4, 1, 1, MX_PLAIN)  /* 64 x 28              stem                                                  */ \
+  V(1, 1, 4, 1, 1, MX_BNACT)  /* 32 x 32              project of blocks 1-3                                 */ \
+  V(1, 1, 4, 1, 1, MX_PLAIN)  /* 32 x 32              (plain)                                               */
+
+static bool wg_dispatch(const WgArgs& a, const WgPlan& p, hipStream_t st, bool launch) {
+  const int lpr = p.nw * 64 / 16;
+  const int gi = cdiv(a.Co / 4, lpr), xi = cdiv(a.Ci / 4, lpr);
+#define WG_TRY(TCO, TCI, NW, GI, XI, MODE)                                                             \
+  if (p.tco == TCO && p.tci == TCI && p.nw == NW && gi == GI && xi == XI && a.X.mode == MODE) {        \
+    if (launch) wg_launch_one<TCO, TCI, NW, GI, XI, MODE>(a, p, st);                                   \
+    return true;                                                                                       \
+  }
+  WG_TABLE(WG_TRY)
+#undef WG_TRY
+  return false;
+}
+
+extern "C" {
+
+// bytes of scratch mx_pw_wgrad_small needs for (R, Co, Ci, x_mode), or 0 when the shape is not one it takes
+long mx_pw_wgrad_small_ws(int R, int Co, int Ci, int x_mode) {
+  WgPlan p;
+  if (!wg_plan(R, Co, Ci, &p)) return 0;
+  WgArgs a{};
+  a.Co = Co; a.Ci = Ci; a.X.mode = x_mode;
+  if (!wg_dispatch(a, p, nullptr, false)) return 0;
+  return (long)p.groups * Co * Ci * 4;
+}
+
+// dW[Co,Ci] += G[R,Co]^T X'[R,Ci] for small outputs and long reductions; deterministic (fixed summation order).
+// ws: caller-owned scratch of mx_pw_wgrad_small_ws bytes.
+int mx_pw_wgrad_small(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
+                      const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
+                      void* ws, long ws_bytes, void* stream) {
+  MX_CHECK_ARG(G && X && dW && ws, "wgrad_small: null pointer");
+  MX_CHECK_ARG(((uintptr_t)dW & 15) == 0 && ((uintptr_t)ws & 15) == 0, "wgrad_small: dW / workspace must be 16-byte aligned");
+  MX_CHECK_ARG(ldg % 4 == 0 && ldx % 4 == 0, "wgrad_small: leading dimensions must be multiples of 4");
+  MX_CHECK_ARG(x_mode == MX_PLAIN || (x_scale && x_shift && rows_per_sample > 0), "wgrad_small: prologue needs scale/shift");
+  WgPlan p;
+  MX_CHECK_ARG(wg_plan(R, Co, Ci, &p), "wgrad_small: shape R=%d Co=%d Ci=%d not supported", R, Co, Ci);
+  MX_CHECK_ARG(ws_bytes >= (long)p.groups * Co * Ci * 4, "wgrad_small: workspace too small");
+  WgArgs a{};
+  a.G = G; a.X = MxOperand{X, x_scale, x_shift, x_gate, x_mode, rows_per_sample};
+  a.part = (float*)ws; a.R = R; a.Co = Co; a.Ci = Ci; a.ldg = ldg; a.ldx = ldx;
+  a.rows_per_wg = p.rows_per_wg; a.WCO = p.wco; a.WCI = p.wci; a.SG = p.SG; a.SX = p.SX;
+  hipStream_t st = (hipStream_t)stream;
+  MX_CHECK_ARG(wg_dispatch(a, p, st, true), "wgrad_small: no kernel for Co=%d Ci=%d mode=%d (ask mx_pw_wgrad_small_ws first)", Co, Ci, x_mode);
+  MX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_parts_reduce_kernel, dim3(cdiv((long)Co * Ci, 64)), dim3(256), 0, st, (const float*)ws, p.groups, Co * Ci, dW);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+}  // extern "C"

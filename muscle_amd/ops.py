@@ -66,10 +66,30 @@ def pw_dgrad(G, W, N_in, *, residual=None, out=None):
     return out
 
 
+_wgrad_ws: dict = {}
+WGRAD_SMALL = True       # small outputs / long reductions: one workgroup owns the whole output, deterministic partial sums
+
+
+def _wgrad_workspace(device, nbytes):
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
+        _wgrad_ws[key] = ws
+    return ws
+
+
 def pw_wgrad(G, X, dW, *, x_mode=PLAIN, x_scale=None, x_shift=None, x_gate=None, rows_per_sample=1):
     """dW[Co, Ci] += G[R, Co]^T X'[R, Ci]."""
     R, Co = G.shape
     Ci = X.shape[1]
+    if WGRAD_SMALL and dW.is_contiguous():
+        need = lib().mx_pw_wgrad_small_ws(R, Co, Ci, x_mode)
+        if need > 0:
+            ws = _wgrad_workspace(G.device, need)
+            call("mx_pw_wgrad_small", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),
+                 R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())
+            return
     call("mx_pw_wgrad", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),
          R, Co, Ci, G.stride(0), X.stride(0), stream())
 

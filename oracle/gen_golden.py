@@ -506,6 +506,24 @@ def gen_muscle_step(src, name, n, size, seed, fname, lamb, k, step, lr=1e-5, tor
     model.train()
     random.seed(78)
     torch.manual_seed(torch_seed)
+    # Which boundary points enter the BEACON term depends on thresholding a softmax(100*seg) edge map: 1e-6 of round-off in
+    # seg moves pixels in and out of the point lists, so two fp32 implementations draw different samples from the same
+    # random stream.  The reference's own choices are recorded (in_out_div's lists through random.sample's picks) so that
+    # the loss and its gradient can be compared on identical points.
+    div_log, smp_log = [], []
+    real_div, real_sample = ref_edge.FieldLoss.in_out_div, random.sample
+
+    def logging_div(self, *a_, **k_):
+        o, i = real_div(self, *a_, **k_)
+        div_log.append((o.clone(), i.clone()))
+        return o, i
+
+    def logging_sample(pop, kk):
+        r = real_sample(pop, kk)
+        smp_log.append(list(r))
+        return r
+    ref_edge.FieldLoss.in_out_div = logging_div
+    random.sample = logging_sample
     clip_log = []
     real_clip = torch.nn.utils.clip_grad_norm_
 
@@ -518,7 +536,25 @@ def gen_muscle_step(src, name, n, size, seed, fname, lamb, k, step, lr=1e-5, tor
         exec(muscle_loop_body(), ns)
     finally:
         torch.nn.utils.clip_grad_norm_ = real_clip
+        ref_edge.FieldLoss.in_out_div = real_div
+        random.sample = real_sample
+    # reassemble the sampled points per qualifying (sample, class) slot, in the loss's own order (edge.py:279-299)
+    lab_t = torch.from_numpy(lab)
+    slots = [(b_, c_) for b_ in range(n) for c_ in range(20) if lab_t[b_, c_] != 0]
+    rp_b, rp_out, rp_in, j = [], [], [], 0
+    if lamb > 0:
+        assert len(div_log) == len(slots), (len(div_log), len(slots))
+        for (b_, c_), (o_, i_) in zip(slots, div_log):
+            if i_.numel() > k and o_.numel() > k:
+                r_out, r_in = smp_log[j], smp_log[j + 1]
+                j += 2
+                rp_b.append(b_)
+                rp_out.append(o_[r_out].numpy())
+                rp_in.append(i_[r_in].numpy())
+        assert j == len(smp_log)
     out = {
+        "replay_b": np.array(rp_b, dtype=np.int64), "replay_out": np.array(rp_out, dtype=np.int64).reshape(len(rp_b), k),
+        "replay_in": np.array(rp_in, dtype=np.int64).reshape(len(rp_b), k),
         "meta": np.array([n, size, seed, torch_seed, k, step], dtype=np.int64), "name": np.array(name),
         "lamb": np.array(lamb), "lr": np.array(lr),
         "drop_idx": np.array(drop_idx, dtype=np.int64), "drop_u": np.array(drop_u, dtype=np.float32).reshape(len(drop_idx), n),

@@ -118,11 +118,16 @@ def test_muscle_step_golden(fname, fused):
     opt = M.FusedAdam(model.parameters(), lr=float(G["lr"]), weight_decay=1e-5)
     du = {int(i): T(u).to(DEV) for i, u in zip(G["drop_idx"], G["drop_u"])}
     random.seed(78)
-    out = M.muscle_step(model, opt, b, lamb=float(G["lamb"]), step=step, k=kk, drop_u=du, fused=fused)
+    crit = None
+    if float(G["lamb"]) > 0:
+        # the BEACON term on the reference's own boundary points (thresholding softmax(100*seg) at 0.8*max is decided by
+        # fp32 round-off, so the sets themselves are replayed; what is compared is everything downstream of them)
+        crit = M.edge.FieldLoss(sobel_size=5, beta=1e2, k=kk)
+        crit.replay_points = (G["replay_b"], G["replay_out"], G["replay_in"])
+    out = M.muscle_step(model, opt, b, lamb=float(G["lamb"]), step=step, k=kk, drop_u=du, fused=fused, criterion2=crit)
     close(out["loss_seg"], G["losses"][0], 1e-4)
     assert torch.is_tensor(out["loss_beacon"]) == bool(G["l2_is_tensor"])
-    # boundary-point sets differ by round-off between implementations (see tests/test_oracle_golden.py): magnitude only
-    assert abs(float(out["loss_beacon"]) - G["losses"][1]) <= 0.5 * abs(G["losses"][1]) + 1e-6
+    close(out["loss_beacon"], G["losses"][1], 1e-4)
     close(out["grad_norm"], G["grad_norm"][0], 2e-3)
     keys = [str(k) for k in G["param_keys"]]
     named = dict(model.named_parameters())
@@ -130,7 +135,7 @@ def test_muscle_step_golden(fname, fused):
     ref = G["grad1"]
     g = gu.tensor_summary([(k, named[k].grad) for k in keys])
     assert np.array_equal(np.isnan(g[:, 0]), np.isnan(ref[:, 0]))          # dead branches of the last BiFPN layer: no grad
-    if float(G["lamb"]) == 0.0:
+    if True:                                                              # lamb = 0 and lamb = 0.05 alike
         live = ~np.isnan(ref[:, 0])
         scale = np.maximum(ref[live, :1], 1e-3 * ref[live, 0].max())
         assert np.all(np.abs(g[live] - ref[live]) <= 3e-3 * scale), np.abs((g[live] - ref[live]) / scale).max()

@@ -27,7 +27,13 @@ def family(n):
     if n.startswith("gemm_kernel"):
         m = re.match(r"gemm_kernel<(\d)", n)
         return "gemm_kernel<%s>" % {"0": "NT fwd", "1": "NN dgrad", "2": "TN wgrad"}[m.group(1)]
+    if n.startswith("gemm_nt_kernel"):
+        return "gemm_nt_kernel<NT fwd + dgrad>"
+    if n.startswith("dw_bwd_fused_kernel"):
+        return "dw_bwd_fused_kernel<%s>" % re.match(r"dw_bwd_fused_kernel<(\d)", n).group(1)
     return re.sub(r"<.*", "", n)
+
+GEMM_FAMILIES = ("gemm_kernel", "gemm_nt_kernel", "wgrad_small_kernel")
 
 dirs = dict(a.split("=") for a in sys.argv[2:])
 res = {}
@@ -49,3 +55,13 @@ json.dump({"source": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | 
            "as HBM-side traffic by these counters; mfma_util = MFMA busy cycles / (duration x 1024 SIMDs x 2.4 GHz)",
            "kernels": res}, open(sys.argv[1], "w"), indent=1)
 print(open(sys.argv[1]).read())
+# the bench line's roofline.traffic: memory-side bytes per pointwise-GEMM launch (all GEMM families together)
+gl = sum(cf[f] for f in cf if f.startswith(GEMM_FAMILIES))
+gb = sum(2.0 * fetch[f].get("FETCH_SIZE", 0.0) * 1024 + write[f].get("WRITE_SIZE", 0.0) * 1024 for f in cf if f.startswith(GEMM_FAMILIES))
+if len(sys.argv) > 1 and gl:
+    tp = os.path.join(os.path.dirname(sys.argv[1]), "traffic.json")
+    json.dump({"source": "tools/summarize_pmc.py over the three --pmc passes named in " + os.path.basename(sys.argv[1]),
+               "gemm_launches_profiled": gl, "gemm_hbm_bytes_per_launch": gb / gl,
+               "per_family_MB_per_launch": {f: {"read": res[f]["read_MB_per_launch"], "write": res[f]["write_MB_per_launch"], "mfma_util": res[f]["mfma_util"]}
+                                            for f in res if f.startswith(GEMM_FAMILIES)}}, open(tp, "w"), indent=1)
+    print("wrote", tp, gb / gl / 1e6, "MB per GEMM launch over", gl, "launches")

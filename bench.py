@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--epoch", type=int, default=4, help="epoch gate semantics of train_mcl.py (4: cls+ER+IMC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay phase 1 from a captured hipGraph (muscle_amd.GraphedStep; single GPU, epoch < 8): for the "
+                         "launch-bound small-model configs; per-kernel HIP-event timing is off in this mode")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -185,6 +188,14 @@ def main():
     def step():
         return muscle_amd.mcl_step(model, opt, batch, a.epoch, valid_channel=vc, grad_hook=hook)
 
+    if a.graph:
+        if world > 1:
+            raise SystemExit("--graph is the single-GPU launch-bound path")
+        gstep = muscle_amd.GraphedStep(model, opt, a.epoch)
+        for _ in range(gstep.warmup + 1):          # eager settling steps + the capturing call
+            gstep(batch)
+        step = lambda: gstep(batch)                # noqa: E731  (copies the batch into the static buffers, replays)
+
     if a.epoch >= 8:
         # phase 2 runs in eval mode (train_mcl.py:196): give the random-init model BatchNorm running statistics of its
         # own activations (one train-mode pass at momentum 1.0), as SURVEY 8(c) prescribes for eval-mode work
@@ -209,7 +220,7 @@ def main():
     host_t0 = [0.0]
 
     barrier()
-    timer.on = (rank == 0)
+    timer.on = (rank == 0) and not a.graph
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
@@ -253,7 +264,8 @@ def main():
                                 f"{'+IMC' if a.epoch >= 4 else ''}, one backward, one Adam step), ") +
                                f"MuSCLe({a.model}, last_pooling=False, 21 classes), random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
-                   "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused"},
+                   "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused",
+                   "launch": "hipGraph replay" if a.graph else "eager"},
         "losses": {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in out.items()},
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> / gemm_kernel<*> (exact-fp32 MFMA pointwise convs: fwd + dgrad on v_mfma_f32_16x16x4_f32, wgrad on 32x32x2; stem)",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",

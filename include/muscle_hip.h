@@ -249,16 +249,19 @@ int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsi
 
 /* The same ER loss computed straight from the low-resolution NHWC maps cam/sgc [N,h,w,L] (MuSCLe.py:256-257 fused in):
  * no H*W-sized tensor is read or written.  gsgc [N,h,w,L] = d loss / d sgc_lowres. */
+/* k_dev (optional, device int32): the top-k count read at run time instead of k / gscale's 1/(N k) - for hipGraph replays
+ * of the step, where k = int(0.2 * sum(labels) * H * W) (train_mcl.py:178,188) changes with every batch */
 int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
-                 unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss,
-                 void* stream);
+                 const int* k_dev, unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum,
+                 float* loss, void* stream);
 int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix, const unsigned* krem,
-                 const unsigned* cnt_eq, const float* gup, float gscale, float* gsgc, int N, int h, int w, int L, int K, int H,
-                 int W, void* stream);
+                 const unsigned* cnt_eq, const float* gup, float gscale, const int* k_dev, float* gsgc, int N, int h, int w, int L,
+                 int K, int H, int W, void* stream);
 
 /* torch.optim.Adam(weight_decay) update on flat arrays (train_mcl.py:134,199,229) */
+/* dyn (optional, device float[3] = {lr, bias_corr1, sqrt_bias_corr2}): read at run time instead of the arguments (hipGraph replays) */
 int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-            float weight_decay, float bias_corr1, float sqrt_bias_corr2, void* stream);
+            float weight_decay, float bias_corr1, float sqrt_bias_corr2, const float* dyn, void* stream);
 
 /* ---- phase 2 (epochs >= 8 / >= 12): cam_maxnorm, PixPro, crops, Sinkhorn EMD ------------------------------------ */
 

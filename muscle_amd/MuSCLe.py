@@ -30,6 +30,20 @@ class _HeadTape:
     __slots__ = ("emb", "cam", "fs", "f", "fn", "nrm", "aff", "T", "hw", "hwp", "h", "w", "H", "W", "fcw", "mode")
 
 
+_one_cache = {}
+
+
+def _one_hot_bias(K: int, dev):
+    """[_CPAD] bias with a 1 at column K; cached per device (a host scalar written per forward would be a blocking
+    copy, and is not allowed while a stream is capturing)."""
+    key = (K, str(dev))
+    if key not in _one_cache:
+        v = torch.zeros(_CPAD, dtype=torch.float32)
+        v[K] = 1.0
+        _one_cache[key] = v.to(dev)
+    return _one_cache[key]
+
+
 class _ArenaSink(engine.GradSink):
     """Gradient sink whose buffers are consecutive views of one flat, zero-filled fp32 arena."""
 
@@ -291,8 +305,7 @@ class MuSCLe(nn.Module):
                 return (emb, logits), tape, ht
         # CAM = relu(1x1 conv of p7 with the detached fc weight), :243-247.  Column K of the padded class
         # dimension is forced to 1 through the bias so that aff @ [cam|1] also yields the affinity row sums.
-        one = torch.zeros(_CPAD, dtype=torch.float32, device=dev)
-        one[K] = 1.0
+        one = _one_hot_bias(K, dev)
         cam = torch.zeros(M7 + 4, _CPAD, dtype=torch.float32, device=dev)               # +4 rows: padded-K reads
         ops.pw_fwd(p7m, fcw, _CPAD, bias=one, relu=True, out=cam, ldc=_CPAD)
         ht.cam = cam

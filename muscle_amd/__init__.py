@@ -18,4 +18,5 @@ from . import phase2 as torchutils  # noqa: F401  (reference name of the module 
 __all__ = ["MuSCLe", "FocalLoss", "Log_Sum_Exp_Pairwise_Loss", "MultiLabelSoftMarginLoss", "image_level_contrast",
            "FusedAdam", "cam_softmaxnorm", "er_loss", "mcl_step", "EMD", "PixPro", "cam_maxnorm", "get_dynamic_crops",
            "torchutils", "edge", "muscle_step"]
+from .graph import GraphedStep  # noqa: F401,E402
 from . import data  # noqa: F401,E402  (input path: two-view sampler + device-side color_norm / crop stage)

@@ -294,7 +294,15 @@ __global__ __launch_bounds__(64) void er_scan_kernel(const unsigned* hcnt, const
 }
 
 // loss = sum_n (sum_gt[n] + krem[n] * tau[n]) / (N * k)
-__global__ void er_final_kernel(const unsigned* krem, const unsigned* prefix, const float* sum_gt, int N, float inv_nk, float* loss) {
+// k_dev (optional, device int): the top-k count read at run time (hipGraph replays: k = int(0.2 * sum(labels) * H * W) changes
+// with every batch, train_mcl.py:178,188)
+__global__ void er_krem_init_kernel(unsigned* krem, int N, const int* k_dev) {
+  for (int n = threadIdx.x; n < N; n += 64) krem[n] = (unsigned)k_dev[0];
+}
+
+__global__ void er_final_kernel(const unsigned* krem, const unsigned* prefix, const float* sum_gt, int N, float inv_nk, float* loss,
+                                const int* k_dev) {
+  if (k_dev) inv_nk = 1.0f / ((float)N * (float)k_dev[0]);
   float acc = 0.f;
   for (int n = threadIdx.x; n < N; n += 64) acc += sum_gt[n] + (float)krem[n] * __uint_as_float(prefix[n]);
   acc = wave_sum(acc);
@@ -336,8 +344,11 @@ __global__ __launch_bounds__(256) void er_bwd_kernel(const float* cams, const fl
 // ---------------------------------------------------------------------------
 // Adam, L2 weight decay folded into the gradient (torch.optim.Adam, not AdamW), flat arrays
 // ---------------------------------------------------------------------------
+// dyn (optional, device): {lr, bias_corr1, sqrt_bias_corr2} read at run time instead of the launch arguments, so that a
+// captured hipGraph of the step keeps advancing Adam's step count and follows the LR scheduler when it is replayed
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1,
-                                                   float b2, float eps, float wd, float bc1, float bc2s) {
+                                                   float b2, float eps, float wd, float bc1, float bc2s, const float* dyn) {
+  if (dyn) { lr = dyn[0]; bc1 = dyn[1]; bc2s = dyn[2]; }
   for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
     if (i + 3 < n) {
       float4 pp = ld4(p + i), gg = ld4(g + i), mm = ld4(m + i), vv = ld4(v + i);
@@ -417,7 +428,7 @@ int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int
     hipLaunchKernelGGL(er_scan_kernel, dim3(N), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
                        cnt_eq, N);
   }
-  hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)k), loss);
+  hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)k), loss, (const int*)nullptr);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -432,11 +443,11 @@ int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsi
 }
 
 int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps,
-            float weight_decay, float bias_corr1, float sqrt_bias_corr2, void* stream) {
+            float weight_decay, float bias_corr1, float sqrt_bias_corr2, const float* dyn, void* stream) {
   MX_CHECK_ARG(p && g && m && v && n > 0, "adam: bad args");
   MX_CHECK_ARG((((uintptr_t)p | (uintptr_t)g | (uintptr_t)m | (uintptr_t)v) & 15) == 0, "adam: pointers must be 16-byte aligned");
   hipLaunchKernelGGL(adam_kernel, dim3(gs((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1, beta2, eps,
-                     weight_decay, bias_corr1, sqrt_bias_corr2);
+                     weight_decay, bias_corr1, sqrt_bias_corr2, dyn);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -524,10 +535,11 @@ __global__ __launch_bounds__(256) void er_lr_hist_kernel(const float* cam, const
 // gradient w.r.t. the low-res SGC: one workgroup per low-res cell gathers from the full-res pixels it feeds
 __global__ __launch_bounds__(256) void er_lr_bwd_kernel(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix,
                                                         const unsigned* krem, const unsigned* cnt_eq, const float* gup,
-                                                        float gscale, float* gsgc, int h, int w, int L, int K, int H, int W) {
+                                                        float gscale, const int* k_dev, float* gsgc, int h, int w, int L, int K, int H, int W) {
   __shared__ float red[4][KMAX];
   const int cell = blockIdx.x, n = blockIdx.y;
   const int cy = cell / w, cx = cell % w;
+  if (k_dev) gscale = 1.0f / ((float)gridDim.y * (float)k_dev[0]);
   if (gup) gscale *= gup[0];
   // full-res rows / cols whose interpolation touches (cy, cx): source coordinate in (cy-1, cy+1)
   const float sy = (H > 1) ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = (W > 1) ? (float)(w - 1) / (float)(W - 1) : 0.f;
@@ -582,7 +594,7 @@ __global__ __launch_bounds__(256) void er_lr_bwd_kernel(const float* cam, const 
 template <int KT>
 __global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, const float* sgc, const float* lwb,
                                                              const unsigned* prefix, const unsigned* krem, const unsigned* cnt_eq,
-                                                             const float* gup, float gscale, float* gsgc, int h, int w, int L,
+                                                             const float* gup, float gscale, const int* k_dev, float* gsgc, int h, int w, int L,
                                                              int H, int W, int ty) {
   extern __shared__ float lacc[];                 // [3][ncx][KT]
   const int n = blockIdx.z, Y0 = blockIdx.y * ty, X = blockIdx.x * 256 + threadIdx.x;
@@ -595,6 +607,7 @@ __global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, c
   const int ncx = xe - xb + 1;
   for (int i = threadIdx.x; i < 3 * ncx * KT; i += 256) lacc[i] = 0.f;
   __syncthreads();
+  if (k_dev) gscale = 1.0f / ((float)gridDim.z * (float)k_dev[0]);
   if (gup) gscale *= gup[0];
   float S[3][KT];
 #pragma unroll
@@ -664,13 +677,14 @@ extern "C" {
 // ER loss from the low-res NHWC maps cam/sgc [N,h,w,L] for an H x W image (train_mcl.py:175-188 + MuSCLe.py:256-257 fused).
 // state buffers as mx_er_fwd (prefix and sum_gt zeroed by the caller); nothing of size H*W is allocated.
 int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
-                 unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss,
-                 void* stream) {
+                 const int* k_dev, unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum,
+                 float* loss, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && krem && prefix && sum_gt && cnt_eq && hcnt && hsum && loss, "er_lr_fwd: null pointer");
   MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && H > 0 && W > 0, "er_lr_fwd: bad extents");
-  MX_CHECK_ARG(k >= 1 && k <= (long)K * H * W, "er_lr_fwd: k=%ld out of range for rows of %ld (torch.topk would raise)", k, (long)K * H * W);
+  MX_CHECK_ARG(k_dev || (k >= 1 && k <= (long)K * H * W), "er_lr_fwd: k=%ld out of range for rows of %ld (torch.topk would raise)", k, (long)K * H * W);
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetD32Async((hipDeviceptr_t)krem, (int)(unsigned)k, N, st);
+  if (k_dev) hipLaunchKernelGGL(er_krem_init_kernel, dim3(1), dim3(64), 0, st, krem, N, k_dev);
+  else hipMemsetD32Async((hipDeviceptr_t)krem, (int)(unsigned)k, N, st);
   const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
   const unsigned himask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
   long HW = (long)H * W;
@@ -684,14 +698,14 @@ int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, in
     hipLaunchKernelGGL(er_scan_kernel, dim3(N), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
                        cnt_eq, N);
   }
-  hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)k), loss);
+  hipLaunchKernelGGL(er_final_kernel, dim3(1), dim3(64), 0, st, krem, prefix, sum_gt, N, 1.0f / ((float)N * (float)(k > 0 ? k : 1)), loss, k_dev);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
 int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix, const unsigned* krem,
-                 const unsigned* cnt_eq, const float* gup, float gscale, float* gsgc, int N, int h, int w, int L, int K, int H,
-                 int W, void* stream) {
+                 const unsigned* cnt_eq, const float* gup, float gscale, const int* k_dev, float* gsgc, int N, int h, int w, int L,
+                 int K, int H, int W, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && prefix && krem && cnt_eq && gsgc, "er_lr_bwd: null pointer");
   MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L <= 256 && H > 0 && W > 0, "er_lr_bwd: bad extents");
   if (K == 21) {
@@ -708,10 +722,10 @@ int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const uns
     MX_CHECK_ARG(sh <= 64 * 1024, "er_lr_bwd: low-res span per segment too wide (%d columns)", xe0);
     hipMemsetAsync(gsgc, 0, sizeof(float) * (size_t)N * h * w * L, (hipStream_t)stream);
     hipLaunchKernelGGL(er_lr_bwd_band_kernel<21>, dim3(cdiv(W, 256), cdiv(H, ty), N), dim3(256), sh, (hipStream_t)stream, cam, sgc,
-                       lwb, prefix, krem, cnt_eq, gup, gscale, gsgc, h, w, L, H, W, ty);
+                       lwb, prefix, krem, cnt_eq, gup, gscale, k_dev, gsgc, h, w, L, H, W, ty);
   } else {
     hipLaunchKernelGGL(er_lr_bwd_kernel, dim3(h * w, N), dim3(256), 0, (hipStream_t)stream, cam, sgc, lwb, prefix, krem, cnt_eq, gup,
-                       gscale, gsgc, h, w, L, K, H, W);
+                       gscale, k_dev, gsgc, h, w, L, K, H, W);
   }
   MX_LAUNCH_CHECK();
   return MX_OK;

@@ -18,6 +18,41 @@ class FusedAdam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._flat = None
+        self._device_scalars = False
+        self._touched = []
+
+    # ---- hipGraph support: lr and the bias corrections read from device memory --------------------------------------
+    def use_device_scalars(self, on: bool = True):
+        """With this on, a step advances a per-group step count that lives on the device and hands the kernel
+        {lr, 1 - b1^t, sqrt(1 - b2^t)} through a 3-float device buffer, so the enqueued work has no host-side scalar
+        that changes from step to step and can be replayed from a captured graph (muscle_amd.graph).  Requires what the
+        MCL loop has anyway: every parameter that receives a gradient has taken the same number of steps."""
+        self._device_scalars = bool(on)
+        return self
+
+    def _dev_state(self, group, t_host: int):
+        st = group.get("_dyn")
+        if st is None:
+            dev = group["_dev"]
+            st = {"dyn": torch.zeros(3, dtype=torch.float32, device=dev),
+                  "t": torch.full((), float(t_host), dtype=torch.float64, device=dev),
+                  "lr": torch.full((), float(group["lr"]), dtype=torch.float64, device=dev)}
+            group["_dyn"] = st
+        return st
+
+    def sync_lr(self):
+        """Push group['lr'] (an lr scheduler's product) into the device scalar; call before each replay."""
+        for group in self.param_groups:
+            st = group.get("_dyn")
+            if st is not None:
+                st["lr"].fill_(float(group["lr"]))
+
+    def note_replayed_step(self):
+        """Host bookkeeping after a graph replay: the parameters the captured step touched took one more step."""
+        for group, idx in self._touched:
+            steps = group["_steps"]
+            for q in idx:
+                steps[q] += 1
 
     def _flatten(self, group):
         """Move every parameter of the group into one arena (views keep the nn.Parameter objects intact)."""
@@ -40,7 +75,7 @@ class FusedAdam(torch.optim.Optimizer):
         group["_dev"] = dev
 
     # ---- checkpointing: torch.optim.Adam's layout (state[idx] = {step, exp_avg, exp_avg_sq}), never the arenas ------
-    _PRIVATE = ("_arena", "_offs", "_sizes", "_m", "_v", "_steps", "_dev")
+    _PRIVATE = ("_arena", "_offs", "_sizes", "_m", "_v", "_steps", "_dev", "_dyn")
 
     def state_dict(self):
         """{'state': {param index: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]} - the same shape
@@ -105,6 +140,7 @@ class FusedAdam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
+        self._touched = []
         for group in self.param_groups:
             if not group["params"]:
                 continue
@@ -116,6 +152,23 @@ class FusedAdam(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             ps, offs, sizes, steps = group["params"], group["_offs"], group["_sizes"], group["_steps"]
             arena, m, v = group["_arena"], group["_m"], group["_v"]
+            dyn, touched = None, []
+            if not self._device_scalars:
+                group.pop("_dyn", None)          # a later device-scalar step re-seeds its count from the host's
+            else:
+                live = [steps[q] for q, p in enumerate(ps) if p.grad is not None]
+                if not live:
+                    continue
+                if min(live) != max(live):
+                    raise RuntimeError("FusedAdam device scalars need one step count for all parameters with gradients")
+                st = self._dev_state(group, live[0])
+                # same expressions as the host path (double, then rounded to float by the kernel argument)
+                st["t"].add_(1.0)
+                st["dyn"][0] = st["lr"]
+                st["dyn"][1] = 1.0 - torch.pow(torch.full_like(st["t"], b1), st["t"])
+                st["dyn"][2] = torch.sqrt(1.0 - torch.pow(torch.full_like(st["t"], b2), st["t"]))
+                dyn = st["dyn"]
+                self._touched.append((group, touched))
             # runs of consecutive parameters that have gradients laid out contiguously and share a step count
             i, n = 0, len(ps)
             while i < n:
@@ -138,8 +191,9 @@ class FusedAdam(torch.optim.Optimizer):
                 t = steps[i] + 1
                 call("mx_adam", arena.data_ptr() + 4 * offs[i], gptr, m.data_ptr() + 4 * offs[i], v.data_ptr() + 4 * offs[i],
                      span, float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                     1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), stream())
+                     1.0 - b1 ** t, math.sqrt(1.0 - b2 ** t), ptr(dyn), stream())
                 for q in range(i, j):
                     steps[q] = t
+                    touched.append(q)
                 i = j
         return None

@@ -81,7 +81,10 @@ class _ERLossLowRes(torch.autograd.Function):
         cam_lr, sgc_lr, lwb = cam_lr.contiguous().float(), sgc_lr.contiguous().float(), lwb.contiguous().float()
         N, h, w, L = cam_lr.shape
         K = lwb.shape[1]
-        if k > K * H * W:
+        k_dev = None
+        if torch.is_tensor(k):                    # device-side count (int32[1]): hipGraph replays, see muscle_amd.graph
+            k_dev, k = k.contiguous(), 0
+        elif k > K * H * W:
             raise RuntimeError(f"selected index k={k} out of range for rows of {K * H * W} (torch.topk raises the same)")
         dev = cam_lr.device
         st_u = torch.zeros(3, N, dtype=torch.int32, device=dev)          # krem, prefix, cnt_eq
@@ -89,10 +92,11 @@ class _ERLossLowRes(torch.autograd.Function):
         hcnt = torch.empty(N * _RBINS, dtype=torch.int32, device=dev)
         hsum = torch.empty(N * _RBINS, dtype=torch.float32, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
-        call("mx_er_lr_fwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), N, h, w, L, K, H, W, int(k), ptr(st_u[0]), ptr(st_u[1]),
+        call("mx_er_lr_fwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), N, h, w, L, K, H, W, int(k), ptr(k_dev), ptr(st_u[0]), ptr(st_u[1]),
              ptr(sum_gt), ptr(st_u[2]), ptr(hcnt), ptr(hsum), ptr(loss), stream())
         ctx.save_for_backward(cam_lr, sgc_lr, lwb, st_u)
         ctx.dims = (int(k), H, W)
+        ctx.k_dev = k_dev
         return loss[0]
 
     @staticmethod
@@ -103,11 +107,16 @@ class _ERLossLowRes(torch.autograd.Function):
         out = torch.empty_like(sgc_lr)
         gup = g.contiguous().float().reshape(1)
         call("mx_er_lr_bwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), ptr(st_u[1]), ptr(st_u[0]), ptr(st_u[2]), ptr(gup),
-             1.0 / (N * k), ptr(out), N, h, w, L, lwb.shape[1], H, W, stream())
+             (1.0 / (N * k) if ctx.k_dev is None else 0.0), ptr(ctx.k_dev), ptr(out), N, h, w, L, lwb.shape[1], H, W, stream())
         return None, out, None, None, None, None
 
 
-def er_loss_lowres(cam_lr, sgc_lr, label_with_bg, valid_channel: int, H: int, W: int):
+def er_loss_lowres(cam_lr, sgc_lr, label_with_bg, valid_channel, H: int, W: int):
+    """valid_channel: Python int, or a device scalar (label.sum()) - then k = int(0.2 * valid_channel * H * W) of
+    train_mcl.py:179 is evaluated on the device in the same double arithmetic and never read back."""
+    if torch.is_tensor(valid_channel):
+        k = (((0.2 * valid_channel.detach().double()) * H) * W).to(torch.int32).reshape(1)
+        return _ERLossLowRes.apply(cam_lr, sgc_lr, label_with_bg, k, H, W)
     return _ERLossLowRes.apply(cam_lr, sgc_lr, label_with_bg, int(0.2 * valid_channel * H * W), H, W)
 
 
@@ -126,7 +135,8 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
 
     batch: {"img" [N,3,S,S], "label" [N,20], "view1","view2" [N,3,V,V], "coord1","coord2" [N,4] int64}, CUDA.
     valid_channel: int(label.sum()) if the caller already has it on the host (train_mcl.py:178 reads it
-    back from the device every iteration; passing it avoids that synchronisation).
+    back from the device every iteration; passing it avoids that synchronisation), or the device scalar label.sum()
+    itself (fused_er only): then nothing in phase 1 touches the host and the step can be captured (muscle_amd.graph).
     grad_hook(model, phase): called after each backward and before the optimizer step — the data-parallel
     gradient all-reduce plugs in here (muscle_amd.dist).
     imc_sync: reproduce the reference's Python-float fall-through for IMC with a device->host read

@@ -1,0 +1,110 @@
+"""hipGraph replay of phase 1 of the MCL step (muscle_amd.GraphedStep) against the eager path on the same batches:
+same losses, same parameters after several optimizer steps, with the label set (hence ER's top-k count, now taken on
+the device) changing from batch to batch; and the device-scalar mode of FusedAdam against the host-scalar mode."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from muscle_amd import synth
+from muscle_amd.arch import net_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+T = lambda a: torch.from_numpy(np.asarray(a))  # noqa: E731
+
+
+def build(name, seed):
+    import muscle_amd
+    cfg = net_cfg(name, False)
+    sd = synth.synth_state_dict(cfg, seed)
+    m = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)
+    m.load_state_dict({k: T(v) for k, v in sd.items()}, strict=True)
+    return m.to(DEV)
+
+
+def batches(n, size, count, seed):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for i in range(count):
+        lab = torch.zeros(n, 20)
+        for r in range(n):
+            lab[r, torch.randperm(20, generator=g)[: 1 + (i + r) % 3]] = 1.0       # 1..3 classes, varies per batch
+        lab[1] = lab[0]                                                                # a positive pair for IMC
+        out.append({"img": torch.randn(n, 3, size, size, generator=g).to(DEV), "label": lab.to(DEV)})
+    return out
+
+
+def test_adam_device_scalars_match_host_scalars():
+    import muscle_amd
+    torch.manual_seed(3)
+    ws = [torch.randn(1000, device=DEV), torch.randn(37, 5, device=DEV)]
+    pa = [torch.nn.Parameter(w.clone()) for w in ws]
+    pb = [torch.nn.Parameter(w.clone()) for w in ws]
+    oa = muscle_amd.FusedAdam(pa, lr=1e-3, weight_decay=5e-5)
+    ob = muscle_amd.FusedAdam(pb, lr=1e-3, weight_decay=5e-5).use_device_scalars(True)
+    for t in range(7):
+        if t == 4:
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 3e-4
+            ob.sync_lr()
+        for a, b in zip(pa, pb):
+            g = torch.randn_like(a)
+            a.grad, b.grad = g, g.clone()
+        oa.step(); ob.step()
+    for a, b in zip(pa, pb):
+        # the bias corrections come from torch.pow on the device instead of Python's pow: equal after rounding to float
+        # except for a possible last-place difference of the double result
+        assert gu.rel_err(b.detach().cpu(), a.detach().cpu()) <= 1e-6
+    assert ob.state_dict()["state"][0]["step"] == 7
+
+
+@pytest.mark.parametrize("ep", [0, 4])
+def test_graphed_step_matches_eager(ep):
+    import muscle_amd
+    n, size, count = 4, 64, 6
+    bs = batches(n, size, count, 11)
+    ref, gra = build("efficientnet-b0", 5), build("efficientnet-b0", 5)
+    o_ref = muscle_amd.FusedAdam(ref.parameters(), lr=1e-4, weight_decay=5e-5)
+    o_gra = muscle_amd.FusedAdam(gra.parameters(), lr=1e-4, weight_decay=5e-5)
+    torch.manual_seed(99)
+    want = []
+    for b in bs:
+        out = muscle_amd.mcl_step(ref, o_ref, b, ep)
+        want.append({k: float(v) for k, v in out.items()})
+    step = muscle_amd.GraphedStep(gra, o_gra, ep, warmup=2)
+    torch.manual_seed(99)                       # same drop_connect draws: the graph takes its Philox offset at replay
+    got = []
+    for b in bs:
+        out = step(b)
+        got.append({k: float(v) for k, v in out.items()})
+    assert step.replays == count - 2
+    ers = [w["loss_er"] for w in want]
+    assert max(ers) - min(ers) > 1e-4           # the batches do differ (k follows label.sum())
+    for i, (w, g) in enumerate(zip(want, got)):
+        for k in w:
+            assert abs(w[k] - g[k]) <= 2e-4 * max(abs(w[k]), 1e-3), (i, k, w[k], g[k])
+    pr, pg = dict(ref.named_parameters()), dict(gra.named_parameters())
+    num = sum(float((pr[k].detach() - pg[k].detach()).double().pow(2).sum()) for k in pr)
+    den = sum(float(pr[k].detach().double().pow(2).sum()) for k in pr)
+    assert (num / den) ** 0.5 <= 1e-4
+    for k, v in ref.state_dict().items():       # BatchNorm running statistics and batch counters advance in the replay
+        if "num_batches_tracked" in k:
+            assert int(v) == int(gra.state_dict()[k]), k           # (the unused conv_head BN stays at 0 in both)
+    assert int(gra.state_dict()["backbone._bn0.num_batches_tracked"]) == count
+    assert gu.rel_err(gra.state_dict()["backbone._bn0.running_var"].cpu(), ref.state_dict()["backbone._bn0.running_var"].cpu()) <= 1e-4
+    sa, sb = o_ref.state_dict()["state"], o_gra.state_dict()["state"]
+    assert {k: v["step"] for k, v in sa.items()} == {k: v["step"] for k, v in sb.items()}
+
+
+def test_graphed_step_refuses_phase2_and_shape_change():
+    import muscle_amd
+    m = build("efficientnet-b0", 5)
+    o = muscle_amd.FusedAdam(m.parameters(), lr=1e-4)
+    with pytest.raises(ValueError):
+        muscle_amd.GraphedStep(m, o, 8)
+    step = muscle_amd.GraphedStep(m, o, 0, warmup=1)
+    bs = batches(2, 64, 2, 1)
+    step(bs[0]); step(bs[1])
+    with pytest.raises(ValueError):
+        step(batches(3, 64, 1, 2)[0])

@@ -147,8 +147,10 @@ def main():
     ap.add_argument("--epoch", type=int, default=4, help="epoch gate semantics of train_mcl.py (4: cls+ER+IMC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="replay phase 1 from a captured hipGraph (muscle_amd.GraphedStep; single GPU, epoch < 8): for the "
-                         "launch-bound small-model configs; per-kernel HIP-event timing is off in this mode")
+                    help="timed steps replay phase 1 from a captured hipGraph (muscle_amd.GraphedStep; one GPU, epoch < 8).  Not "
+                         "the default: measured on MI355X the replay saves 0.5 ms of 136 on B7 but serialises the weight-gradient "
+                         "side stream, which is worth 3.6 ms (B7) / 6 % (B0) when launched eagerly")
+    ap.add_argument("--eager", action="store_true", help="(the default; kept for older command lines)")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -188,9 +190,10 @@ def main():
     def step():
         return muscle_amd.mcl_step(model, opt, batch, a.epoch, valid_channel=vc, grad_hook=hook)
 
+    if a.graph and (world > 1 or a.epoch >= 8):
+        raise SystemExit("--graph covers phase 1 on one GPU (epoch < 8)")
+    eager_step = step
     if a.graph:
-        if world > 1:
-            raise SystemExit("--graph is the single-GPU launch-bound path")
         gstep = muscle_amd.GraphedStep(model, opt, a.epoch)
         for _ in range(gstep.warmup + 1):          # eager settling steps + the capturing call
             gstep(batch)
@@ -220,13 +223,26 @@ def main():
     host_t0 = [0.0]
 
     barrier()
-    timer.on = (rank == 0) and not a.graph
     t0 = time.perf_counter()
     for _ in range(a.steps):
         out = step()
     barrier()
     dt = time.perf_counter() - t0
+    # Per-launch HIP events for the roofline: the same work enqueued eagerly right after the timed region, with the
+    # weight-gradient side stream off.  The timed steps cannot carry them: graph replays have no host-side launch to
+    # bracket, and a weight-gradient GEMM that shares the chip with HBM-bound kernels has no duration of its own.
+    from muscle_amd import engine
+    overlap = engine.WGRAD_SIDE_STREAM
+    engine.WGRAD_SIDE_STREAM = False
+    inst_steps = min(a.steps, 3)
+    timer.on = (rank == 0)
+    t1 = time.perf_counter()
+    for _ in range(inst_steps):
+        eager_step()
+    barrier()
+    inst_dt = time.perf_counter() - t1
     timer.on = False
+    engine.WGRAD_SIDE_STREAM = overlap
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -246,7 +262,7 @@ def main():
         sv = cfg.stem_out_size(view)
         stem_v = 28 * cfg.stem_out * sv * sv
         flops_img += 2 * 2 * mv["pointwise"] + 4 * mv["pointwise"] + 2 * 2 * stem_v + 2 * stem_v
-    flops = flops_img * a.batch * a.steps
+    flops = flops_img * a.batch * inst_steps
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -265,14 +281,16 @@ def main():
                                f"MuSCLe({a.model}, last_pooling=False, 21 classes), random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
                    "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused",
-                   "launch": "hipGraph replay" if a.graph else "eager"},
+                   "launch": ("hipGraph replay" if a.graph else "eager") + (", weight-gradient GEMMs on a second stream" if overlap else "")},
         "losses": {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in out.items()},
         "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> / gemm_kernel<*> (exact-fp32 MFMA pointwise convs: fwd + dgrad on v_mfma_f32_16x16x4_f32, wgrad on 32x32x2; stem)",
                      "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
-                     "launches_per_step": gemm_launches // max(a.steps, 1),
+                     "measured_over": f"{inst_steps} eager steps right after the timed region (HIP events per launch, weight-gradient "
+                                      f"side stream off; {inst_dt / inst_steps * 1e3:.1f} ms/step in that mode)",
+                     "launches_per_step": gemm_launches // max(inst_steps, 1),
                      "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
-                     "time_share_of_step": gemm_ms * 1e-3 / dt,
+                     "time_share_of_step": gemm_ms * 1e-3 / inst_dt,
                      "algorithmic_gflop_per_image": flops_img / 1e9},
     }
     if (a.model, a.size, full) == ("efficientnet-b7", 448, False):
@@ -286,8 +304,8 @@ def main():
         res["roofline"]["hbm_kernel"] = {"kernel": f"dw_bwd_fused_kernel<{worst[0][1:]}> (stride-1 depthwise backward, 3 reads + 1 write)",
                                          "achieved": worst[1]["GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                          "frac": worst[1]["GBps"] / HBM_PEAK_GBPS,
-                                         "ms_per_step": worst[1]["ms"] / max(a.steps, 1),
-                                         "all": {k: {"GBps": round(v["GBps"], 1), "ms_per_step": round(v["ms"] / max(a.steps, 1), 3)} for k, v in dws.items()}}
+                                         "ms_per_step": worst[1]["ms"] / max(inst_steps, 1),
+                                         "all": {k: {"GBps": round(v["GBps"], 1), "ms_per_step": round(v["ms"] / max(inst_steps, 1), 3)} for k, v in dws.items()}}
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.size, view, a.epoch)
     print(json.dumps(res))

@@ -306,11 +306,15 @@ static void launch(const GemmArgs& g, int batch_or_splits, hipStream_t st) {
   constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
   const int mt = cdiv(g.M, BM), nt = cdiv(g.N, BN);
   static const int xcd_mode = getenv("MX_GEMM_XCD") ? atoi(getenv("MX_GEMM_XCD")) : 1;
+  // experiment knob: unused dynamic LDS for the weight-gradient kernels, which caps their workgroups per CU and so leaves
+  // wave slots to the HBM-bound kernels of the main stream while they run on the side stream
+  static const int tn_pad = getenv("MX_WGRAD_LDS_PAD") ? atoi(getenv("MX_WGRAD_LDS_PAD")) : 0;
+  const int dyn = LAYOUT == L_TN ? tn_pad : 0;
   if (LAYOUT != L_TN && xcd_mode && nt >= 2 && nt <= 16 && mt >= 64) {     // 17..32 N tiles measured: 1-5 % slower
     GemmArgs a = g;
     a.xcd_nt = nt; a.mt = mt;
     dim3 grid(8 * cdiv(mt, 8) * nt, 1, batch_or_splits);
-    hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), dyn, st, a);
     return;
   }
   // weight gradient: measured win only for the stage-2 layers (401 408 rows, 2-6 output tiles: 277 -> 236, 331 -> 255 us);
@@ -319,13 +323,13 @@ static void launch(const GemmArgs& g, int batch_or_splits, hipStream_t st) {
     GemmArgs a = g;
     a.xcd_nt = nt; a.mt = mt; a.zt = batch_or_splits;
     dim3 grid(8 * cdiv(batch_or_splits, 8) * mt * nt, 1, 1);
-    hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), dyn, st, a);
     return;
   }
   GemmArgs a = g;
   a.xcd_nt = 0; a.mt = mt; a.zt = batch_or_splits;
   dim3 grid(mt, nt, batch_or_splits);
-  hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), 0, st, a);
+  hipLaunchKernelGGL((gemm_kernel<LAYOUT, WM, WN, TM, TN, BK>), grid, dim3(256), dyn, st, a);
 }
 
 // Tile configurations (block tile BM x BN; 4 waves).  EfficientNet's channel counts (48, 80, 160, 224, 288, 480,

@@ -269,12 +269,13 @@ class GradSink:
 
 
 FUSED_DW_BACKWARD = True
-# Optional (MUSCLE_WGRAD_STREAM=1): weight-gradient GEMMs on a second HIP stream.  Nothing in the backward chain consumes
-# them (only the optimizer does), they are MFMA-bound and the chain between two of them (BN backward, SE, depthwise) is
-# HBM-bound.  Measured on MI355X, B7/448/bs32: 162.0 -> 156.3 ms/step (+3.6 %), whether the weight gradient starts with
-# or after its data-gradient twin - both kernels fill every CU's wave slots, so the second one only trickles in.  Off by
-# default: under overlap the per-launch GEMM durations bench.py reports as roofline.achieved stop meaning anything.
-WGRAD_SIDE_STREAM = os.environ.get("MUSCLE_WGRAD_STREAM", "0") == "1"
+# Weight-gradient GEMMs on a second HIP stream (MUSCLE_WGRAD_STREAM=0 turns it off; `engine.WGRAD_SIDE_STREAM` can be
+# flipped at run time).  Nothing in the backward chain consumes them (only the optimizer and the gradient exchange do),
+# they are MFMA-bound, and the chain between two of them (BN backward, SE, depthwise) is HBM-bound.  Measured on
+# MI355X, B7/448/bs32: round 1 162.0 -> 156.3 ms/step (+3.6 %), whether the weight gradient starts with or after its
+# data-gradient twin - both kernels fill every CU's wave slots, so the second one only trickles in.  Under overlap the
+# duration of a single launch says nothing about the kernel: bench.py takes its per-launch HIP events with this off.
+WGRAD_SIDE_STREAM = os.environ.get("MUSCLE_WGRAD_STREAM", "1") == "1"
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
@@ -282,10 +283,11 @@ class _WgradLane:
     def __init__(self, device):
         self.s = None
         self.pending = []
+        self.keep = []
         if WGRAD_SIDE_STREAM:
             key = device.index if device.index is not None else torch.cuda.current_device()
             if key not in _side_streams:
-                _side_streams[key] = torch.cuda.Stream(device=device)
+                _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MUSCLE_WGRAD_PRIO", "0")))
             self.s = _side_streams[key]
 
     def wgrad(self, G, X, dW, **kw):
@@ -303,15 +305,27 @@ class _WgradLane:
         with torch.cuda.stream(self.s):
             for G, X, dW, kw in self.pending:
                 ops.pw_wgrad(G, X, dW, **kw)
-        for G, X, _, _ in self.pending:                      # the caller drops these before the side stream has read them
-            G.record_stream(self.s)
-            X.record_stream(self.s)
+        # the caller drops G and X before the side stream has read them: they stay referenced until join() (one dz per
+        # block, ~10 GB for B7/448/bs32 of 288; no record_stream, so the same code can be captured into a hipGraph)
+        self.keep.extend((G, X) for G, X, _, _ in self.pending)
         self.pending = []
+
+    def progress(self, done, module):
+        """Data parallelism: report `module`'s (and every later block's) gradients complete.  The exchange it may start
+        must come after the kernels of BOTH streams, so it is issued from the side stream once that has caught up with
+        the main one."""
+        if self.s is None:
+            return done(module)
+        self.flush()
+        self.s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.s):
+            done(module)
 
     def join(self):
         self.flush()
         if self.s is not None:
             torch.cuda.current_stream().wait_stream(self.s)
+        self.keep = []
 
 
 def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, torch.Tensor], sink: GradSink):
@@ -397,7 +411,7 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         else:
             g_out = gx
         done = getattr(sink, "block_done", None)
-        if done is not None and not WGRAD_SIDE_STREAM:
-            done(m)                  # this block's (and every later block's) parameter gradients are enqueued
+        if done is not None and getattr(sink, "on_ready", None) is not None:
+            lane.progress(done, m)   # this block's (and every later block's) parameter gradients are enqueued
     lane.join()
     return

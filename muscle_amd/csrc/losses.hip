@@ -481,10 +481,25 @@ __device__ __forceinline__ int lr_pixel(const float* cam, const float* sgc, int 
   const float* s00 = sgc + base + ((long)y0 * w + x0) * L; const float* s01 = sgc + base + ((long)y0 * w + x1) * L;
   const float* s10 = sgc + base + ((long)y1 * w + x0) * L; const float* s11 = sgc + base + ((long)y1 * w + x1) * L;
   float ma = -INFINITY, mb = -INFINITY;
-  for (int k = 1; k < K; ++k) {
-    a[k] = (1.f - wy) * ((1.f - wx) * c00[k] + wx * c01[k]) + wy * ((1.f - wx) * c10[k] + wx * c11[k]);
-    b[k] = (1.f - wy) * ((1.f - wx) * s00[k] + wx * s01[k]) + wy * ((1.f - wx) * s10[k] + wx * s11[k]);
-    ma = fmaxf(ma, a[k]); mb = fmaxf(mb, b[k]);
+  // cells are L floats apart with L % 4 == 0 (checked by the callers): 16-byte loads, four classes per step; the
+  // interpolation of each class is the same expression as before (bit-identical)
+  const float u00 = (1.f - wx), u01 = wx, v0 = (1.f - wy), v1 = wy;
+  for (int k4 = 0; k4 < K; k4 += 4) {
+    const float4 p00 = ld4(c00 + k4), p01 = ld4(c01 + k4), p10 = ld4(c10 + k4), p11 = ld4(c11 + k4);
+    const float4 q00 = ld4(s00 + k4), q01 = ld4(s01 + k4), q10 = ld4(s10 + k4), q11 = ld4(s11 + k4);
+    const float av[4] = {v0 * (u00 * p00.x + u01 * p01.x) + v1 * (u00 * p10.x + u01 * p11.x),
+                         v0 * (u00 * p00.y + u01 * p01.y) + v1 * (u00 * p10.y + u01 * p11.y),
+                         v0 * (u00 * p00.z + u01 * p01.z) + v1 * (u00 * p10.z + u01 * p11.z),
+                         v0 * (u00 * p00.w + u01 * p01.w) + v1 * (u00 * p10.w + u01 * p11.w)};
+    const float bv[4] = {v0 * (u00 * q00.x + u01 * q01.x) + v1 * (u00 * q10.x + u01 * q11.x),
+                         v0 * (u00 * q00.y + u01 * q01.y) + v1 * (u00 * q10.y + u01 * q11.y),
+                         v0 * (u00 * q00.z + u01 * q01.z) + v1 * (u00 * q10.z + u01 * q11.z),
+                         v0 * (u00 * q00.w + u01 * q01.w) + v1 * (u00 * q10.w + u01 * q11.w)};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = k4 + j;
+      if (k >= 1 && k < K) { a[k] = av[j]; b[k] = bv[j]; ma = fmaxf(ma, av[j]); mb = fmaxf(mb, bv[j]); }
+    }
   }
   float sa = 0.f, sb = 0.f;
   for (int k = 1; k < K; ++k) { a[k] = __expf(a[k] - ma); sa += a[k]; b[k] = __expf(b[k] - mb); sb += b[k]; }
@@ -680,7 +695,8 @@ int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, in
                  const int* k_dev, unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum,
                  float* loss, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && krem && prefix && sum_gt && cnt_eq && hcnt && hsum && loss, "er_lr_fwd: null pointer");
-  MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && H > 0 && W > 0, "er_lr_fwd: bad extents");
+  MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L % 4 == 0 && H > 0 && W > 0, "er_lr_fwd: bad extents (L must be a multiple of 4)");
+  MX_CHECK_ARG((((uintptr_t)cam | (uintptr_t)sgc) & 15) == 0, "er_lr_fwd: maps must be 16-byte aligned");
   MX_CHECK_ARG(k_dev || (k >= 1 && k <= (long)K * H * W), "er_lr_fwd: k=%ld out of range for rows of %ld (torch.topk would raise)", k, (long)K * H * W);
   hipStream_t st = (hipStream_t)stream;
   if (k_dev) hipLaunchKernelGGL(er_krem_init_kernel, dim3(1), dim3(64), 0, st, krem, N, k_dev);
@@ -707,7 +723,8 @@ int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const uns
                  const unsigned* cnt_eq, const float* gup, float gscale, const int* k_dev, float* gsgc, int N, int h, int w, int L,
                  int K, int H, int W, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && prefix && krem && cnt_eq && gsgc, "er_lr_bwd: null pointer");
-  MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L <= 256 && H > 0 && W > 0, "er_lr_bwd: bad extents");
+  MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L % 4 == 0 && L <= 256 && H > 0 && W > 0, "er_lr_bwd: bad extents (L must be a multiple of 4)");
+  MX_CHECK_ARG((((uintptr_t)cam | (uintptr_t)sgc) & 15) == 0, "er_lr_bwd: maps must be 16-byte aligned");
   if (K == 21) {
     // rows per band: the largest count that keeps a band within one low-res row spacing (at most three low-res rows touched)
     int ty = (h > 1) ? (H - 1) / (h - 1) : H;

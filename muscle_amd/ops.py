@@ -26,6 +26,29 @@ def _f32(*shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
+# Zero-initialised accumulators (pooled sums, SE / BN1 partials): ~230 per B7 step, each a 5 us fill launch of its own.
+# They are carved out of 32 MB slabs that one memset clears (keyed by stream: a slab is only valid behind its memset).
+_zslabs: dict = {}
+_ZSLAB_FLOATS = 8 << 20
+
+
+def _zeros(*shape, device):
+    n = 1
+    for d in shape:
+        n *= d
+    n4 = (n + 3) // 4 * 4
+    if n4 > _ZSLAB_FLOATS // 4 or torch.cuda.is_current_stream_capturing():
+        return torch.zeros(shape, dtype=torch.float32, device=device)   # (captured graphs must re-clear at every replay)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
+    ent = _zslabs.get(key)
+    if ent is None or ent[1] + n4 > _ZSLAB_FLOATS:
+        ent = [torch.zeros(_ZSLAB_FLOATS, dtype=torch.float32, device=device), 0]
+        _zslabs[key] = ent
+    out = ent[0][ent[1]:ent[1] + n].view(shape)
+    ent[1] += n4
+    return out
+
+
 # ---- GEMMs ------------------------------------------------------------------------------------
 def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None, rows_per_sample=1,
            bias=None, residual=None, relu=False, want_stats=False, out=None, ldc=None):
@@ -214,7 +237,7 @@ def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNStat
 def se_bn1_pool(dA2d, X2d, st: BNState, rows_per_sample):
     rows, C = X2d.shape
     N = rows // rows_per_sample
-    out = torch.zeros(5, N, C, dtype=torch.float32, device=X2d.device)
+    out = _zeros(5, N, C, device=X2d.device)
     call("mx_se_bn1_pool", ptr(dA2d), ptr(X2d), ptr(st.scale), ptr(st.shift), rows, C, rows_per_sample, ptr(out), stream())
     return out
 
@@ -228,7 +251,7 @@ def bn1_sums(pooled5, gate, add):
 
 def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=False):
     rows, C = X2d.shape
-    out = torch.zeros(rows // rows_per_sample, C, dtype=torch.float32, device=X2d.device)
+    out = _zeros(rows // rows_per_sample, C, device=X2d.device)
     call("mx_pool_sum", ptr(X2d), ptr(G), ptr(st.scale) if st else None, ptr(st.shift) if st else None, int(act), rows, C,
          rows_per_sample, ptr(out), stream())
     return out
@@ -240,7 +263,7 @@ def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, want
     N, H, Wd, C = X.shape
     Y = _f32(N, Ho, Wo, C, device=X.device)
     stats = _f32(lib().mx_dwconv_fwd_parts(N, Ho, Wo, S), 2, C, device=X.device) if want_stats else None
-    pooled = torch.zeros(N, C, dtype=torch.float32, device=X.device) if pool is not None else None
+    pooled = _zeros(N, C, device=X.device) if pool is not None else None
     call("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),
          ptr(pool[0]) if pool is not None else None, ptr(pool[1]) if pool is not None else None, ptr(pooled),
          N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())

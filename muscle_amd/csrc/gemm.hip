@@ -427,86 +427,83 @@ static void dispatch(const GemmArgs& g, int zdim, hipStream_t st) {
 // prefetched into registers during MFMA + store): 173 registers, 2 workgroups per CU, 205 vs 163 us on K = 48 -> N = 288.
 // More resident workgroups of the simple structure beat software pipelining inside one workgroup here.
 
-// ---- epilogue of the NT kernel: accumulator (lane = column 16j + l15, registers = rows 4q + r) -> bias / residual
-// / relu / statistics in that layout, then through a per-wave LDS patch to 16-byte row stores.  Every wave must be out of
-// the main loop (operand images are overwritten).  `smem` needs 4*16*(TN*16+4) + WM*2*BN floats.
+// ---- epilogue of the NT kernel.  The main loop feeds the WEIGHT rows as the MFMA's first operand and the activation rows
+// as its second, so a lane's four accumulator registers are four CONSECUTIVE OUTPUT CHANNELS of one pixel row
+// (acc[i][j][r] = C[m = 16 i + l15][n = 16 j + 4 q + r]): bias, residual, relu and the 16-byte non-temporal store need
+// no exchange at all (round-2 first version: through a per-wave LDS patch, 64 ds_write_b32 + 16 ds_read_b128 per lane).
+// Column statistics: per-lane sums over the TM row tiles, then a rotate-and-add over the 16 lanes of a DPP row.
+// `smem` needs WM*2*BN floats (statistics only); every wave must be out of the main loop.
+static __device__ __forceinline__ float row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+
 template <int WM, int WN, int TM, int TN>
 static __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, float* C, int tile_m, int m0, int n0, f32x4 (&acc)[TM][TN],
                                                    float* smem, int tid) {
-  constexpr int BN = WN * TN * 16, PS = TN * 16 + 4;
+  constexpr int BN = WN * TN * 16;
   const int lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   const int wm = wave / WN, wn = wave % WN;
-  float* patch = smem + wave * (16 * PS);
-  float* red = smem + 4 * 16 * PS;                           // [WM][2][BN]
-  const bool early = !g.residual || g.stats;                 // residual needed before the statistics: scalar loads here
+  float* red = smem;                                         // [WM][2][BN]
   const bool vec = ((g.ldc | g.N) & 3) == 0;
-  float cs[TN], cq[TN];
+  f32x4 cs[TN], cq[TN];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) cs[j] = cq[j] = 0.f;
+  for (int j = 0; j < TN; ++j) cs[j] = cq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    const int rbase = m0 + wm * TM * 16 + 16 * i;
+  for (int j = 0; j < TN; ++j) {
+    const int col = n0 + wn * TN * 16 + 16 * j + 4 * q;
+    const bool full = vec && col + 3 < g.N;
+    float b[4] = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = n0 + wn * TN * 16 + 16 * j + l15;
-      const bool cok = col < g.N;
-      const float bias = (g.bias && cok) ? g.bias[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = rbase + 4 * q + r;
-        float v = acc[i][j][r] + bias;
-        if (early) {
-          if (g.residual && cok && row < g.M) v += g.residual[(long)row * g.ldc + col];
-          if (g.relu) v = fmaxf(v, 0.f);
-          if (cok && row < g.M) { cs[j] += v; cq[j] += v * v; }
-        }
-        patch[(4 * q + r) * PS + 16 * j + l15] = v;
-      }
+      for (int e = 0; e < 4; ++e) if (col + e < g.N) b[e] = g.bias[col + e];
     }
-    // rows of the patch: 16 rows x TN*4 float4
 #pragma unroll
-    for (int t = 0; t < TN; ++t) {
-      const int f = lane + 64 * t;
-      const int rl = f / (4 * TN), c4 = (f - rl * (4 * TN)) * 4;
-      const int row = rbase + rl, colb = n0 + wn * TN * 16 + c4;
-      float4 v4 = ld4(patch + rl * PS + c4);
-      if (row < g.M && colb < g.N) {
-        const long idx = (long)row * g.ldc + colb;
-        float v[4] = {v4.x, v4.y, v4.z, v4.w};
-        const bool full = vec && colb + 3 < g.N;
-        if (!early) {
-          if (full) {
-            const float4 r4 = ld4(g.residual + idx);
-            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) if (colb + e < g.N) v[e] += g.residual[idx + e];
-          }
-          if (g.relu) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-          }
-        }
+    for (int i = 0; i < TM; ++i) {
+      const int row = m0 + wm * TM * 16 + 16 * i + l15;
+      if (row >= g.M || col >= g.N) continue;
+      const long idx = (long)row * g.ldc + col;
+      float v[4] = {acc[i][j][0] + b[0], acc[i][j][1] + b[1], acc[i][j][2] + b[2], acc[i][j][3] + b[3]};
+      if (g.residual) {
         if (full) {
-          f32x4 o = {v[0], v[1], v[2], v[3]};
-          __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + idx));
+          const float4 r4 = ld4(g.residual + idx);
+          v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
         } else {
 #pragma unroll
-          for (int e = 0; e < 4; ++e) if (colb + e < g.N) C[idx + e] = v[e];
+          for (int e = 0; e < 4; ++e) if (col + e < g.N) v[e] += g.residual[idx + e];
         }
+      }
+      if (g.relu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float u = (col + e < g.N) ? v[e] : 0.f;
+        cs[j][e] += u; cq[j][e] += u * u;
+      }
+      if (full) {
+        f32x4 o = {v[0], v[1], v[2], v[3]};
+        __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(C + idx));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (col + e < g.N) C[idx + e] = v[e];
       }
     }
   }
   if (g.stats) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      float s = cs[j], sq = cq[j];
-      s += __shfl_xor(s, 16, 64); sq += __shfl_xor(sq, 16, 64);
-      s += __shfl_xor(s, 32, 64); sq += __shfl_xor(sq, 32, 64);
-      if (lane < 16) {
-        red[(wm * 2 + 0) * BN + wn * TN * 16 + 16 * j + l15] = s;
-        red[(wm * 2 + 1) * BN + wn * TN * 16 + 16 * j + l15] = sq;
+      f32x4 s, sq;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s[e] = row16_sum(cs[j][e]); sq[e] = row16_sum(cq[j][e]); }
+      if (l15 == 0) {
+        *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * BN + wn * TN * 16 + 16 * j + 4 * q) = s;
+        *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * BN + wn * TN * 16 + 16 * j + 4 * q) = sq;
       }
     }
     __syncthreads();
@@ -541,7 +538,7 @@ __global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kerne
   constexpr int PA = (BM * 4 + 255) / 256, PB = (BN * 4 + 255) / 256;
   constexpr int SMEM = 2 * (BM + BN) * LS;
   static_assert(WM * WN == 4, "four waves");
-  static_assert(4 * 16 * (TN * 16 + 4) + WM * 2 * BN <= SMEM, "epilogue staging does not fit the operand buffers");
+  static_assert(WM * 2 * BN <= SMEM, "statistics staging does not fit the operand buffers");
   __shared__ __attribute__((aligned(16))) float smem[SMEM];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
@@ -645,7 +642,7 @@ __global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kerne
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i][st], bv[j][st], acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[j][st], av[i][st], acc[i][j], 0, 0, 0);   // D[n][m]: see nt_epilogue
     __syncthreads();
   }
   MX_GEMM_STAMP(g, 2);

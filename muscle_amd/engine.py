@@ -67,6 +67,8 @@ class Tape:
     H0: int = 0
     W0: int = 0
     blocks: List[BlockTape] = field(default_factory=list)
+    wt: Dict[int, torch.Tensor] = field(default_factory=dict)     # id(conv weight) -> transposed copy for the data gradient
+    wt_event: Optional["torch.cuda.Event"] = None                 # ... valid on the main stream after this event
 
 
 _keep_cache: Dict[tuple, torch.Tensor] = {}
@@ -142,6 +144,26 @@ def _block_forward_eval(m, b: BlockCfg, f, ident, x, x_st, N, h, w, ho, wo):
 EVAL_FOLD = os.environ.get("MUSCLE_EVAL_FOLD", "1") == "1"
 
 
+def _prefetch_transposes(backbone, cfg: NetCfg, tape: Tape, dev):
+    """The data-gradient GEMMs run as forward GEMMs against W^T (ops.pw_dgrad).  The ~110 small transposes depend on
+    nothing but the weights, so they are issued on the side stream at the start of the forward, where they fill the gaps
+    of the main stream's kernel chain instead of sitting on the backward's critical path (5 + 2 us each there)."""
+    if not (WGRAD_SIDE_STREAM and ops.DGRAD_AS_FORWARD):
+        return
+    side = _WgradLane(dev).s
+    side.wait_stream(torch.cuda.current_stream())            # the optimizer step that produced these weights
+    with torch.cuda.stream(side):
+        for b in cfg.blocks:
+            m = _blk(backbone, b.index)
+            if b.expand and b.cexp % 4 == 0:
+                w = m._expand_conv.weight
+                tape.wt[id(w)] = ops.transpose(w.view(b.cexp, b.cin))
+            if b.cout % 4 == 0:
+                w = m._project_conv.weight
+                tape.wt[id(w)] = ops.transpose(w.view(b.cout, b.cexp))
+        tape.wt_event = side.record_event()
+
+
 def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
                      drop_u: Optional[Dict[int, torch.Tensor]] = None, save: bool = True) -> Tape:
     """img: NCHW fp32 CUDA.  Returns the tape; block outputs are tape.blocks[i].out (NHWC).
@@ -154,6 +176,8 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
     lo, hi = cfg.stem_pad
     H0, W0 = (H + lo + hi - 3) // 2 + 1, (W + lo + hi - 3) // 2 + 1
     tape.H0, tape.W0 = H0, W0
+    if training and save:
+        _prefetch_transposes(backbone, cfg, tape, dev)
     # stem: im2col + MFMA GEMM (K = 27 padded to 28), BN statistics in the GEMM epilogue
     tape.cols = ops.stem_im2col(img, H0, W0, lo)
     C0 = cfg.stem_out
@@ -334,6 +358,8 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
     N, training = tape.N, tape.training
     g_out: Optional[torch.Tensor] = None
     lane = _WgradLane(tape.blocks[0].out.device)
+    if tape.wt_event is not None:
+        torch.cuda.current_stream().wait_event(tape.wt_event)
     for t in reversed(tape.blocks):
         b, m = t.cfg, _blk(backbone, t.cfg.index)
         tg = tap_grads.get(b.index)
@@ -355,7 +381,8 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         else:
             lane.wgrad(dp, d2, sink.of(m._project_conv.weight).view(b.cout, b.cexp), x_mode=ops.BNACT, x_scale=t.bn1.scale,
                        x_shift=t.bn1.shift, x_gate=t.gate, rows_per_sample=hw)
-        ga = ops.pw_dgrad(dp, m._project_conv.weight.view(b.cout, b.cexp), b.cexp)          # dL/d(act*gate) [Mo,Cexp]
+        ga = ops.pw_dgrad(dp, m._project_conv.weight.view(b.cout, b.cexp), b.cexp,
+                          wt=tape.wt.get(id(m._project_conv.weight)))                         # dL/d(act*gate) [Mo,Cexp]
         lane.flush()
         del dp
         # One pass over (ga, d_raw) yields the SE gate gradient sum_hw ga*act AND the per-sample pieces of the BN1 backward
@@ -398,7 +425,7 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
                                      act=dw_st, out=gx2)
             if b.expand:
                 lane.wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
-                g_in = ops.pw_dgrad(dz, m._expand_conv.weight.view(b.cexp, b.cin), b.cin,
+                g_in = ops.pw_dgrad(dz, m._expand_conv.weight.view(b.cexp, b.cin), b.cin, wt=tape.wt.get(id(m._expand_conv.weight)),
                                     residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)
                 lane.flush()
                 g_out = g_in.view(N, t.H, t.W, b.cin)

@@ -76,13 +76,13 @@ def transpose(W):
 DGRAD_AS_FORWARD = True      # dX = G W as a forward GEMM against W^T (row-major LDS images, 16-column tiles); False: NN kernel
 
 
-def pw_dgrad(G, W, N_in, *, residual=None, out=None):
-    """G: [M, K=Cout]; W: [Cout, Cin] -> dX [M, Cin]."""
+def pw_dgrad(G, W, N_in, *, residual=None, out=None, wt=None):
+    """G: [M, K=Cout]; W: [Cout, Cin] -> dX [M, Cin].  wt: W^T [Cin, Cout] if the caller already has it."""
     M, K = G.shape
     if out is None:
         out = _f32(M, N_in, device=G.device)
     if DGRAD_AS_FORWARD and K % 4 == 0:
-        call("mx_pw_fwd", ptr(G), PLAIN, None, None, None, 1, ptr(transpose(W)), ptr(out), M, K, N_in, G.stride(0), N_in,
+        call("mx_pw_fwd", ptr(G), PLAIN, None, None, None, 1, ptr(wt if wt is not None else transpose(W)), ptr(out), M, K, N_in, G.stride(0), N_in,
              None, ptr(residual), 0, None, stream())
         return out
     call("mx_pw_dgrad", ptr(G), ptr(W), ptr(out), M, K, N_in, G.stride(0), N_in, ptr(residual), stream())

@@ -112,6 +112,11 @@ int mx_pool_sum(const float* X, const float* G, const float* scale, const float*
 int mx_se_bn1_pool(const float* dA, const float* X, const float* scale, const float* shift, long rows, int C, int rows_per_sample,
                    float* out5, void* stream);
 int mx_bn1_sums(const float* pooled5, const float* gate, const float* add, int N, int C, float* part, void* stream);
+/* The same sums followed by mx_bn_bwd_finalize on them, in one launch (one row per channel, nothing to reduce across
+ * workgroups): dgamma/dbeta += and the coefficients c1, c2, c3 of dX = c1*g + c2*X + c3. */
+int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* add, int N, int C, double count,
+                         const float* gamma, const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
+                         float* c1, float* c2, float* c3, void* stream);
 
 /* ---- depthwise k x k convolution, k in {3,5}, stride in {1,2}: model.py:50-52,78; utils.py:122-145 ---- */
 
@@ -148,7 +153,8 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
 int mx_se_fwd(const float* pooled_sum, float inv_hw, const float* W1, const float* b1, const float* W2, const float* b2,
               float* s, float* h, float* gate, int N, int C, int SQ, void* stream);
 
-/* given ggate[n,c] = dL/dgate: add[n,c] = (dL/ds)[n,c]*inv_hw; dW1,db1,dW2,db2 +=; gh_scratch: N*SQ floats */
+/* given ggate[n,c] = dL/dgate: add[n,c] += (dL/ds)[n,c]*inv_hw (`add` is handed in ZERO-FILLED: it is accumulated
+ * across squeeze slices); dW1,db1,dW2,db2 +=; gh_scratch: N*SQ floats */
 int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W1, const float* W2,
               float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, float* gh_scratch, int N, int C,
               int SQ, void* stream);

@@ -414,6 +414,23 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* pa
   else bn_fwd_finalize_one(c, s0, s1, f.count, f.gamma, f.beta, f.rmean, f.rvar, f.momentum, f.eps, 1, f.scale, f.shift, f.mean_out, f.rstd_out);
 }
 
+// bn1_sums + the BN1 backward finalisation in one launch (the sums are one row per channel: nothing to reduce across
+// workgroups).  Same arithmetic as bn1_sums_kernel followed by bn_reduce_finalize_kernel<true> on its single fp32 row.
+__global__ void bn1_sums_finalize_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* add, int N, int C,
+                                         BnBwdFin b) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const long plane = (long)N * C;
+  double s0 = 0.0, s1 = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const long i = (long)n * C + c;
+    s0 += (double)gate[i] * pooled[plane + i] + (double)add[i] * pooled[2 * plane + i];
+    s1 += (double)gate[i] * pooled[3 * plane + i] + (double)add[i] * pooled[4 * plane + i];
+  }
+  bn_bwd_finalize_one(c, (double)(float)s0, (double)(float)s1, b.count, b.gamma, b.mean, b.rstd, b.training, b.dgamma, b.dbeta,
+                      b.c1, b.c2, b.c3);
+}
+
 // ---------------------------------------------------------------------------
 // streaming elementwise kernels
 // ---------------------------------------------------------------------------
@@ -566,6 +583,17 @@ int mx_se_bn1_pool(const float* dA, const float* X, const float* scale, const fl
 int mx_bn1_sums(const float* pooled5, const float* gate, const float* add, int N, int C, float* part, void* stream) {
   MX_CHECK_ARG(pooled5 && gate && add && part && N > 0 && C > 0, "bn1_sums: bad args");
   hipLaunchKernelGGL(bn1_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, pooled5, gate, add, N, C, part);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* add, int N, int C, double count,
+                         const float* gamma, const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
+                         float* c1, float* c2, float* c3, void* stream) {
+  MX_CHECK_ARG(pooled5 && gate && add && N > 0 && C > 0 && count > 0, "bn1_sums_finalize: bad args");
+  MX_CHECK_ARG(gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3, "bn1_sums_finalize: null pointer");
+  BnBwdFin b{count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3};
+  hipLaunchKernelGGL(bn1_sums_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, pooled5, gate, add, N, C, b);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

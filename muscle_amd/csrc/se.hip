@@ -193,7 +193,7 @@ int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float
 
   size_t shb = (size_t)2 * N * SE_JB * sizeof(float);
   MX_CHECK_ARG(shb <= 48 * 1024, "se_bwd: N=%d too large for LDS staging", N);
-  hipMemsetAsync(add, 0, sizeof(float) * (size_t)N * C, (hipStream_t)stream);
+  // `add` is accumulated with atomics across the squeeze slices: the CALLER hands it in zero-filled
   if (SQ % 4 == 0 && ((uintptr_t)W2 & 15) == 0)
     hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 16)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
                        C, SQ);

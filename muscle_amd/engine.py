@@ -397,8 +397,7 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         fused = FUSED_DW_BACKWARD and b.stride == 1 and b.pad_lo == (b.kernel - 1) // 2
         if fused:
             # stride 1: BN1 data gradient, depthwise weight + data gradients and the BN0 backward sums in one kernel
-            c1 = ops.bn_bwd_coeffs(ops.bn1_sums(pooled5, t.gate, add), Mo, m._bn1, t.bn1, sink.of(m._bn1.weight),
-                                   sink.of(m._bn1.bias), training)
+            c1 = ops.bn1_coeffs(pooled5, t.gate, add, Mo, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training)
             gx, part0 = ops.dwconv_bwd_fused(ga.view(N, t.Ho, t.Wo, b.cexp), t.d_raw, t.gate, add, t.bn1, c1, dw_in, dw_st,
                                              m._depthwise_conv.weight, sink.of(m._depthwise_conv.weight), b.kernel, b.pad_lo,
                                              residual=None if dw_st is not None else skip_res)

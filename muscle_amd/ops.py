@@ -249,6 +249,15 @@ def bn1_sums(pooled5, gate, add):
     return part
 
 
+def bn1_coeffs(pooled5, gate, add, rows, bn, st: BNState, dgamma, dbeta, training: bool):
+    """bn1_sums + bn_bwd_coeffs in one launch: the [3,C] coefficients of the BN1 data gradient, dgamma/dbeta (+=)."""
+    _, N, C = pooled5.shape
+    c = _f32(3, C, device=gate.device)
+    call("mx_bn1_sums_finalize", ptr(pooled5), ptr(gate), ptr(add), N, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd),
+         int(training), ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]), stream())
+    return c
+
+
 def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=False):
     rows, C = X2d.shape
     out = _zeros(rows // rows_per_sample, C, device=X2d.device)
@@ -300,7 +309,7 @@ def se_fwd(pooled, inv_hw, W1, b1, W2, b2):
 def se_bwd(ggate, gate, s, h, W1, W2, inv_hw, dW1, db1, dW2, db2):
     N, C = ggate.shape
     SQ = W1.shape[0]
-    add = torch.empty_like(ggate)
+    add = _zeros(N, C, device=ggate.device)          # accumulated with atomics: handed in zero-filled
     gh = torch.empty_like(h)
     call("mx_se_bwd", ptr(ggate), ptr(gate), ptr(s), ptr(h), ptr(W1), ptr(W2), float(inv_hw), ptr(add), ptr(dW1), ptr(db1),
          ptr(dW2), ptr(db2), ptr(gh), N, C, SQ, stream())

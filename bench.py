@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--epoch", type=int, default=4, help="epoch gate semantics of train_mcl.py (4: cls+ER+IMC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="skip the extra K steps in split-MFMA arithmetic (reported as split_mfma)")
     ap.add_argument("--graph", action="store_true",
                     help="timed steps replay phase 1 from a captured hipGraph (muscle_amd.GraphedStep; one GPU, epoch < 8).  Not "
                          "the default: measured on MI355X the replay saves 0.5 ms of 136 on B7 but serialises the weight-gradient "
@@ -243,6 +244,27 @@ def main():
     inst_dt = time.perf_counter() - t1
     timer.on = False
     engine.WGRAD_SIDE_STREAM = overlap
+    # Reported beside the contract value, never as it: the same K steps with the forward / data-gradient GEMMs of the
+    # MFMA-bound layers in "split" arithmetic (fp32 operands split exactly into three bf16 terms, six products on the
+    # bf16 matrix pipe, fp32 accumulation; include/muscle_hip.h mx_set_gemm_mode)
+    split = None
+    if not a.no_split:
+        muscle_amd.set_gemm_mode(1)
+        eager_step()
+        barrier()
+        t2 = time.perf_counter()
+        for _ in range(a.steps):
+            eager_step()
+        barrier()
+        dts = time.perf_counter() - t2
+        muscle_amd.set_gemm_mode(0)
+        if world > 1:
+            t = torch.tensor([dts], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dts = float(t)
+        split = {"value": a.batch * world * a.steps / dts, "unit": "images/sec", "ms_per_step": dts / a.steps * 1e3,
+                 "arithmetic": "opt-in: fwd/dgrad GEMMs with K >= 128 on v_mfma_f32_32x32x16_bf16, fp32 operands as h+m+l bf16 "
+                               "terms (exact split), 6 of 9 products, fp32 accumulate; error vs fp64 equal to the fp32-MFMA kernel's"}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -298,6 +320,8 @@ def main():
         per_gpu = imgs / dt / world
         res["roofline"]["step_frac_mfma"] = per_gpu / STEP_CEILING_MFMA_IMGS
         res["roofline"]["step_frac_hbm"] = per_gpu / STEP_CEILING_HBM_IMGS
+    if split is not None:
+        res["split_mfma"] = split
     dws = timer.dw_summary()
     if dws:
         worst = min(dws.items(), key=lambda kv: kv[1]["GBps"])

@@ -43,6 +43,15 @@ int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_s
               int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,
               const float* bias, const float* residual, int relu, float* stats, void* stream);
 
+/* Arithmetic of the forward / data-gradient GEMMs (process-wide; initial value from MX_GEMM_SPLIT, default 0).
+ * 0: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) - the parity mode of record.
+ * 1: "split" mode for the MFMA-bound shapes: each fp32 operand is split exactly into three bf16 terms (x = h + m + l),
+ *    six of the nine cross products (each exact in fp32) are accumulated in fp32 on the bf16 matrix pipe; the dropped
+ *    terms are <= 3 * 2^-24 of a product.  Same results to fp32 round-off, 2.67x the matrix rate.  Opt-in.
+ * 2: split mode for every NT GEMM (tests). */
+int mx_set_gemm_mode(int mode);
+int mx_get_gemm_mode(void);
+
 /* dst[cols,rows] = src[rows,cols]^T (conv weights): the data gradient runs as mx_pw_fwd against the transposed weight. */
 int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 

@@ -19,4 +19,5 @@ __all__ = ["MuSCLe", "FocalLoss", "Log_Sum_Exp_Pairwise_Loss", "MultiLabelSoftMa
            "FusedAdam", "cam_softmaxnorm", "er_loss", "mcl_step", "EMD", "PixPro", "cam_maxnorm", "get_dynamic_crops",
            "torchutils", "edge", "muscle_step"]
 from .graph import GraphedStep  # noqa: F401,E402
+from .ops import get_gemm_mode, set_gemm_mode  # noqa: F401,E402
 from . import data  # noqa: F401,E402  (input path: two-view sampler + device-side color_norm / crop stage)

@@ -650,6 +650,296 @@ __global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kerne
   MX_GEMM_STAMP(g, 3);
 }
 
+// =====================================================================================================================
+// NT GEMM on the bf16 matrix pipe with fp32-exact operands ("split" mode; OPT-IN, see mx_set_gemm_mode).
+//
+// Every fp32 operand value is split by truncation into three terms whose low 16 bits are zero, x = h + m + l EXACTLY
+// (8 + 8 + 8 significand bits), i.e. three bf16 numbers.  a*b = (ah+am+al)(bh+bm+bl); the six products of total order
+// <= 2 (hh, hm, mh, hl, lh, mm) are each exact in fp32 and are accumulated in fp32 by v_mfma_f32_32x32x16_bf16; the three
+// dropped products are <= 3 * 2^-24 |a b|, the size of ONE fp32 rounding of the product - the accumulation roundings,
+// which dominate the error of an fp32 dot product, are the same as in the fp32-MFMA kernel.  Cost: 6 bf16 MFMAs of
+// 32 cycles per 32x32x16 block against 32 cycles per 32x32x2 on the fp32 pipe: 2.67x the rate.
+// Tile 128 x 128, K in 16-wide slabs, 4 waves of 64 x 64 (2 x 2 MFMA tiles).  LDS: per stage and operand three planes
+// [128 rows][16 bf16] (32-byte rows, the two 16-byte halves of a row swapped when bit 3 of the row is set: conflict-free
+// for the lane groups of ds_read_b128), 48 KB for two stages: 3 workgroups per CU.  The split runs on the VALU when a
+// slab moves from registers to LDS (5.5 operations per value), after the operand prologue.  As in gemm_nt_kernel the
+// weight rows are the MFMA's first operand, so a lane's accumulators are runs of four consecutive output channels.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+static __device__ __forceinline__ void split3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned u0 = __float_as_uint(x0) & 0xffff0000u, u1 = __float_as_uint(x1) & 0xffff0000u;
+  const float r0 = x0 - __uint_as_float(u0), r1 = x1 - __uint_as_float(u1);                // exact
+  const unsigned v0 = __float_as_uint(r0) & 0xffff0000u, v1 = __float_as_uint(r1) & 0xffff0000u;
+  const float s0 = r0 - __uint_as_float(v0), s1 = r1 - __uint_as_float(v1);                // exact, <= 8 significant bits
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);     // {bf16(x1), bf16(x0)}: the top halves of both words
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+// NJ = 32-column MFMA tiles per wave: tile 128 x (64 NJ).  NJ = 1 doubles the tile count where 128 x 128 leaves CUs idle.
+template <int AMODE, int NJ>
+__global__ __launch_bounds__(256, 3) void gemm_nt_split_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 64 * NJ, WN = 2, WNC = 32 * NJ;   // WNC: columns per wave
+  constexpr int PA_ = 128 * 32, PB_ = BN * 32;              // bytes of one [rows][16 bf16] plane of A / B
+  constexpr int STAGE = 3 * PA_ + 3 * PB_;
+  constexpr int PS = WNC + 4;                               // epilogue patch row stride (floats)
+  constexpr int SMEM = (2 * STAGE > 4 * 32 * PS * 4 + 2 * 2 * BN * 4) ? 2 * STAGE : 4 * 32 * PS * 4 + 2 * 2 * BN * 4;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN;
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (g.xcd_nt > 0) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    tile_n = j % g.xcd_nt;
+    tile_m = (j / g.xcd_nt) * 8 + xcd;
+    if (tile_m >= g.mt) return;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const long zb = blockIdx.z;
+  const float* A = g.a.p + zb * g.sa;
+  const float* B = g.b.p + zb * g.sb;
+  float* C = g.c + zb * g.sc;
+  const int K = g.K;
+
+  // slab movers: thread t owns rows t/4 (+64) of A and of B (B: only while < BN), 16-byte column chunk t % 4
+  constexpr int NB = BN / 64;
+  const int ck = (tid & 3) * 4;
+  float4 ra[2], rb[NB];
+  float4 gt[AMODE == MX_BNACT ? 2 : 1];
+  float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;
+  long ga_off[AMODE == MX_BNACT ? 2 : 1];
+  const float* pa[2];
+  const float* pb[NB];
+  bool oka[2], okb[NB];
+  int woff[2];                                              // byte offset of this thread's 8 bytes inside a plane
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int row = (tid >> 2) + 64 * i;
+    oka[i] = m0 + row < g.M;
+    pa[i] = A + (long)(m0 + row) * g.lda + ck;
+    if (AMODE == MX_BNACT) ga_off[i] = g.a.rowp ? (long)((m0 + row) / g.a.rps) * K + ck : -1;
+    if (i < NB) {
+      okb[i] = n0 + row < g.N;
+      pb[i] = B + (long)(n0 + row) * g.ldb + ck;
+    }
+    const int kq = tid & 3;
+    woff[i] = row * 32 + (((kq >> 1) ^ ((row >> 3) & 1)) << 4) + ((kq & 1) << 3);
+  }
+  auto load = [&](int k0) {
+    const bool kin = k0 + ck < K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      ra[i] = (oka[i] && kin) ? ld4(pa[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AMODE == MX_BNACT) gt[i] = (oka[i] && kin && ga_off[i] >= 0) ? ld4(g.a.rowp + ga_off[i] + k0) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (i < NB) rb[i] = (okb[i] && kin) ? ld4(pb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (AMODE != MX_PLAIN) {
+      sc4 = kin ? ld4(g.a.c1 + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
+      sh4 = kin ? ld4(g.a.c2 + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto put = [&](unsigned char* base, int plane, int off, float4 v) {
+    unsigned h0, m0_, l0, h1, m1, l1;
+    split3_pair(v.x, v.y, h0, m0_, l0);
+    split3_pair(v.z, v.w, h1, m1, l1);
+    *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(base + plane + off) = make_uint2(m0_, m1);
+    *reinterpret_cast<uint2*>(base + 2 * plane + off) = make_uint2(l0, l1);
+  };
+  auto store = [&](unsigned char* st, int k0) {
+    const bool kin = k0 + ck < K;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      float4 v = ra[i];
+      if (AMODE != MX_PLAIN && oka[i] && kin) v = nt_prologue<AMODE>(v, sc4, sh4, gt[AMODE == MX_BNACT ? i : 0]);
+      put(st, PA_, woff[i], v);
+      if (i < NB) put(st + 3 * PA_, PB_, woff[i], rb[i]);
+    }
+  };
+
+  f32x16 acc[2][NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // fragment addresses of this lane inside a plane
+  int fa[2], fb[NJ];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ra_ = wm * 64 + 32 * i + l31;
+    fa[i] = ra_ * 32 + ((hf ^ ((ra_ >> 3) & 1)) << 4);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int rb_ = wn * WNC + 32 * j + l31;
+    fb[j] = rb_ * 32 + ((hf ^ ((rb_ >> 3) & 1)) << 4);
+  }
+  const int nk = (K + 15) / 16;
+  load(0);
+  store(smem, 0);
+  if (nk > 1) load(16);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int cur = kt & 1;
+    if (kt + 1 < nk) {
+      store(smem + (cur ^ 1) * STAGE, (kt + 1) * 16);
+      if (kt + 2 < nk) load((kt + 2) * 16);
+    }
+    const unsigned char* sa = smem + cur * STAGE;
+    const unsigned char* sb = sa + 3 * PA_;
+    bf16x8 av[2][3], bv[NJ][3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) av[i][p] = *reinterpret_cast<const bf16x8*>(sa + p * PA_ + fa[i]);
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bv[j][p] = *reinterpret_cast<const bf16x8*>(sb + p * PB_ + fb[j]);
+    }
+    // six products, smallest terms first: (w,a) = (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); product-major so that consecutive
+    // MFMAs write different accumulators; the weight fragment is the first operand (see the epilogue)
+    constexpr int PW[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][PW[t]], av[i][PX[t]], acc[i][j], 0, 0, 0);
+    __syncthreads();
+  }
+  // epilogue: acc[i][j][4 gq + e] = C[m = 32 i + l31][n = 32 j + 8 gq + 4 hf + e].  Bias / residual / relu / statistics in
+  // registers; the values then cross a per-wave LDS patch [32][WNC] so that a store instruction writes whole rows
+  // (64 lanes x 16 bytes = WNC*4-byte row segments) instead of 32-byte pieces.
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PS);
+  float* red = reinterpret_cast<float*>(smem) + 4 * 32 * PS;           // [2 (wm)][2][BN]
+  const bool vec = ((g.ldc | g.N) & 3) == 0;
+  f32x4 cs[NJ][4], cq[NJ][4];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) cs[j][gq] = cq[j][gq] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int rbase = m0 + wm * 64 + 32 * i;
+    const int row = rbase + l31;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        const int cl = 32 * j + 8 * gq + 4 * hf;             // column inside the wave's WNC columns
+        const int col = n0 + wn * WNC + cl;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * gq + e] + ((g.bias && col + e < g.N) ? g.bias[col + e] : 0.f);
+        if (g.residual && row < g.M) {
+          const long idx = (long)row * g.ldc + col;
+          if (vec && col + 3 < g.N) {
+            const float4 r4 = ld4(g.residual + idx);
+            v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) if (col + e < g.N) v[e] += g.residual[idx + e];
+          }
+        }
+        if (g.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (row < g.M) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float u = (col + e < g.N) ? v[e] : 0.f;
+            cs[j][gq][e] += u; cq[j][gq][e] += u * u;
+          }
+        }
+        *reinterpret_cast<f32x4*>(patch + l31 * PS + cl) = f32x4{v[0], v[1], v[2], v[3]};
+      }
+    // patch -> rows: WNC/4 float4 per row, 64 lanes cover 64/(WNC/4) rows per pass
+    constexpr int C4 = WNC / 4, RPP = 64 / C4;
+#pragma unroll
+    for (int t = 0; t < 32 / RPP; ++t) {
+      const int rl = t * RPP + lane / C4, c4 = (lane % C4) * 4;
+      const int orow = rbase + rl, ocol = n0 + wn * WNC + c4;
+      const float4 v4 = ld4(patch + rl * PS + c4);
+      if (orow < g.M && ocol < g.N) {
+        const long idx = (long)orow * g.ldc + ocol;
+        if (vec && ocol + 3 < g.N) {
+          __builtin_nontemporal_store(f32x4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<f32x4*>(C + idx));
+        } else {
+          const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (ocol + e < g.N) C[idx + e] = v[e];
+        }
+      }
+    }
+  }
+  if (g.stats) {
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int gq = 0; gq < 4; ++gq) {
+        f32x4 s, sq;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float a = row16_sum(cs[j][gq][e]), q = row16_sum(cq[j][gq][e]);
+          a += __shfl_xor(a, 16, 64); q += __shfl_xor(q, 16, 64);
+          s[e] = a; sq[e] = q;
+        }
+        if (l31 == 0) {
+          const int coll = wn * WNC + 32 * j + 8 * gq + 4 * hf;
+          *reinterpret_cast<f32x4*>(red + (wm * 2 + 0) * BN + coll) = s;
+          *reinterpret_cast<f32x4*>(red + (wm * 2 + 1) * BN + coll) = sq;
+        }
+      }
+    __syncthreads();
+    float* prow = g.stats + (long)tile_m * 2 * g.N;
+    for (int i = tid; i < 2 * BN; i += 256) {
+      const int which = i / BN, col = i - which * BN;
+      const float v = red[(0 * 2 + which) * BN + col] + red[(1 * 2 + which) * BN + col];
+      if (n0 + col < g.N) prow[which * g.N + n0 + col] = v;
+    }
+  }
+}
+
+// 0 = fp32 MFMA everywhere (default, the parity mode of record); 1 = split mode for the MFMA-bound forward / data-gradient
+// shapes; 2 = split mode for every NT GEMM (tests).  Process-wide; MX_GEMM_SPLIT sets the initial value.
+static int g_gemm_mode = getenv("MX_GEMM_SPLIT") ? atoi(getenv("MX_GEMM_SPLIT")) : 0;
+
+template <int NJ>
+static void launch_nt_split_t(const GemmArgs& g, int batch, hipStream_t st) {
+  constexpr int BN = 64 * NJ;
+  const int mt = cdiv(g.M, 128), nt = cdiv(g.N, BN);
+  GemmArgs a = g;
+  a.mt = mt;
+  a.xcd_nt = 0;
+  dim3 grid(mt, nt, batch);
+  if (nt >= 2 && nt <= 16 && mt >= 64) { a.xcd_nt = nt; grid = dim3(8 * cdiv(mt, 8) * nt, 1, batch); }
+  switch (g.a.mode) {
+    case MX_PLAIN: hipLaunchKernelGGL((gemm_nt_split_kernel<MX_PLAIN, NJ>), grid, dim3(256), 0, st, a); break;
+    case MX_BNACT: hipLaunchKernelGGL((gemm_nt_split_kernel<MX_BNACT, NJ>), grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((gemm_nt_split_kernel<MX_AFFINE, NJ>), grid, dim3(256), 0, st, a); break;
+  }
+}
+
+// 128 x 128 unless the narrower tile pads fewer columns or balances the 768 resident workgroups (3 per CU) better
+static void launch_nt_split(const GemmArgs& g, int batch, hipStream_t st) {
+  static const int forced = getenv("MX_GEMM_SPLIT_NJ") ? atoi(getenv("MX_GEMM_SPLIT_NJ")) : 0;
+  auto score = [&](int bn, double eff) {
+    const long nt = cdiv(g.N, bn), tiles = (long)cdiv(g.M, 128) * nt * batch;
+    const double pad = (double)g.N / (double)(nt * bn);
+    const double rounds = (double)tiles / 768.0;
+    const double balance = rounds / (double)(long)(rounds + 0.999999);
+    return eff * pad * balance;
+  };
+  const bool narrow = forced ? forced == 1 : score(64, 0.92) > score(128, 1.0) + 1e-9;
+  if (narrow) launch_nt_split_t<1>(g, batch, st);
+  else launch_nt_split_t<2>(g, batch, st);
+}
+
 // tile table of the second-generation NT kernel: {BM, BN}; every entry has 128 rows
 struct NtCfg { int bm, bn; };
 static const NtCfg kNtCfgs[] = {{128, 128}, {128, 96}, {128, 64}, {128, 48}, {128, 80}, {128, 32}, {128, 160}};
@@ -695,6 +985,10 @@ static int pick_nt_cfg(int M, int N) {
 }
 
 static void dispatch_nt(const GemmArgs& g, int batch, hipStream_t st) {
+  if (g_gemm_mode == 2 || (g_gemm_mode == 1 && g.K >= 128 && g.N >= 96 && (double)g.N / (64.0 * cdiv(g.N, 64)) >= 0.74)) {
+    launch_nt_split(g, batch, st);       // MFMA-bound shapes only: K and N large enough, <= 26 % padded columns
+    return;
+  }
   switch (pick_nt_cfg(g.M, g.N)) {
     case 0: launch_nt<2, 2, 4, 4>(g, batch, st); break;     // 128 x 128
     case 1: launch_nt<2, 2, 4, 3>(g, batch, st); break;     // 128 x 96
@@ -783,6 +1077,14 @@ int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream)
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
+
+int mx_set_gemm_mode(int mode) {
+  MX_CHECK_ARG(mode >= 0 && mode <= 2, "set_gemm_mode: mode %d (0 fp32 MFMA, 1 split for MFMA-bound shapes, 2 split everywhere)", mode);
+  g_gemm_mode = mode;
+  return MX_OK;
+}
+
+int mx_get_gemm_mode(void) { return g_gemm_mode; }
 
 // number of partial-statistics rows mx_pw_fwd writes for an [M, N] output
 int mx_pw_fwd_parts(int M, int N, int K) {

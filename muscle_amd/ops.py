@@ -65,6 +65,17 @@ def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None
     return (out, stats) if want_stats else out
 
 
+def set_gemm_mode(mode: int):
+    """Arithmetic of the forward / data-gradient GEMMs (include/muscle_hip.h, mx_set_gemm_mode): 0 = exact-fp32 MFMA (the
+    default and the parity mode of record); 1 = fp32 operands split exactly into three bf16 terms, six products on the
+    bf16 matrix pipe with fp32 accumulation, for the MFMA-bound shapes; 2 = the same for every NT GEMM (tests)."""
+    call("mx_set_gemm_mode", int(mode))
+
+
+def get_gemm_mode() -> int:
+    return int(lib().mx_get_gemm_mode())
+
+
 def transpose(W):
     """[rows, cols] -> contiguous [cols, rows] (weights)."""
     rows, cols = W.shape

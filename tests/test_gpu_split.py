@@ -1,0 +1,105 @@
+"""The opt-in "split" arithmetic of the forward / data-gradient GEMMs (include/muscle_hip.h, mx_set_gemm_mode): fp32
+operands split exactly into three bf16 terms, six products on the bf16 matrix pipe, fp32 accumulation.  Claim under
+test: the results are fp32 results - the error against fp64 is no larger than the exact-fp32 MFMA kernel's (up to a
+small factor for the different summation order), on every operand prologue / epilogue option and on ragged shapes, and
+the model-level parity tests hold in this mode with the SAME tolerances."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture
+def split_everywhere():
+    import muscle_amd
+    muscle_amd.set_gemm_mode(2)
+    yield
+    muscle_amd.set_gemm_mode(0)
+
+
+def _ref(A, W, scale, shift, gate, rps, bias, res, relu, mode):
+    A64 = A.double()
+    if mode != 0:                       # ops.BNACT = 1: affine + SiLU + per-sample gate; ops.AFFINE = 2: affine only
+        A64 = A64 * scale.double() + shift.double()
+        if mode == 1:
+            A64 = A64 * torch.sigmoid(A64)
+            A64 = A64 * gate.double().repeat_interleave(rps, dim=0)[: A.shape[0]]
+    C = A64 @ W.double().t()
+    if bias is not None:
+        C = C + bias.double()
+    if res is not None:
+        C = C + res.double()
+    if relu:
+        C = C.clamp_min(0)
+    return C
+
+
+@pytest.mark.parametrize("M,K,N,mode,opts", [
+    (25088, 384, 2304, 0, "stats"), (6272, 2304, 384, 1, "stats"), (777, 640, 21, 0, "bias+relu"), (3001, 36, 48, 2, "res"),
+    (12544, 224, 1344, 1, "stats"), (4096, 1344, 224, 0, "res+stats"), (130, 132, 200, 0, ""), (128, 16, 128, 0, "stats")])
+def test_split_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, mode, opts):
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * (K ** -0.5)
+    rps = 49 if M % 49 == 0 else 1
+    scale = torch.rand(K, device=DEV, generator=g) + 0.5
+    shift = torch.randn(K, device=DEV, generator=g) * 0.3
+    gate = torch.rand((M + rps - 1) // rps, K, device=DEV, generator=g)
+    bias = torch.randn(N, device=DEV, generator=g) if "bias" in opts else None
+    res = torch.randn(M, N, device=DEV, generator=g) if "res" in opts else None
+    kw = dict(a_mode=mode, a_scale=scale if mode else None, a_shift=shift if mode else None, a_gate=gate if mode == 1 else None,
+              rows_per_sample=rps, bias=bias, residual=res, relu="relu" in opts, want_stats="stats" in opts)
+    want = _ref(A, W, scale, shift, gate, rps, bias, res, "relu" in opts, mode)
+    errs, stats = [], []
+    for gm in (0, 2):
+        muscle_amd.set_gemm_mode(gm)
+        try:
+            out = ops.pw_fwd(A, W, N, **kw)
+        finally:
+            muscle_amd.set_gemm_mode(0)
+        if "stats" in opts:
+            out, st = out
+            s = st.double().sum(0)                     # [2, N]
+            stats.append((float((s[0] - want.sum(0)).abs().max() / want.sum(0).abs().max()),
+                          float((s[1] - (want * want).sum(0)).abs().max() / (want * want).sum(0).abs().max())))
+        errs.append(float((out.double() - want).abs().max()))
+    scale_ = float(want.abs().max())
+    assert errs[0] <= 2e-6 * scale_ + 1e-6, errs                 # the exact-fp32 kernel itself
+    assert errs[1] <= 1.5 * errs[0] + 2e-7 * scale_, errs        # the split kernel is as close to fp64
+    for a, b in stats:
+        assert a <= 1e-5 and b <= 1e-5
+
+
+def test_split_mode_leaves_small_shapes_on_fp32_mfma_in_mode_1():
+    """mode 1 only switches the MFMA-bound shapes: a K = 48 GEMM must give bit-identical results in modes 0 and 1."""
+    import muscle_amd
+    from muscle_amd import ops
+    A = torch.randn(4096, 48, device=DEV)
+    W = torch.randn(288, 48, device=DEV)
+    a = ops.pw_fwd(A, W, 288)
+    muscle_amd.set_gemm_mode(1)
+    try:
+        b = ops.pw_fwd(A, W, 288)
+        assert muscle_amd.get_gemm_mode() == 1
+    finally:
+        muscle_amd.set_gemm_mode(0)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("name,n,size,mode,training", [("efficientnet-b0", 3, 64, "cam", True), ("efficientnet-b7", 2, 64, "cam", True)])
+def test_model_parity_holds_in_split_mode(split_everywhere, name, n, size, mode, training):
+    import test_gpu_model as tm
+    tm.test_model_forward_backward(name, n, size, mode, training)
+
+
+@pytest.mark.parametrize("fname", ["step_b0_ep4.npz", "step_b7_448_ep4.npz"])
+def test_mcl_step_golden_in_split_mode(split_everywhere, fname):
+    """The reference's own step fixtures (B0, and B7 at 448x448 where the big layers take the split kernel)."""
+    import test_gpu_model as tm
+    tm.test_mcl_step_phase1_golden(fname, False)

@@ -500,6 +500,8 @@ __device__ __forceinline__ int lr_pixel(const float* cam, const float* sgc, int 
       const int k = k4 + j;
       if (k >= 1 && k < K) { a[k] = av[j]; b[k] = bv[j]; ma = fmaxf(ma, av[j]); mb = fmaxf(mb, bv[j]); }
     }
+    // at most two chunks (16 loads) in flight: hoisting all six chunks' loads costs 190 registers and the callers' occupancy
+    if ((k4 & 4) != 0) __builtin_amdgcn_sched_barrier(0);
   }
   float sa = 0.f, sb = 0.f;
   for (int k = 1; k < K; ++k) { a[k] = __expf(a[k] - ma); sa += a[k]; b[k] = __expf(b[k] - mb); sb += b[k]; }

@@ -22,7 +22,7 @@ sys.path.insert(0, ROOT)
 
 from muscle_amd import arch, synth  # noqa: E402
 
-GEMM_CALLS = ("mx_pw_fwd", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small")
+GEMM_CALLS = ("mx_pw_fwd", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile")
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 HBM_PEAK_GBPS = 8000.0                # same guide: HBM3E spec; 6290 GB/s is what a float4 copy achieves
 # whole-step ceilings per GPU for B7 / 448x448 step-A: exact-fp32 MFMA and HBM (minimum-materialisation schedule)

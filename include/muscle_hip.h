@@ -72,6 +72,14 @@ int mx_pw_wgrad_small(const float* G, const float* X, int x_mode, const float* x
                       const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
                       void* ws, long ws_bytes, void* stream);
 
+/* The same weight gradient for LARGE outputs (Co*Ci >= 16384): dW cut into 128/64-wide tiles, the rows into groups, partial
+ * tiles per group added in a fixed order - deterministic, no atomics; workgroup ids are XCD-aware so that a row slab crosses
+ * the fabric once.  mx_pw_wgrad_tile_ws: bytes of scratch needed, 0 = shape not taken. */
+long mx_pw_wgrad_tile_ws(int R, int Co, int Ci, int x_mode);
+int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
+                     const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
+                     void* ws, long ws_bytes, void* stream);
+
 /* batched plain GEMM for the PCM head (MuSCLe.py:213-223): layout 0: C=A*B^T (B [N,K]); 1: C=A*B (B [K,N]). */
 int mx_bgemm(int layout, const float* A, const float* B, float* C, int M, int N, int K, int lda, int ldb, int ldc,
              long sa, long sb, long sc, int batch, int relu, void* stream);

@@ -247,6 +247,201 @@ static bool wg_dispatch(const WgArgs& a, const WgPlan& p, hipStream_t st, bool l
   return false;
 }
 
+// =====================================================================================================================
+// Tiled, deterministic weight gradient for the LARGE outputs (stages 4-7: Co*Ci up to 3840 x 640).
+//
+// dW is cut into TCO x TCI tiles (128/64 wide), the pixel rows into `groups` contiguous ranges; workgroup (tile, group)
+// walks its rows in 16-row slabs through k-major LDS and leaves its partial tile in part[group]; the reduce kernel adds
+// the groups in a fixed order (no atomics: run-to-run identical, and no read-modify-write traffic).  k-major LDS means a
+// slab row is a plain copy of 512 contiguous bytes of the operand row, and ONE ds_read_b128 per operand and 4 reduction
+// rows feeds 16 v_mfma_f32_16x16x4_f32: lane (l15, q) reads columns 4 l15 .. 4 l15 + 3 of row 4 qd + q, value e goes to
+// the MFMA of sub-tile e, whose row/column l15 therefore IS column 4 l15 + e of the wave's 64 (a fixed permutation of the
+// output coordinates, undone when the accumulators are stored: each lane owns runs of four consecutive Ci).  Row stride
+// 128 floats (= 0 mod 64 banks: the 16 lanes of a ds_read_b128 group differ in l15 only) or 96 for the 64-wide operand.
+// Workgroup ids are XCD-aware: all tiles of one row group run back to back on ONE XCD, so a slab crosses the fabric once
+// (per-XCD L2) instead of once per tile - the tiled TN kernel of gemm.hip re-read its operands 2.8x (profiles/traffic).
+struct WtArgs {
+  const float* G;
+  MxOperand X;
+  float* part;             // [groups][Co*Ci], or dW itself when groups == 1 (then accumulated in place)
+  int R, Co, Ci, ldg, ldx;
+  int rows_per_group;      // multiple of 16
+  int groups, tiles_co, tiles_ci;
+  int accumulate;          // groups == 1: part == dW, add instead of store
+  int order;               // 0: XCD-aware (tiles of a group on one XCD); 1: group-major; 2: tile-major
+};
+
+template <int TE, int TF, int XMODE>
+__global__ __launch_bounds__(256, (TE * TF >= 16) ? 3 : 4) void wgrad_tile_kernel(WtArgs a) {
+  constexpr int TCO = 32 * TE, TCI = 32 * TF;                 // 2 x 2 waves, wave tile 16 TE x 16 TF
+  constexpr int SG = (TE == 4) ? 128 : 96, SX = (TF == 4) ? 128 : 96;
+  constexpr int SLAB = 16 * (SG + SX);
+  constexpr int GP = (16 * TCO / 4) / 256 > 0 ? (16 * TCO / 4) / 256 : 1;   // float4 per thread per slab
+  constexpr int XP = (16 * TCI / 4) / 256 > 0 ? (16 * TCI / 4) / 256 : 1;
+  __shared__ __attribute__((aligned(16))) float smem[2 * SLAB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, q = lane >> 4;
+  const int wco = wave >> 1, wci = wave & 1;
+  // XCD-aware ids: L % 8 is the XCD (round-robin dispatch); the tiles of one group are consecutive ON that XCD
+  const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+  const int tiles = a.tiles_co * a.tiles_ci;
+  int group = (j / tiles) * 8 + xcd, tile = j % tiles;
+  if (a.order == 1) { group = L / tiles; tile = L % tiles; }
+  else if (a.order == 2) { const int g8 = 8 * ((a.groups + 7) / 8); group = L % g8; tile = L / g8; }
+  if (group >= a.groups) return;
+  const int co0 = (tile / a.tiles_ci) * TCO, ci0 = (tile % a.tiles_ci) * TCI;
+  const long r_beg = (long)group * a.rows_per_group;
+  const long r_end = min((long)a.R, r_beg + a.rows_per_group);
+
+  float4 rg[GP], rx[XP], gt[XMODE == MX_BNACT ? XP : 1];
+  auto load = [&](long r0) {
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+      const int idx = tid + 256 * i, row = idx / (TCO / 4), c = idx % (TCO / 4);
+      const long r = r0 + row;
+      rg[i] = (idx < 16 * TCO / 4 && r < r_end && co0 + 4 * c < a.Co) ? ld4(a.G + r * a.ldg + co0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int idx = tid + 256 * i, row = idx / (TCI / 4), c = idx % (TCI / 4);
+      const long r = r0 + row;
+      const bool ok = idx < 16 * TCI / 4 && r < r_end && ci0 + 4 * c < a.Ci;
+      rx[i] = ok ? ld4(a.X.p + r * a.ldx + ci0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (XMODE == MX_BNACT) gt[i] = (ok && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + ci0 + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  };
+  auto store = [&](float* buf, long r0) {
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+      const int idx = tid + 256 * i, row = idx / (TCO / 4), c = idx % (TCO / 4);
+      if (idx < 16 * TCO / 4) st4(buf + row * SG + 4 * c, rg[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const int idx = tid + 256 * i, row = idx / (TCI / 4), c = idx % (TCI / 4);
+      if (idx < 16 * TCI / 4) {
+        float4 v = rx[i];
+        if (XMODE != MX_PLAIN && r0 + row < r_end && ci0 + 4 * c < a.Ci) {
+          const float4 sc = ld4(a.X.c1 + ci0 + 4 * c), sh = ld4(a.X.c2 + ci0 + 4 * c);
+          v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
+          if (XMODE == MX_BNACT) {
+            const float4 g4 = gt[XMODE == MX_BNACT ? i : 0];
+            v.x = swishf_(v.x) * g4.x; v.y = swishf_(v.y) * g4.y; v.z = swishf_(v.z) * g4.z; v.w = swishf_(v.w) * g4.w;
+          }
+        }
+        st4(buf + 16 * SG + row * SX + 4 * c, v);
+      }
+    }
+  };
+
+  f32x4w acc[TE][TF];
+#pragma unroll
+  for (int e = 0; e < TE; ++e)
+#pragma unroll
+    for (int f = 0; f < TF; ++f) acc[e][f] = f32x4w{0.f, 0.f, 0.f, 0.f};
+
+  const int ns = (int)((r_end - r_beg + 15) / 16);
+  if (ns > 0) {
+    load(r_beg);
+    store(smem, r_beg);
+    if (ns > 1) load(r_beg + 16);
+  }
+  __syncthreads();
+  for (int s = 0; s < ns; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < ns) {
+      store(smem + (cur ^ 1) * SLAB, r_beg + (long)(s + 1) * 16);
+      if (s + 2 < ns) load(r_beg + (long)(s + 2) * 16);
+    }
+    const float* gs = smem + cur * SLAB + q * SG + 16 * TE * wco + TE * l15;
+    const float* xs = smem + cur * SLAB + 16 * SG + q * SX + 16 * TF * wci + TF * l15;
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd) {
+      float av[TE], bv[TF];
+      if (TE == 4) { const float4 t = ld4(gs + 4 * qd * SG); av[0] = t.x; av[1] = t.y; av[2] = t.z; av[TE - 1] = t.w; }
+      else { const float2 t = *reinterpret_cast<const float2*>(gs + 4 * qd * SG); av[0] = t.x; av[TE - 1] = t.y; }
+      if (TF == 4) { const float4 t = ld4(xs + 4 * qd * SX); bv[0] = t.x; bv[1] = t.y; bv[2] = t.z; bv[TF - 1] = t.w; }
+      else { const float2 t = *reinterpret_cast<const float2*>(xs + 4 * qd * SX); bv[0] = t.x; bv[TF - 1] = t.y; }
+#pragma unroll
+      for (int e = 0; e < TE; ++e)
+#pragma unroll
+        for (int f = 0; f < TF; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[e], bv[f], acc[e][f], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  // acc[e][f][r] = dW[co0 + 16 TE wco + TE (4 q + r) + e][ci0 + 16 TF wci + TF l15 + f]
+  float* out = a.part + (a.accumulate ? 0 : (long)group * a.Co * a.Ci);
+#pragma unroll
+  for (int e = 0; e < TE; ++e)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + 16 * TE * wco + TE * (4 * q + r) + e;
+      const int ci = ci0 + 16 * TF * wci + TF * l15;
+      if (co >= a.Co || ci >= a.Ci) continue;                 // Ci % 4 == 0 and TF | 4: a lane's run is in or out as a whole
+      float* o = out + (long)co * a.Ci + ci;
+      if (TF == 4) {
+        float4 v = make_float4(acc[e][0][r], acc[e][1][r], acc[e][2][r], acc[e][TF - 1][r]);
+        if (a.accumulate) { const float4 d = ld4(o); v.x += d.x; v.y += d.y; v.z += d.z; v.w += d.w; }
+        st4(o, v);
+      } else {
+        float2 v = make_float2(acc[e][0][r], acc[e][TF - 1][r]);
+        if (a.accumulate) { const float2 d = *reinterpret_cast<const float2*>(o); v.x += d.x; v.y += d.y; }
+        *reinterpret_cast<float2*>(o) = v;
+      }
+    }
+}
+
+struct WtPlan { int te, tf, tiles_co, tiles_ci, groups, rows_per_group; };
+
+static int wt_order() {
+  static const int order = getenv("MX_WGRAD_TILE_ORDER") ? atoi(getenv("MX_WGRAD_TILE_ORDER")) : 0;
+  return order;
+}
+
+static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
+  if (Co % 4 || Ci % 4 || R < 1024 || (long)Co * Ci < 16384) return false;
+  // tile: least padded area, ties to the larger tile
+  long best = -1;
+  for (int te : {4, 2})
+    for (int tf : {4, 2}) {
+      const long area = (long)cdiv(Co, 32 * te) * 32 * te * cdiv(Ci, 32 * tf) * 32 * tf;
+      const long cost = area * 100 / (te * tf >= 16 ? 100 : te * tf >= 8 ? 95 : 88);      // smaller tiles feed the MFMA less well
+      if (best < 0 || cost < best) { best = cost; p->te = te; p->tf = tf; }
+    }
+  p->tiles_co = cdiv(Co, 32 * p->te); p->tiles_ci = cdiv(Ci, 32 * p->tf);
+  const int tiles = p->tiles_co * p->tiles_ci;
+  // Row groups: tiles x groups should fill a whole number of residency rounds (256 CUs x 4 workgroups, 3 for the 128 x 128
+  // tile with the BN+SiLU+gate prologue).  1026 workgroups on 1024 slots cost 25 % (two stragglers run alone after a full
+  // round); every extra group costs a partial matrix written and read back.
+  static const int forced = getenv("MX_WGRAD_TILE_GROUPS") ? atoi(getenv("MX_WGRAD_TILE_GROUPS")) : 0;
+  const int slots = 256 * ((p->te * p->tf >= 16 && x_mode == MX_BNACT) ? 3 : 4);
+  const int maxg = R / 256 > 0 ? R / 256 : 1;
+  int groups = 1;
+  double best_score = -1.0;
+  static const int rmin = getenv("MX_WGRAD_TILE_RMIN") ? atoi(getenv("MX_WGRAD_TILE_RMIN")) : 2;    // measured in the step: 1 / 2 / 3 -> 132.7 / 131.5 / 131.6 ms
+  for (int rounds = rmin; rounds <= rmin + 2; ++rounds) {
+    int g = slots * rounds / tiles;
+    if (g < 1) g = 1;
+    if (g > maxg) g = maxg;
+    if (wt_order() == 0 && g >= 8) g = g / 8 * 8;             // XCD-aware ids hand out groups eight at a time
+    const double fill = (double)tiles * g / ((double)slots * cdiv(tiles * g, slots));
+    const double score = fill - 0.0025 * g;
+    if (score > best_score + 1e-9) { best_score = score; groups = g; }
+  }
+  if (forced > 0) groups = forced < maxg ? forced : maxg;
+  p->rows_per_group = cdiv(cdiv(R, groups), 16) * 16;
+  p->groups = cdiv(R, p->rows_per_group);
+  return true;
+}
+
+template <int TE, int TF>
+static void wt_launch(const WtArgs& a, hipStream_t st) {
+  const dim3 grid(8 * cdiv(a.groups, 8) * a.tiles_co * a.tiles_ci);
+  if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_PLAIN>), grid, dim3(256), 0, st, a);
+  else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_BNACT>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_AFFINE>), grid, dim3(256), 0, st, a);
+}
+
 extern "C" {
 
 // bytes of scratch mx_pw_wgrad_small needs for (R, Co, Ci, x_mode), or 0 when the shape is not one it takes
@@ -280,6 +475,45 @@ int mx_pw_wgrad_small(const float* G, const float* X, int x_mode, const float* x
   MX_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_parts_reduce_kernel, dim3(cdiv((long)Co * Ci, 64)), dim3(256), 0, st, (const float*)ws, p.groups, Co * Ci, dW);
   MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// bytes of scratch mx_pw_wgrad_tile needs (0 = shape not taken; a single row group accumulates straight into dW)
+long mx_pw_wgrad_tile_ws(int R, int Co, int Ci, int x_mode) {
+  WtPlan p;
+  if (!wt_plan(R, Co, Ci, x_mode, &p)) return 0;
+  return p.groups > 1 ? (long)p.groups * Co * Ci * 4 : 16;
+}
+
+// dW[Co,Ci] += G[R,Co]^T X'[R,Ci], large outputs: tiled, deterministic (partial tiles per row group, fixed-order reduce).
+int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
+                     const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
+                     void* ws, long ws_bytes, void* stream) {
+  MX_CHECK_ARG(G && X && dW && ws, "wgrad_tile: null pointer");
+  MX_CHECK_ARG(((uintptr_t)dW & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)G & 15) == 0 && ((uintptr_t)X & 15) == 0,
+               "wgrad_tile: pointers must be 16-byte aligned");
+  MX_CHECK_ARG(ldg % 4 == 0 && ldx % 4 == 0, "wgrad_tile: leading dimensions must be multiples of 4");
+  MX_CHECK_ARG(x_mode == MX_PLAIN || (x_scale && x_shift && rows_per_sample > 0), "wgrad_tile: prologue needs scale/shift");
+  WtPlan p;
+  MX_CHECK_ARG(wt_plan(R, Co, Ci, x_mode, &p), "wgrad_tile: shape R=%d Co=%d Ci=%d not supported", R, Co, Ci);
+  MX_CHECK_ARG(p.groups == 1 || ws_bytes >= (long)p.groups * Co * Ci * 4, "wgrad_tile: workspace too small");
+  WtArgs a{};
+  a.G = G; a.X = MxOperand{X, x_scale, x_shift, x_gate, x_mode, rows_per_sample};
+  a.R = R; a.Co = Co; a.Ci = Ci; a.ldg = ldg; a.ldx = ldx;
+  a.rows_per_group = p.rows_per_group; a.groups = p.groups; a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci;
+  a.accumulate = p.groups == 1;
+  a.order = wt_order();
+  a.part = a.accumulate ? dW : (float*)ws;
+  hipStream_t st = (hipStream_t)stream;
+  if (p.te == 4 && p.tf == 4) wt_launch<4, 4>(a, st);
+  else if (p.te == 4) wt_launch<4, 2>(a, st);
+  else if (p.tf == 4) wt_launch<2, 4>(a, st);
+  else wt_launch<2, 2>(a, st);
+  MX_LAUNCH_CHECK();
+  if (!a.accumulate) {
+    hipLaunchKernelGGL(wgrad_parts_reduce_kernel, dim3(cdiv((long)Co * Ci, 64)), dim3(256), 0, st, (const float*)ws, p.groups, Co * Ci, dW);
+    MX_LAUNCH_CHECK();
+  }
   return MX_OK;
 }
 

@@ -6,6 +6,7 @@ enqueues on torch's current stream.
 """
 from __future__ import annotations
 
+import os
 from typing import NamedTuple, Optional
 
 import torch
@@ -101,6 +102,7 @@ def pw_dgrad(G, W, N_in, *, residual=None, out=None, wt=None):
 
 
 _wgrad_ws: dict = {}
+WGRAD_TILE = os.environ.get("MUSCLE_WGRAD_TILE", "1") == "1"   # large outputs: tiled deterministic kernel (wgrad.hip) instead of the atomic TN GEMM
 WGRAD_SMALL = True       # small outputs / long reductions: one workgroup owns the whole output, deterministic partial sums
 
 
@@ -122,6 +124,13 @@ def pw_wgrad(G, X, dW, *, x_mode=PLAIN, x_scale=None, x_shift=None, x_gate=None,
         if need > 0:
             ws = _wgrad_workspace(G.device, need)
             call("mx_pw_wgrad_small", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),
+                 R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())
+            return
+    if WGRAD_TILE and dW.is_contiguous():
+        need = lib().mx_pw_wgrad_tile_ws(R, Co, Ci, x_mode)
+        if need > 0:
+            ws = _wgrad_workspace(G.device, need)
+            call("mx_pw_wgrad_tile", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),
                  R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())
             return
     call("mx_pw_wgrad", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),

@@ -49,3 +49,49 @@ def test_wgrad_small_matches_fp64_and_is_deterministic(R, Co, Ci, mode):
     finally:
         ops.WGRAD_SMALL = True
     assert (dW2 - outs[0]).abs().max().item() <= 1e-4 * scale
+
+
+@pytest.mark.parametrize("R,Co,Ci,mode", [(25088, 384, 2304, "plain"), (25088, 2304, 384, "bnact"), (12544, 960, 160, "plain"),
+                                          (12544, 224, 1344, "bnact"), (25088, 640, 3840, "plain"), (1111, 200, 136, "bnact"),
+                                          (2048, 128, 128, "plain"), (5000 + 3, 480, 80, "bnact"), (4096, 1344, 224, "affine")])
+def test_wgrad_tile_matches_fp64_and_is_deterministic(R, Co, Ci, mode):
+    """Large-output weight gradient (wgrad_tile_kernel): every tile shape (128/64 x 128/64), ragged rows and edges, the
+    operand prologues, a running sum in dW, bit-identical repeat runs, agreement with the atomic TN GEMM it replaces."""
+    from muscle_amd import ops
+    from muscle_amd._lib import lib
+    assert lib().mx_pw_wgrad_small_ws(R, Co, Ci, 1 if mode == "bnact" else 0) == 0
+    assert lib().mx_pw_wgrad_tile_ws(R, Co, Ci, {'plain': 0, 'bnact': 1, 'affine': 2}[mode]) > 0
+    g = torch.Generator(device=DEV).manual_seed(R + Co)
+    G = torch.randn(R, Co, device=DEV, generator=g)
+    X = torch.randn(R, Ci, device=DEV, generator=g)
+    kw = {}
+    Xr = X.double()
+    if mode != "plain":
+        rps = 49
+        sc = torch.rand(Ci, device=DEV, generator=g) + 0.5
+        sh = torch.randn(Ci, device=DEV, generator=g) * 0.3
+        gate = torch.rand((R + rps - 1) // rps, Ci, device=DEV, generator=g)
+        Xr = Xr * sc.double() + sh.double()
+        if mode == "bnact":
+            kw = dict(x_mode=ops.BNACT, x_scale=sc, x_shift=sh, x_gate=gate, rows_per_sample=rps)
+            Xr = Xr * torch.sigmoid(Xr) * gate.double().repeat_interleave(rps, dim=0)[:R]
+        else:
+            kw = dict(x_mode=ops.AFFINE, x_scale=sc, x_shift=sh, rows_per_sample=rps)
+    ref = G.double().t() @ Xr
+    base = torch.randn(Co, Ci, device=DEV, generator=g)
+    outs = []
+    for _ in range(2):
+        dW = base.clone()
+        ops.pw_wgrad(G, X, dW, **kw)
+        outs.append(dW)
+    assert torch.equal(outs[0], outs[1])
+    scale = ref.abs().max().item()
+    err = (outs[0].double() - base.double() - ref).abs().max().item()
+    assert err <= 2e-5 * scale, (err, scale)
+    ops.WGRAD_TILE = False
+    try:
+        dW2 = base.clone()
+        ops.pw_wgrad(G, X, dW2, **kw)
+    finally:
+        ops.WGRAD_TILE = True
+    assert (dW2 - outs[0]).abs().max().item() <= 1e-4 * scale

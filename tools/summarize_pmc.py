@@ -33,7 +33,8 @@ def family(n):
         return "dw_bwd_fused_kernel<%s>" % re.match(r"dw_bwd_fused_kernel<(\d)", n).group(1)
     return re.sub(r"<.*", "", n)
 
-GEMM_FAMILIES = ("gemm_kernel", "gemm_nt_kernel", "wgrad_small_kernel")
+GEMM_FAMILIES = ("gemm_kernel", "gemm_nt_kernel", "wgrad_small_kernel", "wgrad_tile_kernel")
+GEMM_AUX = ("wgrad_parts_reduce_kernel",)      # bytes belong to the weight-gradient GEMMs, launches are not counted
 
 dirs = dict(a.split("=") for a in sys.argv[2:])
 res = {}
@@ -57,7 +58,7 @@ json.dump({"source": "rocprofv3 --kernel-trace --pmc {FETCH_SIZE | WRITE_SIZE | 
 print(open(sys.argv[1]).read())
 # the bench line's roofline.traffic: memory-side bytes per pointwise-GEMM launch (all GEMM families together)
 gl = sum(cf[f] for f in cf if f.startswith(GEMM_FAMILIES))
-gb = sum(2.0 * fetch[f].get("FETCH_SIZE", 0.0) * 1024 + write[f].get("WRITE_SIZE", 0.0) * 1024 for f in cf if f.startswith(GEMM_FAMILIES))
+gb = sum(2.0 * fetch[f].get("FETCH_SIZE", 0.0) * 1024 + write[f].get("WRITE_SIZE", 0.0) * 1024 for f in cf if f.startswith(GEMM_FAMILIES + GEMM_AUX))
 if len(sys.argv) > 1 and gl:
     tp = os.path.join(os.path.dirname(sys.argv[1]), "traffic.json")
     json.dump({"source": "tools/summarize_pmc.py over the three --pmc passes named in " + os.path.basename(sys.argv[1]),

@@ -149,9 +149,11 @@ int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const 
 int mx_dwconv_bwd_data(const float* dY, const float* W, const float* residual, float* dX, int N, int H, int Wd, int C,
                        int K, int S, int pad_lo, int Ho, int Wo, void* stream);
 
-/* dW[C,1,K,K] += sum dY * act(X) */
-int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, int N, int H,
-                         int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
+/* dW[C,1,K,K] += sum dY * act(X).  dw_scratch: [mx_dwconv_bwd_weight_parts(N,Ho,Wo,C,S)][C*K*K] floats for per-workgroup
+ * partial rows (added by a second kernel), or NULL (every workgroup adds into dW with atomics: slow when contended). */
+int mx_dwconv_bwd_weight_parts(int N, int Ho, int Wo, int C, int S);
+int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, float* dw_scratch,
+                         int N, int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
 
 /* Stride-1 backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> SE gate in one pass: the BatchNorm-1 data gradient
  * dd = c1*g + c2*D + c3 with g = (dA*gate + add)*swish'(a1*D + b1) is formed while staging (never stored);

@@ -328,7 +328,11 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwArgs a) {
   __syncthreads();
   for (int i = tid; i < K * K * CB; i += 256) {
     int cc = i % CB, tap = i / CB;
-    if (c0 + cc < a.C) unsafeAtomicAdd(a.y + (long)(c0 + cc) * K * K + tap, red[i]);
+    if (c0 + cc >= a.C) continue;
+    // a.stats = scratch [gridDim.x][C*K*K]: one partial row per workgroup, added by dw_parts_reduce_kernel (up to 228
+    // workgroups per channel chunk used to add into the same 16*K*K addresses: contended atomics, 323 us for a 5x5 layer)
+    if (a.stats) a.stats[(long)blockIdx.x * a.C * K * K + (long)(c0 + cc) * K * K + tap] = red[i];
+    else unsafeAtomicAdd(a.y + (long)(c0 + cc) * K * K + tap, red[i]);
   }
 }
 
@@ -666,24 +670,48 @@ int mx_dwconv_bwd_data(const float* dY, const float* W, const float* residual, f
 }
 
 // dW[C,1,K,K] += sum dY * act(X)
-int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, int N, int H,
-                         int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
-  DwArgs a{};
-  a.x = X; a.sc = scale; a.sh = shift; a.dy = dY; a.y = dW;
-  a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
-  MX_CHECK_ARG(X && dY && dW, "dwconv_bwd_weight: null pointer");
-  if (int e = dw_check(a, K, S, "dwconv_bwd_weight")) return e;
+static void dw_bww_geom(int N, int Ho, int Wo, int C, int S, int* tiles_x, int* tiles_y, int* tpb, int* rows) {
   const int TH = 8, TW = (S == 1) ? 16 : 8;
-  a.tiles_x = cdiv(Wo, TW); a.tiles_y = cdiv(Ho, TH);
-  long ntiles = (long)N * a.tiles_x * a.tiles_y;
+  *tiles_x = cdiv(Wo, TW); *tiles_y = cdiv(Ho, TH);
+  long ntiles = (long)N * (*tiles_x) * (*tiles_y);
   int chunks = cdiv(C, CB);
   long groups = 2048 / chunks;
   if (groups < 1) groups = 1;
   if (groups > ntiles) groups = ntiles;
-  a.tiles_per_block = (int)((ntiles + groups - 1) / groups);
-  dim3 grid(cdiv(ntiles, a.tiles_per_block), chunks, 1);
+  *tpb = (int)((ntiles + groups - 1) / groups);
+  *rows = cdiv(ntiles, *tpb);
+}
+
+// number of partial rows [C*K*K] mx_dwconv_bwd_weight writes into dw_scratch
+int mx_dwconv_bwd_weight_parts(int N, int Ho, int Wo, int C, int S) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (S != 1 && S != 2)) return MX_EARG;
+  int tx, ty, tpb, rows;
+  dw_bww_geom(N, Ho, Wo, C, S, &tx, &ty, &tpb, &rows);
+  return rows;
+}
+
+// dw_scratch: [mx_dwconv_bwd_weight_parts][C*K*K] floats (per-workgroup partial rows, reduced by a second kernel), or
+// NULL: every workgroup adds into dW with atomics (slow when many workgroups share a channel chunk)
+int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, float* dw_scratch,
+                         int N, int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
+  DwArgs a{};
+  a.x = X; a.sc = scale; a.sh = shift; a.dy = dY; a.y = dW; a.stats = dw_scratch;
+  a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
+  MX_CHECK_ARG(X && dY && dW, "dwconv_bwd_weight: null pointer");
+  if (int e = dw_check(a, K, S, "dwconv_bwd_weight")) return e;
+  int rows;
+  dw_bww_geom(N, Ho, Wo, C, S, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &rows);
+  dim3 grid(rows, cdiv(C, CB), 1);
   DW_DISPATCH(BWW_S1, BWW_S2, K, S, grid, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();
+  if (dw_scratch) {
+    const int n = C * K * K, nb = cdiv(n, 256);
+    int slices = nb >= 512 ? 1 : cdiv(512, nb);
+    if (slices > cdiv(rows, 8)) slices = cdiv(rows, 8);
+    const int rps = cdiv(rows, slices);
+    hipLaunchKernelGGL(dw_parts_reduce_kernel, dim3(nb, cdiv(rows, rps)), dim3(256), 0, (hipStream_t)stream, dw_scratch, rows, rps, n, dW);
+    MX_LAUNCH_CHECK();
+  }
   return MX_OK;
 }
 

@@ -706,7 +706,8 @@ int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, in
   const int shifts[3] = {21, 10, 0}, bits[3] = {11, 11, 10};
   const unsigned himask[3] = {0u, 0xFFE00000u, 0xFFFFFC00u};
   long HW = (long)H * W;
-  int chunks = (int)((HW + 4095) / 4096);
+  static const int chunk_px = getenv("MX_ER_CHUNK") ? atoi(getenv("MX_ER_CHUNK")) : 1024;   // pixels per workgroup; 4096 / 2048 / 1024 / 512: 0.81 / 0.69 / 0.65 / 0.69 ms (N=16), 1.25 / 1.17 / 1.16 / 1.27 (N=32)
+  int chunks = (int)((HW + chunk_px - 1) / chunk_px);
   if (chunks > 256) chunks = 256;
   for (int ps = 0; ps < 3; ++ps) {
     hipMemsetAsync(hcnt, 0, sizeof(unsigned) * N * RBINS, st);

@@ -311,7 +311,8 @@ def dwconv_bwd_data(dY, W, K, S, pad_lo, H, Wd, *, residual=None):
 def dwconv_bwd_weight(X, dY, dW, K, S, pad_lo, *, st: Optional[BNState] = None):
     N, H, Wd, C = X.shape
     _, Ho, Wo, _ = dY.shape
-    call("mx_dwconv_bwd_weight", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(dY), ptr(dW),
+    scratch = _f32(lib().mx_dwconv_bwd_weight_parts(N, Ho, Wo, C, S), C * K * K, device=X.device)
+    call("mx_dwconv_bwd_weight", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(dY), ptr(dW), ptr(scratch),
          N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
 
 

@@ -72,16 +72,17 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(int mode, const float* x, 
 // ws: N*D floats (normalised embeddings) + N floats (norms)
 // ---------------------------------------------------------------------------
 constexpr int IMC_MAXN = 64;
-__global__ __launch_bounds__(256) void imc_kernel(const float* emb, const float* label, int N, int D, int L, float* out,
+__global__ __launch_bounds__(1024) void imc_kernel(const float* emb, const float* label, int N, int D, int L, float* out,
                                                   float* gemb, float* ws) {
   __shared__ float Wm[IMC_MAXN][IMC_MAXN + 1];   // first S, then the symmetric pair weights
   __shared__ unsigned char Pm[IMC_MAXN][IMC_MAXN], Gm[IMC_MAXN][IMC_MAXN];
   __shared__ float nrm[IMC_MAXN], rowk1[IMC_MAXN], rowk2[IMC_MAXN];
   __shared__ float lossacc, validacc;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NW = blockDim.x >> 6, NT = blockDim.x;          // one workgroup of 16 waves: every phase strides over waves / threads
   float* E = ws;
   if (tid == 0) { lossacc = 0.f; validacc = 0.f; }
-  for (int i = wave; i < N; i += 4) {
+  for (int i = wave; i < N; i += NW) {
     float s = 0.f;
     for (int d = lane; d < D; d += 64) { float v = emb[(long)i * D + d]; s += v * v; }
     s = sqrtf(wave_sum(s));
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void imc_kernel(const float* emb, const float*
     if (lane == 0) nrm[i] = s;
   }
   __syncthreads();
-  for (int p = wave; p < N * N; p += 4) {
+  for (int p = wave; p < N * N; p += NW) {
     int i = p / N, j = p % N;
     if (j <= i) { if (lane == 0) { Wm[i][j] = 0.f; Pm[i][j] = 0; Gm[i][j] = 0; } continue; }
     float dot = 0.f;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void imc_kernel(const float* emb, const float*
   }
   __syncthreads();
   // pair weights dL/d(dot_ij), upper triangle
-  for (int p = tid; p < N * N; p += 256) {
+  for (int p = tid; p < N * N; p += NT) {
     int i = p / N, j = p % N;
     if (j > i) {
       float w = (Pm[i][j] ? rowk1[i] : 0.f) + (Gm[i][j] ? rowk2[i] : 0.f);
@@ -135,13 +136,13 @@ __global__ __launch_bounds__(256) void imc_kernel(const float* emb, const float*
     }
   }
   __syncthreads();
-  for (int p = tid; p < N * N; p += 256) {
+  for (int p = tid; p < N * N; p += NT) {
     int i = p / N, j = p % N;
     if (j < i) Wm[i][j] = Wm[j][i];
   }
   __syncthreads();
   // g_e[i] = sum_j Wsym[i][j] * e_j ; then back through the normalisation
-  for (int i = wave; i < N; i += 4) {
+  for (int i = wave; i < N; i += NW) {
     float dotge = 0.f;
     float gloc[16];   // D <= 1024
     int cnt = 0;
@@ -389,7 +390,7 @@ int mx_cls_loss(int mode, const float* x, int ldx, const float* y, int ldy, floa
 int mx_imc(const float* emb, const float* label, int N, int D, int L, float* out2, float* gemb, float* workspace, void* stream) {
   MX_CHECK_ARG(emb && label && out2 && gemb && workspace, "imc: null pointer");
   MX_CHECK_ARG(N > 0 && N <= IMC_MAXN && D > 0 && D <= 1024 && L > 0, "imc: N=%d (<=64) D=%d (<=1024) L=%d", N, D, L);
-  hipLaunchKernelGGL(imc_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, emb, label, N, D, L, out2, gemb, workspace);
+  hipLaunchKernelGGL(imc_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, emb, label, N, D, L, out2, gemb, workspace);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -268,11 +268,12 @@ struct WtArgs {
   int rows_per_group;      // multiple of 16
   int groups, tiles_co, tiles_ci;
   int accumulate;          // groups == 1: part == dW, add instead of store
+  int total;               // number of workgroup ids (8 * ceil(groups / 8) * tiles)
   int order;               // 0: XCD-aware (tiles of a group on one XCD); 1: group-major; 2: tile-major
 };
 
 template <int TE, int TF, int XMODE>
-__global__ __launch_bounds__(256, (TE * TF >= 16) ? 3 : 4) void wgrad_tile_kernel(WtArgs a) {
+__global__ __launch_bounds__(256, (TE * TF >= 16 && XMODE == MX_BNACT) ? 3 : 4) void wgrad_tile_kernel(WtArgs a) {
   constexpr int TCO = 32 * TE, TCI = 32 * TF;                 // 2 x 2 waves, wave tile 16 TE x 16 TF
   constexpr int SG = (TE == 4) ? 128 : 96, SX = (TF == 4) ? 128 : 96;
   constexpr int SLAB = 16 * (SG + SX);
@@ -282,13 +283,15 @@ __global__ __launch_bounds__(256, (TE * TF >= 16) ? 3 : 4) void wgrad_tile_kerne
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, q = lane >> 4;
   const int wco = wave >> 1, wci = wave & 1;
-  // XCD-aware ids: L % 8 is the XCD (round-robin dispatch); the tiles of one group are consecutive ON that XCD
-  const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+  // XCD-aware ids: L % 8 is the XCD (round-robin dispatch); the tiles of one group are consecutive ON that XCD.
+  // a.total > gridDim.x: persistent workgroups (a multiple of 8 of them) walk the ids L, L + grid, ...: same XCD each time.
   const int tiles = a.tiles_co * a.tiles_ci;
+  for (int L = blockIdx.x; L < a.total; L += gridDim.x) {
+  const int xcd = L & 7, j = L >> 3;
   int group = (j / tiles) * 8 + xcd, tile = j % tiles;
   if (a.order == 1) { group = L / tiles; tile = L % tiles; }
   else if (a.order == 2) { const int g8 = 8 * ((a.groups + 7) / 8); group = L % g8; tile = L / g8; }
-  if (group >= a.groups) return;
+  if (group >= a.groups) continue;
   const int co0 = (tile / a.tiles_ci) * TCO, ci0 = (tile % a.tiles_ci) * TCI;
   const long r_beg = (long)group * a.rows_per_group;
   const long r_end = min((long)a.R, r_beg + a.rows_per_group);
@@ -389,6 +392,8 @@ __global__ __launch_bounds__(256, (TE * TF >= 16) ? 3 : 4) void wgrad_tile_kerne
         *reinterpret_cast<float2*>(o) = v;
       }
     }
+  __syncthreads();                                            // the next work item overwrites the LDS slabs
+  }
 }
 
 struct WtPlan { int te, tf, tiles_co, tiles_ci, groups, rows_per_group; };
@@ -436,10 +441,18 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
 
 template <int TE, int TF>
 static void wt_launch(const WtArgs& a, hipStream_t st) {
-  const dim3 grid(8 * cdiv(a.groups, 8) * a.tiles_co * a.tiles_ci);
-  if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_PLAIN>), grid, dim3(256), 0, st, a);
-  else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_BNACT>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_AFFINE>), grid, dim3(256), 0, st, a);
+  // MX_WGRAD_TILE_PERSIST = n > 0: at most 256 * n persistent workgroups (n per CU) instead of one per id - leaves wave
+  // slots and LDS to the main stream's kernels while this one runs beside them on the side stream
+  static const int persist = getenv("MX_WGRAD_TILE_PERSIST") ? atoi(getenv("MX_WGRAD_TILE_PERSIST")) : 0;
+  WtArgs b = a;
+  b.total = 8 * cdiv(a.groups, 8) * a.tiles_co * a.tiles_ci;
+  int g = b.total;
+  if (persist > 0 && g > 256 * persist) g = 256 * persist;
+  const dim3 grid(g);
+  const WtArgs& a_ = b;
+  if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_PLAIN>), grid, dim3(256), 0, st, a_);
+  else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_BNACT>), grid, dim3(256), 0, st, a_);
+  else hipLaunchKernelGGL((wgrad_tile_kernel<TE, TF, MX_AFFINE>), grid, dim3(256), 0, st, a_);
 }
 
 extern "C" {

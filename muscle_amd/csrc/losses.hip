@@ -658,13 +658,19 @@ __global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, c
       float dot = 0.f;
 #pragma unroll
       for (int k = 1; k < KT; ++k) dot += g[k] * b[k];
-      const int s0 = y0 - cb, s1 = y1 - cb;       // uniform over the workgroup (same Y)
+      // rows y0 and y1 (= y0 or y0 + 1) receive this pixel; y0 - cb is 0 or 1 for the whole band row (a band is shorter
+      // than one low-res row spacing) and uniform over the workgroup: branch once per pixel row, not per class
+      const int s0 = y0 - cb;
       const float w0 = 1.f - wy, w1 = (y1 != y0) ? wy : 0.f;
+      if (s0 == 0) {
 #pragma unroll
-      for (int k = 1; k < KT; ++k) {
-        const float v = b[k] * (g[k] - dot);
-        if (s0 == 0) S[0][k] += w0 * v; else if (s0 == 1) S[1][k] += w0 * v; else S[2][k] += w0 * v;
-        if (s1 == 0) S[0][k] += w1 * v; else if (s1 == 1) S[1][k] += w1 * v; else S[2][k] += w1 * v;
+        for (int k = 1; k < KT; ++k) { const float v = b[k] * (g[k] - dot); S[0][k] += w0 * v; S[1][k] += w1 * v; }
+      } else if (s0 == 1) {
+#pragma unroll
+        for (int k = 1; k < KT; ++k) { const float v = b[k] * (g[k] - dot); S[1][k] += w0 * v; S[2][k] += w1 * v; }
+      } else {
+#pragma unroll
+        for (int k = 1; k < KT; ++k) { const float v = b[k] * (g[k] - dot); S[2][k] += (w0 + w1) * v; }
       }
     }
     const float u0 = 1.f - wx, u1 = (x1 != x0) ? wx : 0.f;

@@ -754,7 +754,7 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_split_kernel(GemmArgs g) {
       float4 v = ra[i];
       if (AMODE != MX_PLAIN && oka[i] && kin) v = nt_prologue<AMODE>(v, sc4, sh4, gt[AMODE == MX_BNACT ? i : 0]);
       put(st, PA_, woff[i], v);
-      if (i < NB) put(st + 3 * PA_, PB_, woff[i], rb[i]);
+if (i < NB) put(st + 3 * PA_, PB_, woff[i], rb[i]);   // (weights split per workgroup: pre-split planes measured 2-6 %)
     }
   };
 

@@ -88,12 +88,19 @@ __global__ __launch_bounds__(256) void upsample_to_nchw_bwd_kernel(const float* 
     if (x1 != x0) atomicAdd(&t[y * Ws + x1], wx * v);
   }
   __syncthreads();
-  (void)sx; (void)sy;
+  (void)sx;
   // stage 2: gather along Y: source row i receives from dst rows with floor(src) == i (w 1-f) or i-1 (w f)
   for (int o = threadIdx.x; o < Hs * Ws; o += 256) {
     int sxi = o % Ws, syi = o / Ws;
     float acc = 0.f;
-    for (int y = 0; y < Hd; ++y) {
+    // only destination rows whose source coordinate y*sy lies in (syi - 1, syi + 1) can name row syi (one row of margin
+    // each side for the rounding of bil_coord); the rest of the 448 rows contributed exact zeros
+    int ylo = 0, yhi = Hd - 1;
+    if (sy > 0.f) {
+      ylo = max(0, (int)floorf((float)(syi - 1) / sy) - 1);
+      yhi = min(Hd - 1, (int)ceilf((float)(syi + 1) / sy) + 1);
+    }
+    for (int y = ylo; y <= yhi; ++y) {
       int y0, y1;
       float wy;
       bil_coord(y, Hs, Hd, y0, y1, wy);

@@ -53,6 +53,9 @@ def check_grads(model, net32, net64, keys_live, tol=2e-3):
     return worst
 
 
+_ORACLE_RUNS = {}
+
+
 @pytest.mark.parametrize("name,n,size,mode,training", [
     ("efficientnet-b0", 3, 64, "cam", True), ("efficientnet-b0", 2, 96, "pix", False),
     ("efficientnet-b3", 2, 72, "cam", True), ("efficientnet-b7", 2, 64, "cam", True),
@@ -63,15 +66,18 @@ def test_model_forward_backward(name, n, size, mode, training):
     cfg, sd, model = build(name, seed)
     x = T(synth.normal(seed, "x", (n, 3, size, size)).astype(np.float32))
     du = gu.drop_draws(cfg, n, 5)
-    nets = []
-    for dt in (torch.float32, torch.float64):
-        net = O.OracleNet(name, sd, dtype=dt)
-        net.train() if training else net.eval()
-        outs = net.forward(x.to(dt), mode, du)
-        probes = [T(synth.normal(seed, f"probe{i}", tuple(o.shape)).astype(np.float32)).to(dt) for i, o in enumerate(outs)]
-        sum((o * p).sum() for o, p in zip(outs, probes)).backward()
-        nets.append((net, outs))
-    (net32, outs32), (net64, outs64) = nets
+    key = (name, n, size, mode, training)
+    if key not in _ORACLE_RUNS:                  # the CPU oracle (fp32 + fp64, ~90 s for B7) is shared with tests/test_gpu_split.py
+        nets = []
+        for dt in (torch.float32, torch.float64):
+            net = O.OracleNet(name, sd, dtype=dt)
+            net.train() if training else net.eval()
+            outs = net.forward(x.to(dt), mode, du)
+            probes = [T(synth.normal(seed, f"probe{i}", tuple(o.shape)).astype(np.float32)).to(dt) for i, o in enumerate(outs)]
+            sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+            nets.append((net, [o.detach() for o in outs]))
+        _ORACLE_RUNS[key] = nets
+    (net32, outs32), (net64, outs64) = _ORACLE_RUNS[key]
     model.train() if training else model.eval()
     got = model(x.to(DEV), cam=mode, drop_u={k: v.to(DEV) for k, v in du.items()})
     assert len(got) == len(outs32)

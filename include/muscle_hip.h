@@ -201,7 +201,8 @@ int mx_infer_norm(float* acc, int channels, long HW, void* stream);
 
 /* ---- input stage (src/data.py:215-332, src/imutils.py:143-181,376-388) ------------------------------
  * dst[n,3,Hd,Wd] (fp32, fully written) = RandomCrop container of color_norm(uint8 HWC crop n) at (top,left), CHW, zeros
- * elsewhere; src = packed crops, jobs = n x 8 int32 {src_off, sh, sw, top, left, 0,0,0}, both on the device.
+ * elsewhere; src = packed crops, jobs = n x 8 int32 {src_off, sh, sw, top, left, ey | ex<<16, eh | ew<<16, 0}, both on the
+ * device; the e* box (0 = none) is RandomErasing(value=0) of train_mcl.py:114 in output coordinates.
  * Bit-exact with the numpy expressions (fp64 (x/255 - mean)/std, one rounding to fp32). */
 int mx_input_stage(const unsigned char* src, const int* jobs, float* dst, int n, int Hd, int Wd, void* stream);
 

@@ -7,7 +7,8 @@
 // the same order, one rounding to fp32.
 #include "common.h"
 
-struct InputJob { int src_off, sh, sw, top, left, pad0, pad1, pad2; };   // uint8 HWC crop [sh, sw, 3] placed at (top, left)
+struct InputJob { int src_off, sh, sw, top, left, erase_yx, erase_hw, pad2; };   // uint8 HWC crop [sh, sw, 3] placed at (top, left);
+// erase_yx = y | x << 16, erase_hw = h | w << 16 of RandomErasing's box in the OUTPUT tensor (0 = none)
 
 __global__ __launch_bounds__(256) void input_stage_kernel(const unsigned char* __restrict__ src, const InputJob* __restrict__ jobs,
                                                           float* __restrict__ dst, int Hd, int Wd) {
@@ -15,6 +16,7 @@ __global__ __launch_bounds__(256) void input_stage_kernel(const unsigned char* _
   const long plane = (long)Hd * Wd;
   float* out = dst + (long)blockIdx.y * 3 * plane;
   const double mean[3] = {0.485, 0.456, 0.406}, stdv[3] = {0.229, 0.224, 0.225};
+  const int ey = jb.erase_yx & 0xffff, ex = (jb.erase_yx >> 16) & 0xffff, eh = jb.erase_hw & 0xffff, ew = (jb.erase_hw >> 16) & 0xffff;
   for (long p = blockIdx.x * 256L + threadIdx.x; p < plane; p += (long)gridDim.x * 256) {
     const int y = (int)(p / Wd), x = (int)(p - (long)y * Wd);
     const int sy = y - jb.top, sx = x - jb.left;
@@ -24,6 +26,7 @@ __global__ __launch_bounds__(256) void input_stage_kernel(const unsigned char* _
 #pragma unroll
       for (int c = 0; c < 3; ++c) v[c] = (float)(((double)px[c] / 255.0 - mean[c]) / stdv[c]);   // imutils.py:383-388
     }
+    if (y >= ey && y < ey + eh && x >= ex && x < ex + ew) v[0] = v[1] = v[2] = 0.f;   // RandomErasing(value=0), train_mcl.py:114
     out[p] = v[0]; out[plane + p] = v[1]; out[2 * plane + p] = v[2];
   }
 }
@@ -31,7 +34,7 @@ __global__ __launch_bounds__(256) void input_stage_kernel(const unsigned char* _
 extern "C" {
 
 // dst[n, 3, Hd, Wd] (fp32, fully written) <- color_norm(src crop n) placed at (top, left), zeros elsewhere.
-// src: packed uint8 HWC crops; jobs: n x 8 int32 {src_off, sh, sw, top, left, 0, 0, 0}; both on the device.
+// src: packed uint8 HWC crops; jobs: n x 8 int32 {src_off, sh, sw, top, left, erase y|x<<16, erase h|w<<16, 0}; both on the device.
 int mx_input_stage(const unsigned char* src, const int* jobs, float* dst, int n, int Hd, int Wd, void* stream) {
   MX_CHECK_ARG(src && jobs && dst, "input_stage: null pointer");
   MX_CHECK_ARG(n > 0 && Hd > 0 && Wd > 0, "input_stage: bad extents n=%d Hd=%d Wd=%d", n, Hd, Wd);

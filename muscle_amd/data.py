@@ -14,9 +14,12 @@ RandomCrop's zero container, HWC -> CHW and the fp32 cast on the device, bit-exa
 Per 448x448 image that is 0.9 MB of uint8 over PCIe instead of 2.4 MB fp32 + 2 x 1.2 MB fp64, and no fp64 numpy
 passes on the host cores (at 8 x 219 img/s the node needs ~1 750 img/s from them).
 
-NOT reproduced (torchvision is not installed where the fixtures are generated, so nothing could pin them):
-`ColorJitter` (image and views) and `RandomErasing`.  With them absent the draws they would consume from torch's
-generator are absent too; everything else follows the reference's draw order.
+`ColorJitter` (image and both views, train_mcl.py:108, src/data.py:223) and `RandomErasing` (train_mcl.py:114) live in
+torchvision, which the reference pins at 0.9.0 (environment.yaml:226) and which is NOT installed in the build container:
+they are restated here from torchvision 0.9.0's published source (transforms.py `ColorJitter.get_params/forward`,
+`RandomErasing.get_params/forward`; functional_pil.py `adjust_*`) - same draws from torch's generator in the same order,
+same PIL calls - and are **parity-unpinned**: no fixture could be generated for them.  `plan_item(..., augment=False)`
+switches both off (the bit-exact fixtures of tests/test_input_path.py were made with identity stand-ins).
 """
 from __future__ import annotations
 
@@ -84,16 +87,80 @@ def random_crop_box(h: int, w: int, cropsize: int):
     return cont_top, cont_left, img_top, img_left, ch, cw
 
 
+# ---- torchvision 0.9.0 ColorJitter / RandomErasing, restated (parity unpinned, see the module docstring) ---------------
+def color_jitter_params(brightness=0.2, contrast=0.2, saturation=0.2, hue=0.1):
+    """ColorJitter.get_params: a permutation of the four adjustments, then one factor each, all from torch's generator.
+    Ranges as ColorJitter._check_input builds them: [max(0, 1 - v), 1 + v] and [-hue, hue]."""
+    order = torch.randperm(4).tolist()
+    draw = lambda lo, hi: float(torch.empty(1).uniform_(lo, hi))  # noqa: E731
+    b = draw(max(0.0, 1.0 - brightness), 1.0 + brightness) if brightness else None
+    c = draw(max(0.0, 1.0 - contrast), 1.0 + contrast) if contrast else None
+    s = draw(max(0.0, 1.0 - saturation), 1.0 + saturation) if saturation else None
+    h = draw(-hue, hue) if hue else None
+    return order, b, c, s, h
+
+
+def apply_color_jitter(pil_img, params):
+    """ColorJitter.forward on a PIL image: functional_pil.adjust_brightness / _contrast / _saturation are PIL's ImageEnhance,
+    adjust_hue shifts the H channel of the HSV image with uint8 wrap-around."""
+    from PIL import Image, ImageEnhance
+    order, b, c, s, h = params
+    for fn in order:
+        if fn == 0 and b is not None:
+            pil_img = ImageEnhance.Brightness(pil_img).enhance(b)
+        elif fn == 1 and c is not None:
+            pil_img = ImageEnhance.Contrast(pil_img).enhance(c)
+        elif fn == 2 and s is not None:
+            pil_img = ImageEnhance.Color(pil_img).enhance(s)
+        elif fn == 3 and h is not None:
+            if not -0.5 <= h <= 0.5:
+                raise ValueError("hue_factor ({}) is not in [-0.5, 0.5].".format(h))
+            mode = pil_img.mode
+            if mode in {"L", "1", "I", "F"}:
+                continue
+            hh, ss, vv = pil_img.convert("HSV").split()
+            np_h = np.array(hh, dtype=np.uint8)
+            # torchvision: `np_h += np.uint8(hue_factor * 255)` under numpy 1.19, where the float -> uint8 conversion
+            # truncates toward zero and wraps (numpy 2 raises instead); the addition itself wraps in uint8
+            with np.errstate(over="ignore"):
+                np_h += np.uint8(int(h * 255) & 0xFF)
+            pil_img = Image.merge("HSV", (Image.fromarray(np_h, "L"), ss, vv)).convert(mode)
+    return pil_img
+
+
+def random_erasing_params(img_h: int, img_w: int, p=0.5, scale=(0.02, 0.2), ratio=(0.3, 3.3)):
+    """RandomErasing.forward + get_params for value=0: torch.rand(1) < p, then up to ten attempts of (area, aspect) ->
+    (h, w) with the box position drawn by two torch.randint.  Returns (i, j, h, w) or None (not applied / no box fits:
+    torchvision then 'erases' with the image itself)."""
+    import math
+    if not (torch.rand(1) < p):
+        return None
+    area = img_h * img_w
+    for _ in range(10):
+        erase_area = area * torch.empty(1).uniform_(scale[0], scale[1]).item()
+        aspect_ratio = torch.empty(1).uniform_(ratio[0], ratio[1]).item()
+        h = int(round(math.sqrt(erase_area * aspect_ratio)))
+        w = int(round(math.sqrt(erase_area / aspect_ratio)))
+        if not (h < img_h and w < img_w):
+            continue
+        i = torch.randint(0, img_h - h + 1, size=(1,)).item()
+        j = torch.randint(0, img_w - w + 1, size=(1,)).item()
+        return i, j, h, w
+    return None
+
+
 class ItemPlan:
     """uint8 crops + placements of one training item, ready for the device stage."""
-    __slots__ = ("img_u8", "img_place", "view1_u8", "view2_u8", "coord1", "coord2", "ori_coord")
+    __slots__ = ("img_u8", "img_place", "view1_u8", "view2_u8", "coord1", "coord2", "ori_coord", "erase")
 
 
-def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(448, 768)) -> ItemPlan:
+def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(448, 768), augment: bool = True) -> ItemPlan:
     """Host side of VOC12ImageViews.__getitem__ (src/data.py:306-315) + the train transform (train_mcl.py:104-115) for
-    one decoded RGB PIL image, in the reference's draw order."""
+    one decoded RGB PIL image, in the reference's draw order: flip, views, [img: resize, jitter, crop, erasing], view1
+    jitter, view2 jitter.  augment=False leaves ColorJitter and RandomErasing out (and their draws with them)."""
     from PIL import Image
     p = ItemPlan()
+    p.erase = None
     if torch.rand(1) < 0.5:                                     # :309-310
         pil_img = pil_img.transpose(Image.FLIP_LEFT_RIGHT)
     w, h = pil_img.size
@@ -103,15 +170,23 @@ def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(
     w2, h2 = views_src.size
     (i1, j1), (i2, j2), rel1, rel2, ori = sample_views(h2, w2, view_size)
     th, tw = view_size
-    p.view1_u8 = np.ascontiguousarray(np.asarray(views_src.crop((j1, i1, j1 + tw, i1 + th))))
-    p.view2_u8 = np.ascontiguousarray(np.asarray(views_src.crop((j2, i2, j2 + tw, i2 + th))))
+    view1 = views_src.crop((j1, i1, j1 + tw, i1 + th))
+    view2 = views_src.crop((j2, i2, j2 + tw, i2 + th))
     p.coord1, p.coord2, p.ori_coord = rel1, rel2, ori
-    # transform(img): RandomResizeLong (bicubic, PIL) -> [ColorJitter: not reproduced] -> color_norm -> RandomCrop -> CHW
+    # transform(img): RandomResizeLong (bicubic, PIL) -> ColorJitter -> color_norm -> RandomCrop -> CHW -> RandomErasing
     big = pil_img.resize(resize_long_target(w, h, *resize_long), resample=Image.BICUBIC)
+    if augment:
+        big = apply_color_jitter(big, color_jitter_params())
     arr = np.asarray(big)
     ct, cl, it, il, ch, cw = random_crop_box(arr.shape[0], arr.shape[1], crop_size)
     p.img_u8 = np.ascontiguousarray(arr[it:it + ch, il:il + cw])
     p.img_place = (ct, cl)
+    if augment:
+        p.erase = random_erasing_params(crop_size, crop_size)          # on the cropped [3, crop, crop] tensor
+        view1 = apply_color_jitter(view1, color_jitter_params())       # view_transform, src/data.py:222-228
+        view2 = apply_color_jitter(view2, color_jitter_params())
+    p.view1_u8 = np.ascontiguousarray(np.asarray(view1))
+    p.view2_u8 = np.ascontiguousarray(np.asarray(view2))
     return p
 
 
@@ -151,6 +226,10 @@ class InputStager:
                 buf[off:off + sz] = a.reshape(-1)
                 top, left = place(p)
                 jobs[kind * self.n + i, :5] = (off, a.shape[0], a.shape[1], top, left)
+                er = getattr(p, "erase", None) if kind == 0 else None
+                if er is not None:                                   # RandomErasing box of the image, output coordinates
+                    jobs[kind * self.n + i, 5] = er[0] | (er[1] << 16)
+                    jobs[kind * self.n + i, 6] = er[2] | (er[3] << 16)
                 off += sz
         self._dev_u8[:off].copy_(self._pin[k][:off], non_blocking=True)
         self._dev_jobs.copy_(self._jobs_pin[k], non_blocking=True)
@@ -178,10 +257,10 @@ class VOC12ClsPix:
     `(img, label, view1, view2, coord1, coord2, ori_coord)` tensors on the GPU."""
 
     def __init__(self, img_name_list_path: str, voc12_root: str, labels: Optional[Dict[str, np.ndarray]] = None,
-                 crop_size: int = 448, view_size=(224, 224)):
+                 crop_size: int = 448, view_size=(224, 224), augment: bool = True):
         import os
         self.names = [ln.split(" ")[0].split("/")[-1].split(".")[0] for ln in open(img_name_list_path).read().splitlines()]
-        self.root, self.crop, self.view = voc12_root, crop_size, view_size
+        self.root, self.crop, self.view, self.augment = voc12_root, crop_size, view_size, augment
         if labels is None and os.path.exists("data/cls_labels.npy"):
             labels = np.load("data/cls_labels.npy", allow_pickle=True).item()          # src/data.py:54-57
         self.labels = labels
@@ -195,4 +274,4 @@ class VOC12ClsPix:
         name = self.names[idx]
         img = PIL.Image.open(os.path.join(self.root, "JPEGImages", name + ".jpg")).convert("RGB")
         lab = None if self.labels is None else np.asarray(self.labels[name], dtype=np.float32)
-        return name, plan_item(img, self.crop, self.view), lab
+        return name, plan_item(img, self.crop, self.view, augment=self.augment), lab

@@ -57,7 +57,7 @@ def test_planner_follows_the_reference_draw_order():
     from muscle_amd import data as D
     _seed()
     for i, im in enumerate(_images()):
-        p = D.plan_item(im)
+        p = D.plan_item(im, augment=False)
         assert np.array_equal(np.array([p.coord1, p.coord2, p.ori_coord]), G[f"coords{i}"]), i
         assert p.view1_u8.shape == (224, 224, 3) and p.view1_u8.dtype == np.uint8
         assert p.img_u8.shape[0] <= 448 and p.img_u8.shape[1] <= 448
@@ -67,7 +67,7 @@ def test_planner_follows_the_reference_draw_order():
 def test_device_stage_bit_exact_with_reference():
     from muscle_amd import data as D
     _seed()
-    plans = [D.plan_item(im) for im in _images()]
+    plans = [D.plan_item(im, augment=False) for im in _images()]
     dev = torch.device("cuda:0")
     stager = D.InputStager(dev, batch=8)
     labels = torch.zeros(N_ITEMS, 20)
@@ -88,7 +88,94 @@ def test_device_stage_bit_exact_with_reference():
     st = (torch.get_rng_state(), random.getstate())
     want = O.input_item(im, resize_long=(300, 400))
     torch.set_rng_state(st[0]); random.setstate(st[1])
-    p = D.plan_item(im, resize_long=(300, 400))
+    p = D.plan_item(im, resize_long=(300, 400), augment=False)
     b = stager([p])
     assert np.array_equal(b["img"][0].cpu().numpy(), want[0]) and float((b["img"][0] == 0).float().mean()) > 0.1
     assert np.array_equal(b["view2"][0].cpu().numpy(), want[2].astype(np.float32))
+
+
+# ---- ColorJitter / RandomErasing: restated from torchvision 0.9.0 (not installed here): PARITY UNPINNED ----------------
+# What can be checked without torchvision: the draws they take from torch's generator (count, order, ranges - as the
+# published source has them), the identities of the PIL adjustments, the erase box on the device, and that switching the
+# augmentations off leaves exactly the draw sequence the pinned fixtures were made with.
+def test_color_jitter_draws_and_identities():
+    from muscle_amd import data as D
+    import PIL.Image
+    torch.manual_seed(5)
+    order, b, c, s, h = D.color_jitter_params()
+    torch.manual_seed(5)
+    want_order = torch.randperm(4).tolist()
+    draws = [float(torch.empty(1).uniform_(lo, hi)) for lo, hi in ((0.8, 1.2), (0.8, 1.2), (0.8, 1.2), (-0.1, 0.1))]
+    assert order == want_order and [b, c, s, h] == draws
+    assert 0.8 <= b <= 1.2 and 0.8 <= c <= 1.2 and 0.8 <= s <= 1.2 and -0.1 <= h <= 0.1
+    im = _images()[0]
+    same = D.apply_color_jitter(im, ([0, 1, 2, 3], 1.0, 1.0, 1.0, None))
+    assert np.array_equal(np.asarray(same), np.asarray(im))                       # factor 1 leaves the image alone
+    dark = D.apply_color_jitter(im, ([0, 1, 2, 3], 0.5, None, None, None))
+    a, d = np.asarray(im).astype(np.int32), np.asarray(dark).astype(np.int32)
+    assert np.abs(d - a // 2).max() <= 1                                           # ImageEnhance.Brightness: blend with black
+    grey = D.apply_color_jitter(im, ([2], None, None, 0.0, None))
+    g = np.asarray(grey)
+    assert np.abs(g[..., 0].astype(int) - g[..., 1]).max() <= 1 and np.abs(g[..., 1].astype(int) - g[..., 2]).max() <= 1
+    hue0 = D.apply_color_jitter(im, ([3], None, None, None, 0.0))                  # HSV round trip only
+    assert np.abs(np.asarray(hue0).astype(int) - a).max() <= 4
+    with pytest.raises(ValueError):
+        D.apply_color_jitter(im, ([3], None, None, None, 0.7))
+    assert isinstance(D.apply_color_jitter(im, D.color_jitter_params()), PIL.Image.Image)
+
+
+def test_random_erasing_params_follow_the_published_loop():
+    from muscle_amd import data as D
+    import math
+    for seed in range(40):
+        torch.manual_seed(seed)
+        box = D.random_erasing_params(448, 448)
+        torch.manual_seed(seed)
+        if not (torch.rand(1) < 0.5):
+            assert box is None
+            continue
+        want = None
+        for _ in range(10):
+            area = 448 * 448 * torch.empty(1).uniform_(0.02, 0.2).item()
+            ar = torch.empty(1).uniform_(0.3, 3.3).item()
+            hh, ww = int(round(math.sqrt(area * ar))), int(round(math.sqrt(area / ar)))
+            if not (hh < 448 and ww < 448):
+                continue
+            want = (torch.randint(0, 448 - hh + 1, size=(1,)).item(), torch.randint(0, 448 - ww + 1, size=(1,)).item(), hh, ww)
+            break
+        assert box == want
+        if box is not None:
+            i, j, hh, ww = box
+            assert 0 <= i and i + hh <= 448 and 0 <= j and j + ww <= 448 and 0.02 * 448 * 448 * 0.9 <= hh * ww <= 0.2 * 448 * 448 * 1.1
+
+
+def test_augment_off_consumes_exactly_the_pinned_draws():
+    """augment=True takes extra draws (3 x (randperm + 4 uniforms) + the erasing draws) but must not move the ones the
+    reference fixture pins: flip, view boxes and coordinates come BEFORE any augmentation draw."""
+    from muscle_amd import data as D
+    im = _images()[0]
+    _seed()
+    p0 = D.plan_item(im, augment=False)
+    _seed()
+    p1 = D.plan_item(im, augment=True)
+    assert (p0.coord1, p0.coord2, p0.ori_coord) == (p1.coord1, p1.coord2, p1.ori_coord)
+    assert p0.erase is None and p1.view1_u8.shape == p0.view1_u8.shape
+    assert p1.img_u8.shape[2] == 3 and p1.img_u8.dtype == np.uint8
+
+
+@pytest.mark.gpu
+def test_device_stage_applies_the_erase_box():
+    from muscle_amd import data as D
+    dev = torch.device("cuda:0")
+    _seed()
+    plans = [D.plan_item(im, augment=False) for im in _images()[:3]]
+    st = D.InputStager(dev, batch=3)
+    base = st(plans)["img"].clone()
+    plans[0].erase = (10, 20, 100, 57)
+    plans[2].erase = (0, 0, 447, 1)
+    out = st(plans)["img"]
+    want = base.clone()
+    want[0, :, 10:110, 20:77] = 0
+    want[2, :, 0:447, 0:1] = 0
+    assert torch.equal(out, want)
+    assert torch.equal(out[1], base[1])

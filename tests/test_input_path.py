@@ -179,3 +179,26 @@ def test_device_stage_applies_the_erase_box():
     want[2, :, 0:447, 0:1] = 0
     assert torch.equal(out, want)
     assert torch.equal(out[1], base[1])
+
+
+@pytest.mark.gpu
+def test_staged_batch_feeds_the_full_loop_body():
+    """End to end: decoded images -> plan_item (with the augmentations) -> InputStager -> mcl_step at epoch 12 (phase 2 reads
+    the views and the overlap coordinates): the batch dict is what the loop body expects and every loss is finite."""
+    import muscle_amd
+    from muscle_amd import data as D
+    dev = torch.device("cuda:0")
+    _seed()
+    ims = _images()[:4]
+    plans = [D.plan_item(im) for im in ims]
+    labels = torch.zeros(4, 20)
+    labels[:, 3] = 1; labels[1, 7] = 1; labels[2, 7] = 1
+    batch = D.InputStager(dev, batch=4)(plans, labels=labels)
+    assert batch["img"].shape == (4, 3, 448, 448) and batch["view1"].shape == (4, 3, 224, 224)
+    assert batch["coord1"].dtype == torch.int64 and batch["coord1"].shape == (4, 4)
+    torch.manual_seed(0)
+    model = muscle_amd.MuSCLe(21, "efficientnet-b0", layers=3, last_pooling=False).to(dev)
+    opt = muscle_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=5e-5)
+    out = muscle_amd.mcl_step(model, opt, batch, 12)
+    for k, v in out.items():
+        assert np.isfinite(float(v)), k

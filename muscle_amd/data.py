@@ -275,3 +275,41 @@ class VOC12ClsPix:
         img = PIL.Image.open(os.path.join(self.root, "JPEGImages", name + ".jpg")).convert("RGB")
         lab = None if self.labels is None else np.asarray(self.labels[name], dtype=np.float32)
         return name, plan_item(img, self.crop, self.view, augment=self.augment), lab
+
+    __getitem__ = plan          # a torch.utils.data map-style dataset: DataLoader workers run the host half
+
+
+def _keep(items):               # collate_fn: the plans stay a list (ragged uint8 crops); module-level so workers can pickle it
+    return items
+
+
+def _reference_worker_init(worker_id):
+    np.random.seed(1 + worker_id)                       # train_mcl.py:127-128
+
+
+class StagedLoader:
+    """The reference's `DataLoader(train_dataset, batch_size, num_workers, pin_memory=True, drop_last=True,
+    worker_init_fn, shuffle=True)` (train_mcl.py:130-132) for this input path: torch's DataLoader runs `VOC12ClsPix.plan`
+    in its worker processes (decode, flip, views, PIL resize, jitter, crop: ~10 ms of one core per image, so 245 img/s per
+    GPU want ~3 cores per GPU) with the SAME per-worker seeding of torch / random as in the reference (base_seed + worker
+    id), and each batch of plans goes through the `InputStager` in the training process: one pinned copy + three launches.
+    Iterating yields `(names, batch)`, `batch` being the dict `mcl_step` takes."""
+
+    def __init__(self, dataset: VOC12ClsPix, batch_size: int, device, num_workers: int = 0, shuffle: bool = True,
+                 drop_last: bool = True, generator=None):
+        from torch.utils.data import DataLoader
+        self.dataset, self.stager = dataset, InputStager(device, batch_size, dataset.crop, dataset.view)
+        self.loader = DataLoader(dataset, batch_size=batch_size, shuffle=shuffle, num_workers=num_workers, drop_last=drop_last,
+                                 collate_fn=_keep, worker_init_fn=_reference_worker_init if num_workers else None,
+                                 generator=generator, persistent_workers=bool(num_workers))
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        for items in self.loader:
+            names = [it[0] for it in items]
+            labels = None
+            if items[0][2] is not None:
+                labels = torch.from_numpy(np.stack([it[2] for it in items]))
+            yield names, self.stager([it[1] for it in items], labels=labels)

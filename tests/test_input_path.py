@@ -202,3 +202,61 @@ def test_staged_batch_feeds_the_full_loop_body():
     out = muscle_amd.mcl_step(model, opt, batch, 12)
     for k, v in out.items():
         assert np.isfinite(float(v)), k
+
+
+def _voc_tree(tmp_path):
+    """A tiny VOC-style tree from the fixture JPEGs: JPEGImages/*.jpg, a train list in the reference's format, labels."""
+    root = tmp_path / "VOC2012"
+    (root / "JPEGImages").mkdir(parents=True)
+    names = []
+    for i in range(N_ITEMS):
+        nm = f"2007_{i:06d}"
+        (root / "JPEGImages" / (nm + ".jpg")).write_bytes(G[f"jpg{i}"].tobytes())
+        names.append(nm)
+    lst = tmp_path / "train_aug.txt"
+    lst.write_text("\n".join(f"/JPEGImages/{n}.jpg /SegmentationClassAug/{n}.png" for n in names) + "\n")
+    labels = {n: np.eye(20, dtype=np.float32)[i % 20] for i, n in enumerate(names)}
+    return str(lst), str(root), labels, names
+
+
+def test_dataset_and_worker_loader(tmp_path):
+    """VOC12ClsPix reads the reference's list format; torch DataLoader workers run the host half and hand the plans back
+    intact; without workers the loader is exactly sequential `plan` calls on the caller's generators."""
+    from torch.utils.data import DataLoader
+    from muscle_amd import data as D
+    lst, root, labels, names = _voc_tree(tmp_path)
+    ds = D.VOC12ClsPix(lst, root, labels=labels, augment=True)
+    assert len(ds) == N_ITEMS and ds.names == names
+    _seed()
+    torch.empty((), dtype=torch.int64).random_()      # the base seed a DataLoader iterator draws first (also in the reference)
+    direct = [ds.plan(i) for i in range(N_ITEMS)]
+    _seed()
+    seq = [it for batch in DataLoader(ds, batch_size=2, shuffle=False, num_workers=0, collate_fn=D._keep) for it in batch]
+    for (n0, p0, l0), (n1, p1, l1) in zip(direct, seq):
+        assert n0 == n1 and np.array_equal(l0, l1) and p0.coord1 == p1.coord1 and p0.erase == p1.erase
+        assert np.array_equal(p0.img_u8, p1.img_u8) and np.array_equal(p0.view2_u8, p1.view2_u8)
+    got = []
+    for batch in DataLoader(ds, batch_size=3, shuffle=False, num_workers=2, collate_fn=D._keep, worker_init_fn=D._reference_worker_init):
+        assert len(batch) == 3
+        for name, p, lab in batch:
+            assert p.img_u8.dtype == np.uint8 and p.img_u8.shape[2] == 3 and p.view1_u8.shape == (224, 224, 3)
+            assert p.img_u8.shape[0] <= 448 and p.img_u8.shape[1] <= 448 and lab.shape == (20,)
+            got.append(name)
+    assert got == names
+
+
+@pytest.mark.gpu
+def test_staged_loader_yields_loop_body_batches(tmp_path):
+    from muscle_amd import data as D
+    lst, root, labels, names = _voc_tree(tmp_path)
+    ds = D.VOC12ClsPix(lst, root, labels=labels)
+    loader = D.StagedLoader(ds, batch_size=2, device=torch.device("cuda:0"), num_workers=2, shuffle=True,
+                            generator=torch.Generator().manual_seed(3))
+    assert len(loader) == 3
+    seen = []
+    for nm, batch in loader:
+        seen += nm
+        assert batch["img"].shape == (2, 3, 448, 448) and batch["img"].is_cuda and batch["label"].shape == (2, 20)
+        assert batch["view2"].shape == (2, 3, 224, 224) and batch["ori_coord"].shape == (2, 4)
+        assert torch.isfinite(batch["img"]).all()
+    assert sorted(seen) == names

@@ -201,10 +201,17 @@ int mx_infer_norm(float* acc, int channels, long HW, void* stream);
 
 /* ---- input stage (src/data.py:215-332, src/imutils.py:143-181,376-388) ------------------------------
  * dst[n,3,Hd,Wd] (fp32, fully written) = RandomCrop container of color_norm(uint8 HWC crop n) at (top,left), CHW, zeros
- * elsewhere; src = packed crops, jobs = n x 8 int32 {src_off, sh, sw, top, left, ey | ex<<16, eh | ew<<16, 0}, both on the
+ * elsewhere; src = packed crops, jobs = n x 8 int32 {src_off, sh, sw, top, left, ey | ex<<16, eh | ew<<16, source row
+ * stride in pixels or 0 = sw}, both on the
  * device; the e* box (0 = none) is RandomErasing(value=0) of train_mcl.py:114 in output coordinates.
  * Bit-exact with the numpy expressions (fp64 (x/255 - mean)/std, one rounding to fp32). */
 int mx_input_stage(const unsigned char* src, const int* jobs, float* dst, int n, int Hd, int Wd, void* stream);
+
+/* transforms.ColorJitter (train_mcl.py:108, src/data.py:223; torchvision 0.9.0 PIL backend = Pillow's ImagingBlend, rgb2l,
+ * rgb2hsv_row / hsv2rgb) in place on n uint8 HWC images inside src, bit-exact with Pillow.  jobs: n x 8 words {byte
+ * offset, h, w, order (one nibble per position: 0 brightness, 1 contrast, 2 saturation, 3 hue, 15 none), brightness,
+ * contrast, saturation factors (float32), hue shift 0..255}; sums: n uint64 of scratch. */
+int mx_color_jitter(unsigned char* src, const int* jobs, unsigned long long* sums, int n, int max_pixels, void* stream);
 
 /* ---- IRN random-walk propagation (src/indexing.py:77-142 as called by infer_irn.py:76).
  * mx_irn_affinity: dense[n4][ld] (zero-filled here) <- symmetric affinity 1 - max(edge along the straight path) for every

@@ -18,7 +18,9 @@ passes on the host cores (at 8 x 219 img/s the node needs ~1 750 img/s from them
 torchvision, which the reference pins at 0.9.0 (environment.yaml:226) and which is NOT installed in the build container:
 they are restated here from torchvision 0.9.0's published source (transforms.py `ColorJitter.get_params/forward`,
 `RandomErasing.get_params/forward`; functional_pil.py `adjust_*`) - same draws from torch's generator in the same order,
-same PIL calls - and are **parity-unpinned**: no fixture could be generated for them.  `plan_item(..., augment=False)`
+same PIL calls - and are **parity-unpinned** as far as torchvision's glue goes (which draws, in which order): no fixture
+could be generated for them.  The pixel arithmetic is Pillow's, and `mx_color_jitter` (device_jitter=True) is tested
+bit-exact against Pillow itself.  `plan_item(..., augment=False)`
 switches both off (the bit-exact fixtures of tests/test_input_path.py were made with identity stand-ins).
 """
 from __future__ import annotations
@@ -151,16 +153,21 @@ def random_erasing_params(img_h: int, img_w: int, p=0.5, scale=(0.02, 0.2), rati
 
 class ItemPlan:
     """uint8 crops + placements of one training item, ready for the device stage."""
-    __slots__ = ("img_u8", "img_place", "view1_u8", "view2_u8", "coord1", "coord2", "ori_coord", "erase")
+    __slots__ = ("img_u8", "img_place", "view1_u8", "view2_u8", "coord1", "coord2", "ori_coord", "erase", "jitter", "img_crop")
+    # jitter: None, or the three ColorJitter parameter sets (image, view 1, view 2) still TO BE applied - on the device;
+    # then img_u8 is the whole resized image and img_crop = (top, left, h, w) the RandomCrop window inside it
 
 
-def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(448, 768), augment: bool = True) -> ItemPlan:
+def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(448, 768), augment: bool = True,
+              device_jitter: bool = False) -> ItemPlan:
     """Host side of VOC12ImageViews.__getitem__ (src/data.py:306-315) + the train transform (train_mcl.py:104-115) for
     one decoded RGB PIL image, in the reference's draw order: flip, views, [img: resize, jitter, crop, erasing], view1
-    jitter, view2 jitter.  augment=False leaves ColorJitter and RandomErasing out (and their draws with them)."""
+    jitter, view2 jitter.  augment=False leaves ColorJitter and RandomErasing out (and their draws with them).
+    device_jitter: draw the ColorJitter parameters here but leave the pixel work to `mx_color_jitter` (bit-exact with the
+    PIL calls, 5x less host time per item): the plan then carries the whole resized image."""
     from PIL import Image
     p = ItemPlan()
-    p.erase = None
+    p.erase = p.jitter = p.img_crop = None
     if torch.rand(1) < 0.5:                                     # :309-310
         pil_img = pil_img.transpose(Image.FLIP_LEFT_RIGHT)
     w, h = pil_img.size
@@ -175,16 +182,25 @@ def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(
     p.coord1, p.coord2, p.ori_coord = rel1, rel2, ori
     # transform(img): RandomResizeLong (bicubic, PIL) -> ColorJitter -> color_norm -> RandomCrop -> CHW -> RandomErasing
     big = pil_img.resize(resize_long_target(w, h, *resize_long), resample=Image.BICUBIC)
+    jit = []
     if augment:
-        big = apply_color_jitter(big, color_jitter_params())
+        jit.append(color_jitter_params())
+        if not device_jitter:
+            big = apply_color_jitter(big, jit[0])
     arr = np.asarray(big)
     ct, cl, it, il, ch, cw = random_crop_box(arr.shape[0], arr.shape[1], crop_size)
-    p.img_u8 = np.ascontiguousarray(arr[it:it + ch, il:il + cw])
+    if augment and device_jitter:
+        p.img_u8, p.img_crop = np.ascontiguousarray(arr), (it, il, ch, cw)   # contrast needs the whole image's mean
+    else:
+        p.img_u8 = np.ascontiguousarray(arr[it:it + ch, il:il + cw])
     p.img_place = (ct, cl)
     if augment:
         p.erase = random_erasing_params(crop_size, crop_size)          # on the cropped [3, crop, crop] tensor
-        view1 = apply_color_jitter(view1, color_jitter_params())       # view_transform, src/data.py:222-228
-        view2 = apply_color_jitter(view2, color_jitter_params())
+        jit += [color_jitter_params(), color_jitter_params()]          # view_transform, src/data.py:222-228
+        if device_jitter:
+            p.jitter = jit
+        else:
+            view1, view2 = apply_color_jitter(view1, jit[1]), apply_color_jitter(view2, jit[2])
     p.view1_u8 = np.ascontiguousarray(np.asarray(view1))
     p.view2_u8 = np.ascontiguousarray(np.asarray(view2))
     return p
@@ -195,15 +211,20 @@ class InputStager:
     """Packs the uint8 crops of a batch into one pinned buffer, copies it once and runs `mx_input_stage` three times
     (img, view1, view2).  Two pinned buffers alternate so that packing batch t+1 does not wait for the copy of batch t."""
 
-    def __init__(self, device, batch: int, crop_size: int = 448, view_size=(224, 224)):
+    def __init__(self, device, batch: int, crop_size: int = 448, view_size=(224, 224), max_long: int = 768):
         self.dev, self.n, self.crop, self.view = device, batch, crop_size, view_size
-        cap = batch * (crop_size * crop_size + 2 * view_size[0] * view_size[1]) * 3
+        # room for whole resized images (long side <= max_long) when the ColorJitter runs on the device
+        cap = batch * (max(crop_size, max_long) ** 2 + 2 * view_size[0] * view_size[1]) * 3
         self._pin = [torch.empty(cap, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(cap, dtype=torch.uint8)
                      for _ in range(2)]
         self._jobs_pin = [torch.empty(3 * batch * 8, dtype=torch.int32).pin_memory() if torch.cuda.is_available()
                           else torch.empty(3 * batch * 8, dtype=torch.int32) for _ in range(2)]
         self._dev_u8 = torch.empty(cap, dtype=torch.uint8, device=device)
         self._dev_jobs = torch.empty(3 * batch * 8, dtype=torch.int32, device=device)
+        self._jit_pin = [torch.empty(3 * batch * 8, dtype=torch.int32).pin_memory() if torch.cuda.is_available()
+                         else torch.empty(3 * batch * 8, dtype=torch.int32) for _ in range(2)]
+        self._dev_jit = torch.empty(3 * batch * 8, dtype=torch.int32, device=device)
+        self._dev_sums = torch.empty(3 * batch, dtype=torch.int64, device=device)
         self._flip = 0
         self._evt = [None, None]
 
@@ -215,8 +236,13 @@ class InputStager:
         if self._evt[k] is not None:
             self._evt[k].synchronize()                      # the copy out of this pinned buffer two batches ago is done
         buf, jobs = self._pin[k].numpy(), self._jobs_pin[k].numpy().reshape(3 * self.n, 8)
+        jit = self._jit_pin[k].numpy().reshape(3 * self.n, 8)
+        jit_f = jit.view(np.float32)
         off = 0
         jobs[:] = 0
+        jit[:] = 0
+        jit[:, 3] = 0xFFFF                                  # order nibbles: nothing to do
+        any_jit, max_px = False, 1
         for kind, (get, place) in enumerate(((lambda p: p.img_u8, lambda p: p.img_place),
                                              (lambda p: p.view1_u8, lambda p: (0, 0)),
                                              (lambda p: p.view2_u8, lambda p: (0, 0)))):
@@ -225,20 +251,41 @@ class InputStager:
                 sz = a.size
                 buf[off:off + sz] = a.reshape(-1)
                 top, left = place(p)
-                jobs[kind * self.n + i, :5] = (off, a.shape[0], a.shape[1], top, left)
+                row = kind * self.n + i
+                jobs[row, :5] = (off, a.shape[0], a.shape[1], top, left)
+                pj = getattr(p, "jitter", None)
+                if pj is not None:                                   # ColorJitter still to be applied: on the device
+                    order, fb, fc, fs, fh = pj[kind]
+                    code = 0
+                    for pos in range(4):
+                        fn = order[pos]
+                        live = (fb, fc, fs, fh)[fn] is not None
+                        code |= (fn if live else 15) << (4 * pos)
+                    jit[row, :4] = (off, a.shape[0], a.shape[1], code)
+                    jit_f[row, 4:7] = (fb or 0.0, fc or 0.0, fs or 0.0)
+                    jit[row, 7] = (int(fh * 255) & 0xFF) if fh is not None else 0
+                    any_jit, max_px = True, max(max_px, a.shape[0] * a.shape[1])
+                    if kind == 0:                                    # the stage reads the crop window inside the whole image
+                        it, il, ch, cw = p.img_crop
+                        jobs[row, :3] = (off + (it * a.shape[1] + il) * 3, ch, cw)
+                        jobs[row, 7] = a.shape[1]
                 er = getattr(p, "erase", None) if kind == 0 else None
                 if er is not None:                                   # RandomErasing box of the image, output coordinates
-                    jobs[kind * self.n + i, 5] = er[0] | (er[1] << 16)
-                    jobs[kind * self.n + i, 6] = er[2] | (er[3] << 16)
+                    jobs[row, 5] = er[0] | (er[1] << 16)
+                    jobs[row, 6] = er[2] | (er[3] << 16)
                 off += sz
         self._dev_u8[:off].copy_(self._pin[k][:off], non_blocking=True)
         self._dev_jobs.copy_(self._jobs_pin[k], non_blocking=True)
+        if any_jit:
+            self._dev_jit.copy_(self._jit_pin[k], non_blocking=True)
         evt = torch.cuda.Event()
         evt.record()
         self._evt[k] = evt
         img = torch.empty(n, 3, self.crop, self.crop, dtype=torch.float32, device=self.dev)
         v1 = torch.empty(n, 3, self.view[0], self.view[1], dtype=torch.float32, device=self.dev)
         v2 = torch.empty_like(v1)
+        if any_jit:
+            call("mx_color_jitter", ptr(self._dev_u8), ptr(self._dev_jit), ptr(self._dev_sums), 3 * self.n, int(max_px), stream())
         for kind, dst in enumerate((img, v1, v2)):
             call("mx_input_stage", ptr(self._dev_u8), self._dev_jobs.data_ptr() + 4 * 8 * kind * self.n, ptr(dst), n, dst.shape[2],
                  dst.shape[3], stream())
@@ -257,10 +304,10 @@ class VOC12ClsPix:
     `(img, label, view1, view2, coord1, coord2, ori_coord)` tensors on the GPU."""
 
     def __init__(self, img_name_list_path: str, voc12_root: str, labels: Optional[Dict[str, np.ndarray]] = None,
-                 crop_size: int = 448, view_size=(224, 224), augment: bool = True):
+                 crop_size: int = 448, view_size=(224, 224), augment: bool = True, device_jitter: bool = True):
         import os
         self.names = [ln.split(" ")[0].split("/")[-1].split(".")[0] for ln in open(img_name_list_path).read().splitlines()]
-        self.root, self.crop, self.view, self.augment = voc12_root, crop_size, view_size, augment
+        self.root, self.crop, self.view, self.augment, self.device_jitter = voc12_root, crop_size, view_size, augment, device_jitter
         if labels is None and os.path.exists("data/cls_labels.npy"):
             labels = np.load("data/cls_labels.npy", allow_pickle=True).item()          # src/data.py:54-57
         self.labels = labels
@@ -274,7 +321,7 @@ class VOC12ClsPix:
         name = self.names[idx]
         img = PIL.Image.open(os.path.join(self.root, "JPEGImages", name + ".jpg")).convert("RGB")
         lab = None if self.labels is None else np.asarray(self.labels[name], dtype=np.float32)
-        return name, plan_item(img, self.crop, self.view, augment=self.augment), lab
+        return name, plan_item(img, self.crop, self.view, augment=self.augment, device_jitter=self.device_jitter), lab
 
     __getitem__ = plan          # a torch.utils.data map-style dataset: DataLoader workers run the host half
 

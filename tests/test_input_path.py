@@ -240,7 +240,7 @@ def test_dataset_and_worker_loader(tmp_path):
         assert len(batch) == 3
         for name, p, lab in batch:
             assert p.img_u8.dtype == np.uint8 and p.img_u8.shape[2] == 3 and p.view1_u8.shape == (224, 224, 3)
-            assert p.img_u8.shape[0] <= 448 and p.img_u8.shape[1] <= 448 and lab.shape == (20,)
+            assert max(p.img_u8.shape[:2]) <= 768 and p.img_crop[2] <= 448 and p.img_crop[3] <= 448 and lab.shape == (20,)   # whole resized image: the jitter runs on the device
             got.append(name)
     assert got == names
 
@@ -260,3 +260,90 @@ def test_staged_loader_yields_loop_body_batches(tmp_path):
         assert batch["view2"].shape == (2, 3, 224, 224) and batch["ori_coord"].shape == (2, 4)
         assert torch.isfinite(batch["img"]).all()
     assert sorted(seen) == names
+
+
+@pytest.mark.gpu
+def test_device_color_jitter_is_bit_exact_with_pil():
+    """mx_color_jitter against the PIL calls torchvision's ColorJitter makes (Pillow itself is the comparator): same seeds,
+    once with the pixel work on the host, once on the device - the staged fp32 tensors must be identical, for every image,
+    for many parameter draws (all adjustment orders occur), with and without the erase box."""
+    from muscle_amd import data as D
+    dev = torch.device("cuda:0")
+    ims = _images()
+    st = D.InputStager(dev, batch=len(ims))
+    orders = set()
+    for rep in range(6):
+        torch.manual_seed(100 + rep); random.seed(200 + rep)
+        host = [D.plan_item(im, augment=True, device_jitter=False) for im in ims]
+        torch.manual_seed(100 + rep); random.seed(200 + rep)
+        devp = [D.plan_item(im, augment=True, device_jitter=True) for im in ims]
+        for h, d in zip(host, devp):
+            assert h.coord1 == d.coord1 and h.erase == d.erase and h.img_place == d.img_place and d.jitter is not None
+            orders.add(tuple(d.jitter[0][0]))
+        a = {k: v.clone() for k, v in st(host).items()}
+        b = st(devp)
+        for k in ("img", "view1", "view2"):
+            assert torch.equal(a[k], b[k]), (rep, k, float((a[k] - b[k]).abs().max()))
+    assert len(orders) >= 8
+
+
+@pytest.mark.gpu
+def test_device_color_jitter_extreme_factors():
+    """Factors outside [0, 1] take ImagingBlend's extrapolation branch (clamping); 0 and 1 the interpolation branch."""
+    from muscle_amd import data as D
+    dev = torch.device("cuda:0")
+    im = _images()[2]
+    st = D.InputStager(dev, batch=1)
+    for params in (([0, 1, 2, 3], 1.9, 1.7, 0.0, 0.5), ([3, 2, 1, 0], 0.0, 1.0, 2.0, -0.5), ([1, 3, 0, 2], 0.31, 0.0, 1.0, 0.123),
+                   ([2, 0, 3, 1], 1.0, 3.0, 0.5, -0.25)):
+        torch.manual_seed(1); random.seed(1)
+        d = D.plan_item(im, augment=True, device_jitter=True)
+        d.jitter = [params, params, params]
+        torch.manual_seed(1); random.seed(1)
+        h = D.plan_item(im, augment=False)
+        # host reference: the same geometry, PIL adjustments applied to the whole resized image / the views
+        import PIL.Image
+        big = PIL.Image.fromarray(d.img_u8, "RGB")
+        it, il, ch, cw = d.img_crop
+        h.img_u8 = np.ascontiguousarray(np.asarray(D.apply_color_jitter(big, params))[it:it + ch, il:il + cw])
+        h.view1_u8 = np.ascontiguousarray(np.asarray(D.apply_color_jitter(PIL.Image.fromarray(d.view1_u8, "RGB"), params)))
+        h.view2_u8 = np.ascontiguousarray(np.asarray(D.apply_color_jitter(PIL.Image.fromarray(d.view2_u8, "RGB"), params)))
+        h.erase = d.erase
+        a = {k: v.clone() for k, v in st([h]).items()}
+        b = st([d])
+        for k in ("img", "view1", "view2"):
+            assert torch.equal(a[k], b[k]), (params, k)
+
+
+@pytest.mark.gpu
+def test_device_hue_and_blends_over_all_16m_colours():
+    """mx_color_jitter called directly on a 4096 x 4096 image holding every RGB colour once: the hue path (Pillow's
+    rgb2hsv_row / hsv2rgb) for several shifts and the three blends at an interpolating and an extrapolating factor must
+    equal Pillow's own output for every colour."""
+    import PIL.Image
+    from muscle_amd import data as D
+    from muscle_amd._lib import call, ptr, stream
+    dev = torch.device("cuda:0")
+    r, g, b = np.meshgrid(np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), np.arange(256, dtype=np.uint8), indexing="ij")
+    rgb = np.ascontiguousarray(np.stack([r.ravel(), g.ravel(), b.ravel()], 1).reshape(4096, 4096, 3))
+    im = PIL.Image.fromarray(rgb, "RGB")
+    sums = torch.zeros(1, dtype=torch.int64, device=dev)
+    for params in (([3, 0, 1, 2], None, None, None, 37 / 255 + 1e-4), ([3, 0, 1, 2], None, None, None, -0.5), ([3, 0, 1, 2], None, None, None, 0.0),
+                   ([0, 1, 2, 3], 0.83, None, None, None), ([0, 1, 2, 3], 1.19, None, None, None), ([0, 1, 2, 3], None, 0.9, None, None),
+                   ([0, 1, 2, 3], None, 1.15, None, None), ([0, 1, 2, 3], None, None, 0.87, None), ([0, 1, 2, 3], None, None, 1.2, None),
+                   ([2, 3, 1, 0], 1.1, 0.9, 1.05, 0.07)):
+        want = np.asarray(D.apply_color_jitter(im, params))
+        order, fb, fc, fs, fh = params
+        code = 0
+        for pos in range(4):
+            fn = order[pos]
+            code |= (fn if (fb, fc, fs, fh)[fn] is not None else 15) << (4 * pos)
+        job = np.zeros(8, dtype=np.int32)
+        job[:4] = (0, 4096, 4096, code)
+        job.view(np.float32)[4:7] = (fb or 0.0, fc or 0.0, fs or 0.0)
+        job[7] = (int(fh * 255) & 0xFF) if fh is not None else 0
+        buf = torch.from_numpy(rgb.copy()).to(dev)
+        jobs = torch.from_numpy(job).to(dev)
+        call("mx_color_jitter", ptr(buf), ptr(jobs), ptr(sums), 1, 4096 * 4096, stream())
+        got = buf.cpu().numpy()
+        assert np.array_equal(got, want), (params, int((got != want).any(-1).sum()))

@@ -213,6 +213,14 @@ int mx_input_stage(const unsigned char* src, const int* jobs, float* dst, int n,
  * contrast, saturation factors (float32), hue shift 0..255}; sums: n uint64 of scratch. */
 int mx_color_jitter(unsigned char* src, const int* jobs, unsigned long long* sums, int n, int max_pixels, void* stream);
 
+/* PIL.Image.resize (imutils.RandomResizeLong's bicubic, src/imutils.py:127-141; get_views' bilinear 448x448,
+ * src/data.py:274-276) = Pillow's 8-bit ImagingResample: horizontal pass src -> tmp, vertical pass tmp -> dst, 22-bit
+ * fixed-point coefficient tables computed by the host as Pillow's precompute_coeffs does.  jobs: n x 8 int32 {src_off, Hin,
+ * Win, tmp_off, dst_off, Wout, Hout, tab_off}; tabs (int32): per job ksize_h, ksize_v, bounds_h[Wout][2], kk_h[Wout][ksize_h],
+ * bounds_v[Hout][2], kk_v[Hout][ksize_v].  Bit-exact with Pillow. */
+int mx_resample(const unsigned char* src, const int* jobs, const int* tabs, unsigned char* tmp, unsigned char* dst, int n,
+                int max_pixels, void* stream);
+
 /* ---- IRN random-walk propagation (src/indexing.py:77-142 as called by infer_irn.py:76).
  * mx_irn_affinity: dense[n4][ld] (zero-filled here) <- symmetric affinity 1 - max(edge along the straight path) for every
  *   pixel pair joined by one of the nd search directions, unit diagonal; edge [h,w]; pcoord = int32 (dy,dx) pairs of all

@@ -142,6 +142,58 @@ __global__ __launch_bounds__(256) void jitter_apply_kernel(unsigned char* __rest
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// PIL.Image.resize (RandomResizeLong's bicubic, get_views' bilinear 448 x 448; imutils.py:127-141, data.py:274-276) on the
+// device: Pillow's ImagingResample for 8-bit images is integer arithmetic - per output column / row a window [xmin, xmin +
+// n) of the input and n coefficients in 22-bit fixed point (computed on the host in double exactly as precompute_coeffs +
+// normalize_coeffs_8bpc do), ss = 2^21 + sum in[x] * k[x], out = clip8(ss >> 22) - horizontal pass into a temporary 8-bit
+// image, then the vertical pass.  Bit-exact with Pillow (tests/test_input_path.py).
+// Job: {src_off, Hin, Win, tmp_off, dst_off, Wout, Hout, tab_off}; table at tab_off (int32 words): ksize_h, ksize_v,
+// bounds_h[Wout][2], kk_h[Wout][ksize_h], bounds_v[Hout][2], kk_v[Hout][ksize_v].
+struct ResampleJob { int src_off, hin, win, tmp_off, dst_off, wout, hout, tab_off; };
+
+__device__ __forceinline__ unsigned char rs_clip8(int v) { v >>= 22; return (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+__global__ __launch_bounds__(256) void resample_h_kernel(const unsigned char* __restrict__ src, const ResampleJob* __restrict__ jobs,
+                                                         const int* __restrict__ tabs, unsigned char* __restrict__ tmp) {
+  const ResampleJob jb = jobs[blockIdx.y];
+  const int* tab = tabs + jb.tab_off;
+  const int ks = tab[0];
+  const int* bounds = tab + 2;
+  const int* kk = bounds + 2 * jb.wout;
+  const long total = (long)jb.hin * jb.wout;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+    const int y = (int)(p / jb.wout), xx = (int)(p - (long)y * jb.wout);
+    const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+    const int* k = kk + (long)xx * ks;
+    const unsigned char* in = src + jb.src_off + ((long)y * jb.win + xmin) * 3;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int x = 0; x < n; ++x) { const int c = k[x]; s0 += in[3 * x] * c; s1 += in[3 * x + 1] * c; s2 += in[3 * x + 2] * c; }
+    unsigned char* o = tmp + jb.tmp_off + p * 3;
+    o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+  }
+}
+
+__global__ __launch_bounds__(256) void resample_v_kernel(const unsigned char* __restrict__ tmp, const ResampleJob* __restrict__ jobs,
+                                                         const int* __restrict__ tabs, unsigned char* __restrict__ dst) {
+  const ResampleJob jb = jobs[blockIdx.y];
+  const int* tab = tabs + jb.tab_off;
+  const int ksh = tab[0], ks = tab[1];
+  const int* bounds = tab + 2 + 2 * jb.wout + (long)jb.wout * ksh;
+  const int* kk = bounds + 2 * jb.hout;
+  const long total = (long)jb.hout * jb.wout;
+  for (long p = blockIdx.x * 256L + threadIdx.x; p < total; p += (long)gridDim.x * 256) {
+    const int yy = (int)(p / jb.wout), x = (int)(p - (long)yy * jb.wout);
+    const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+    const int* k = kk + (long)yy * ks;
+    const unsigned char* in = tmp + jb.tmp_off + ((long)ymin * jb.wout + x) * 3;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int y = 0; y < n; ++y) { const int c = k[y]; const unsigned char* q = in + (long)y * jb.wout * 3; s0 += q[0] * c; s1 += q[1] * c; s2 += q[2] * c; }
+    unsigned char* o = dst + jb.dst_off + p * 3;
+    o[0] = rs_clip8(s0); o[1] = rs_clip8(s1); o[2] = rs_clip8(s2);
+  }
+}
+
 extern "C" {
 
 // dst[n, 3, Hd, Wd] (fp32, fully written) <- color_norm(src crop n) placed at (top, left), zeros elsewhere.
@@ -171,6 +223,21 @@ int mx_color_jitter(unsigned char* src, const int* jobs, unsigned long long* sum
     hipLaunchKernelGGL(jitter_lsum_kernel, dim3(bx, n), dim3(256), 0, st, src, (const JitterJob*)jobs, sums, pos);
     hipLaunchKernelGGL(jitter_apply_kernel, dim3(bx, n), dim3(256), 0, st, src, (const JitterJob*)jobs, sums, pos);
   }
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// Pillow's 8-bit two-pass resample of n uint8 HWC images: src -> (horizontal) tmp -> (vertical) dst; jobs n x 8 int32
+// {src_off, Hin, Win, tmp_off, dst_off, Wout, Hout, tab_off (words)}; tabs: the coefficient tables (see above).
+int mx_resample(const unsigned char* src, const int* jobs, const int* tabs, unsigned char* tmp, unsigned char* dst, int n,
+                int max_pixels, void* stream) {
+  MX_CHECK_ARG(src && jobs && tabs && tmp && dst && n > 0 && max_pixels > 0, "resample: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int bx = cdiv(max_pixels, 256 * 4);
+  if (bx < 1) bx = 1;
+  if (bx > 512) bx = 512;
+  hipLaunchKernelGGL(resample_h_kernel, dim3(bx, n), dim3(256), 0, st, src, (const ResampleJob*)jobs, tabs, tmp);
+  hipLaunchKernelGGL(resample_v_kernel, dim3(bx, n), dim3(256), 0, st, (const unsigned char*)tmp, (const ResampleJob*)jobs, tabs, dst);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -7,10 +7,13 @@ What the reference does per image in a DataLoader worker (src/data.py:306-315, t
     viewK = HWC_to_CHW(color_norm(np.asarray(ColorJitter(viewK))))
 and what the loop body then does with the batch (train_mcl.py:161-165): `.cuda().float()`.
 
-Here the host keeps what is geometry and PIL (decode, flip, the bicubic RandomResizeLong, the crops: same PIL calls,
-same random-number draws in the same order from the same generators: `torch` for flip / views, Python's `random` for the
-resize target and the crop box) and ships uint8 crops through one pinned buffer; `mx_input_stage` does color_norm,
-RandomCrop's zero container, HWC -> CHW and the fp32 cast on the device, bit-exact with the numpy expressions.
+Here the host keeps the decode, the flip, the geometry (same random-number draws in the same order from the same
+generators: `torch` for flip / views / jitter / erasing, Python's `random` for the resize target and the crop box) and the
+view crops, and ships uint8 images through one pinned buffer; the device does the pixel work: `mx_resample` the bicubic
+RandomResizeLong (Pillow's fixed-point resample, bit-exact), `mx_color_jitter` the ColorJitter (Pillow's blend / HSV
+arithmetic, bit-exact), `mx_input_stage` color_norm, RandomCrop's zero container, RandomErasing's box, HWC -> CHW and the
+fp32 cast, bit-exact with the numpy expressions.  (`plan_item(device_resize=False, device_jitter=False)` does the PIL
+calls on the host instead: that is the comparator of the tests.)
 Per 448x448 image that is 0.9 MB of uint8 over PCIe instead of 2.4 MB fp32 + 2 x 1.2 MB fp64, and no fp64 numpy
 passes on the host cores (at 8 x 219 img/s the node needs ~1 750 img/s from them).
 
@@ -151,23 +154,75 @@ def random_erasing_params(img_h: int, img_w: int, p=0.5, scale=(0.02, 0.2), rati
     return None
 
 
+# ---- Pillow's resample coefficient tables (Resample.c precompute_coeffs + normalize_coeffs_8bpc), for mx_resample ------
+def _bicubic(x):
+    a = -0.5
+    x = np.abs(x)
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1, np.where(x < 2.0, (((x - 5) * x + 8) * x - 4) * a, 0.0))
+
+
+def _bilinear(x):
+    x = np.abs(x)
+    return np.where(x < 1.0, 1.0 - x, 0.0)
+
+
+_FILTERS = {"bicubic": (_bicubic, 2.0), "bilinear": (_bilinear, 1.0)}
+
+
+def _resample_axis(in_size: int, out_size: int, filt: str):
+    """(bounds [out, 2] int32, coefficients [out, ksize] int32 in 22-bit fixed point) of one resample pass: the same double
+    arithmetic in the same order as Pillow's C (the weights of a window are summed left to right)."""
+    import math
+    f, support0 = _FILTERS[filt]
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = support0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    center = 0.0 + (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    ss = 1.0 / filterscale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    j = np.arange(ksize, dtype=np.int64)
+    w = f(((j[None, :] + xmin[:, None]) - center[:, None] + 0.5) * ss)
+    w = np.where(j[None, :] < xmax[:, None], w, 0.0)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for c in range(ksize):                                   # sequential, as the C loop adds them
+        ww = ww + w[:, c]
+    k = np.where(ww[:, None] != 0.0, w / np.where(ww == 0.0, 1.0, ww)[:, None], w)
+    ki = np.where(k < 0, (-0.5 + k * (1 << 22)).astype(np.int64), (0.5 + k * (1 << 22)).astype(np.int64)).astype(np.int32)
+    return np.stack([xmin, xmax], 1).astype(np.int32), ki
+
+
+def resample_tables(win: int, hin: int, wout: int, hout: int, filt: str = "bicubic") -> np.ndarray:
+    """The int32 table block mx_resample reads for one image: ksize_h, ksize_v, bounds_h, kk_h, bounds_v, kk_v."""
+    bh, kh = _resample_axis(win, wout, filt)
+    bv, kv = _resample_axis(hin, hout, filt)
+    return np.concatenate([np.array([kh.shape[1], kv.shape[1]], dtype=np.int32), bh.reshape(-1), kh.reshape(-1), bv.reshape(-1), kv.reshape(-1)])
+
+
 class ItemPlan:
     """uint8 crops + placements of one training item, ready for the device stage."""
-    __slots__ = ("img_u8", "img_place", "view1_u8", "view2_u8", "coord1", "coord2", "ori_coord", "erase", "jitter", "img_crop")
+    __slots__ = ("img_u8", "img_place", "view1_u8", "view2_u8", "coord1", "coord2", "ori_coord", "erase", "jitter", "img_crop",
+                 "resize_to", "tables")
+    # resize_to: None, or (W, H) of RandomResizeLong still TO BE done - on the device (mx_resample with `tables`); then img_u8 is
+    # the ORIGINAL image and img_crop the RandomCrop window inside the resized one
     # jitter: None, or the three ColorJitter parameter sets (image, view 1, view 2) still TO BE applied - on the device;
     # then img_u8 is the whole resized image and img_crop = (top, left, h, w) the RandomCrop window inside it
 
 
 def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(448, 768), augment: bool = True,
-              device_jitter: bool = False) -> ItemPlan:
+              device_jitter: bool = False, device_resize: bool = False) -> ItemPlan:
     """Host side of VOC12ImageViews.__getitem__ (src/data.py:306-315) + the train transform (train_mcl.py:104-115) for
     one decoded RGB PIL image, in the reference's draw order: flip, views, [img: resize, jitter, crop, erasing], view1
     jitter, view2 jitter.  augment=False leaves ColorJitter and RandomErasing out (and their draws with them).
     device_jitter: draw the ColorJitter parameters here but leave the pixel work to `mx_color_jitter` (bit-exact with the
-    PIL calls, 5x less host time per item): the plan then carries the whole resized image."""
+    PIL calls, 4x less host time per item): the plan then carries the whole resized image.
+    device_resize: leave RandomResizeLong's bicubic resize to `mx_resample` as well (bit-exact with PIL.Image.resize): the
+    plan carries the ORIGINAL image and Pillow's coefficient tables."""
     from PIL import Image
     p = ItemPlan()
-    p.erase = p.jitter = p.img_crop = None
+    p.erase = p.jitter = p.img_crop = p.resize_to = p.tables = None
     if torch.rand(1) < 0.5:                                     # :309-310
         pil_img = pil_img.transpose(Image.FLIP_LEFT_RIGHT)
     w, h = pil_img.size
@@ -181,18 +236,28 @@ def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(
     view2 = views_src.crop((j2, i2, j2 + tw, i2 + th))
     p.coord1, p.coord2, p.ori_coord = rel1, rel2, ori
     # transform(img): RandomResizeLong (bicubic, PIL) -> ColorJitter -> color_norm -> RandomCrop -> CHW -> RandomErasing
-    big = pil_img.resize(resize_long_target(w, h, *resize_long), resample=Image.BICUBIC)
+    target = resize_long_target(w, h, *resize_long)
     jit = []
-    if augment:
-        jit.append(color_jitter_params())
-        if not device_jitter:
-            big = apply_color_jitter(big, jit[0])
-    arr = np.asarray(big)
-    ct, cl, it, il, ch, cw = random_crop_box(arr.shape[0], arr.shape[1], crop_size)
-    if augment and device_jitter:
-        p.img_u8, p.img_crop = np.ascontiguousarray(arr), (it, il, ch, cw)   # contrast needs the whole image's mean
+    if device_resize:
+        if augment and not device_jitter:
+            raise ValueError("device_resize needs the ColorJitter on the device too (the resized image never exists on the host)")
+        if augment:
+            jit.append(color_jitter_params())
+        ct, cl, it, il, ch, cw = random_crop_box(target[1], target[0], crop_size)
+        p.img_u8, p.img_crop = np.ascontiguousarray(np.asarray(pil_img)), (it, il, ch, cw)
+        p.resize_to, p.tables = target, resample_tables(w, h, target[0], target[1], "bicubic")
     else:
-        p.img_u8 = np.ascontiguousarray(arr[it:it + ch, il:il + cw])
+        big = pil_img.resize(target, resample=Image.BICUBIC)
+        if augment:
+            jit.append(color_jitter_params())
+            if not device_jitter:
+                big = apply_color_jitter(big, jit[0])
+        arr = np.asarray(big)
+        ct, cl, it, il, ch, cw = random_crop_box(arr.shape[0], arr.shape[1], crop_size)
+        if augment and device_jitter:
+            p.img_u8, p.img_crop = np.ascontiguousarray(arr), (it, il, ch, cw)   # contrast needs the whole image's mean
+        else:
+            p.img_u8 = np.ascontiguousarray(arr[it:it + ch, il:il + cw])
     p.img_place = (ct, cl)
     if augment:
         p.erase = random_erasing_params(crop_size, crop_size)          # on the cropped [3, crop, crop] tensor
@@ -208,25 +273,43 @@ def plan_item(pil_img, crop_size: int = 448, view_size=(224, 224), resize_long=(
 
 # ---- device stage -----------------------------------------------------------------------------------------------------
 class InputStager:
-    """Packs the uint8 crops of a batch into one pinned buffer, copies it once and runs `mx_input_stage` three times
-    (img, view1, view2).  Two pinned buffers alternate so that packing batch t+1 does not wait for the copy of batch t."""
+    """Packs the uint8 images of a batch into one pinned buffer, copies it once and runs the device half:
+    [mx_resample: RandomResizeLong] -> [mx_color_jitter: ColorJitter of image and views] -> mx_input_stage x 3 (color_norm,
+    RandomCrop container, RandomErasing box, CHW, fp32).  Which of the bracketed steps run is decided by what the plans
+    carry (`plan_item(device_resize=..., device_jitter=...)`).  Two pinned buffer sets alternate so that packing batch t+1
+    does not wait for the copy of batch t."""
 
-    def __init__(self, device, batch: int, crop_size: int = 448, view_size=(224, 224), max_long: int = 768):
+    def __init__(self, device, batch: int, crop_size: int = 448, view_size=(224, 224), max_long: int = 768, max_src: int = 1024):
         self.dev, self.n, self.crop, self.view = device, batch, crop_size, view_size
-        # room for whole resized images (long side <= max_long) when the ColorJitter runs on the device
-        cap = batch * (max(crop_size, max_long) ** 2 + 2 * view_size[0] * view_size[1]) * 3
-        self._pin = [torch.empty(cap, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(cap, dtype=torch.uint8)
-                     for _ in range(2)]
-        self._jobs_pin = [torch.empty(3 * batch * 8, dtype=torch.int32).pin_memory() if torch.cuda.is_available()
-                          else torch.empty(3 * batch * 8, dtype=torch.int32) for _ in range(2)]
+        side = max(crop_size, max_long)
+        cap = batch * (max(side, max_src) ** 2 + 2 * view_size[0] * view_size[1]) * 3     # whole source / resized images + views
+        pin = (lambda t: t.pin_memory()) if torch.cuda.is_available() else (lambda t: t)
+        words = 3 * batch * 8
+        tab_words = batch * (2 + 2 * side * (2 + 13))       # per image: two axes, <= `side` outputs, bounds + <= 13 taps
+        self._pin = [pin(torch.empty(cap, dtype=torch.uint8)) for _ in range(2)]
+        self._jobs_pin = [pin(torch.empty(words, dtype=torch.int32)) for _ in range(2)]
+        self._jit_pin = [pin(torch.empty(words, dtype=torch.int32)) for _ in range(2)]
+        self._rs_pin = [pin(torch.empty(batch * 8, dtype=torch.int32)) for _ in range(2)]
+        self._tab_pin = [pin(torch.empty(tab_words, dtype=torch.int32)) for _ in range(2)]
         self._dev_u8 = torch.empty(cap, dtype=torch.uint8, device=device)
-        self._dev_jobs = torch.empty(3 * batch * 8, dtype=torch.int32, device=device)
-        self._jit_pin = [torch.empty(3 * batch * 8, dtype=torch.int32).pin_memory() if torch.cuda.is_available()
-                         else torch.empty(3 * batch * 8, dtype=torch.int32) for _ in range(2)]
-        self._dev_jit = torch.empty(3 * batch * 8, dtype=torch.int32, device=device)
+        self._dev_jobs = torch.empty(words, dtype=torch.int32, device=device)
+        self._dev_jit = torch.empty(words, dtype=torch.int32, device=device)
         self._dev_sums = torch.empty(3 * batch, dtype=torch.int64, device=device)
+        self._dev_rs_jobs = torch.empty(batch * 8, dtype=torch.int32, device=device)
+        self._dev_tab = torch.empty(tab_words, dtype=torch.int32, device=device)
+        self._dev_rs = self._dev_tmp = None                 # resized images / horizontal-pass images: allocated on first use
+        self._side, self._max_src = side, max_src
         self._flip = 0
         self._evt = [None, None]
+
+    @staticmethod
+    def _jitter_words(params):
+        order, fb, fc, fs, fh = params
+        code = 0
+        for pos in range(4):
+            fn = order[pos]
+            code |= (fn if (fb, fc, fs, fh)[fn] is not None else 15) << (4 * pos)
+        return code, (fb or 0.0, fc or 0.0, fs or 0.0), ((int(fh * 255) & 0xFF) if fh is not None else 0)
 
     def __call__(self, plans: Sequence[ItemPlan], labels: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         n = len(plans)
@@ -234,15 +317,19 @@ class InputStager:
         k = self._flip
         self._flip ^= 1
         if self._evt[k] is not None:
-            self._evt[k].synchronize()                      # the copy out of this pinned buffer two batches ago is done
+            self._evt[k].synchronize()                      # the copies out of this pinned set two batches ago are done
         buf, jobs = self._pin[k].numpy(), self._jobs_pin[k].numpy().reshape(3 * self.n, 8)
         jit = self._jit_pin[k].numpy().reshape(3 * self.n, 8)
         jit_f = jit.view(np.float32)
-        off = 0
+        rsj, tab = self._rs_pin[k].numpy().reshape(self.n, 8), self._tab_pin[k].numpy()
+        resize = getattr(plans[0], "resize_to", None) is not None
+        assert all((getattr(p, "resize_to", None) is not None) == resize for p in plans), "one resize mode per batch"
         jobs[:] = 0
         jit[:] = 0
         jit[:, 3] = 0xFFFF                                  # order nibbles: nothing to do
-        any_jit, max_px = False, 1
+        off = tab_off = tmp_off = rs_off = 0
+        jit_px = [1, 1]                                      # largest image among the jitter jobs of (image, views)
+        any_jit = False
         for kind, (get, place) in enumerate(((lambda p: p.img_u8, lambda p: p.img_place),
                                              (lambda p: p.view1_u8, lambda p: (0, 0)),
                                              (lambda p: p.view2_u8, lambda p: (0, 0)))):
@@ -252,23 +339,31 @@ class InputStager:
                 buf[off:off + sz] = a.reshape(-1)
                 top, left = place(p)
                 row = kind * self.n + i
-                jobs[row, :5] = (off, a.shape[0], a.shape[1], top, left)
+                h, w, base = a.shape[0], a.shape[1], off    # the image the jitter / the stage will see, and where it starts
+                if kind == 0 and resize:                     # RandomResizeLong on the device: source -> tmp -> resized
+                    tw, th = p.resize_to
+                    if max(th, tw) > self._side or max(h, w) > self._max_src:
+                        raise ValueError(f"image {w}x{h} -> {tw}x{th} exceeds the stager's max_src / max_long")
+                    t = p.tables
+                    tab[tab_off:tab_off + t.size] = t
+                    rsj[i] = (off, h, w, tmp_off, rs_off, tw, th, tab_off)
+                    tab_off += t.size
+                    tmp_off += h * tw * 3
+                    h, w, base = th, tw, rs_off
+                    rs_off += th * tw * 3
+                jobs[row, :5] = (base, h, w, top, left)
                 pj = getattr(p, "jitter", None)
                 if pj is not None:                                   # ColorJitter still to be applied: on the device
-                    order, fb, fc, fs, fh = pj[kind]
-                    code = 0
-                    for pos in range(4):
-                        fn = order[pos]
-                        live = (fb, fc, fs, fh)[fn] is not None
-                        code |= (fn if live else 15) << (4 * pos)
-                    jit[row, :4] = (off, a.shape[0], a.shape[1], code)
-                    jit_f[row, 4:7] = (fb or 0.0, fc or 0.0, fs or 0.0)
-                    jit[row, 7] = (int(fh * 255) & 0xFF) if fh is not None else 0
-                    any_jit, max_px = True, max(max_px, a.shape[0] * a.shape[1])
-                    if kind == 0:                                    # the stage reads the crop window inside the whole image
-                        it, il, ch, cw = p.img_crop
-                        jobs[row, :3] = (off + (it * a.shape[1] + il) * 3, ch, cw)
-                        jobs[row, 7] = a.shape[1]
+                    code, facs, hue = self._jitter_words(pj[kind])
+                    jit[row, :4] = (base, h, w, code)
+                    jit_f[row, 4:7] = facs
+                    jit[row, 7] = hue
+                    any_jit = True
+                    jit_px[min(kind, 1)] = max(jit_px[min(kind, 1)], h * w)
+                if kind == 0 and getattr(p, "img_crop", None) is not None:   # the stage reads the crop window inside the whole image
+                    it, il, ch, cw = p.img_crop
+                    jobs[row, :3] = (base + (it * w + il) * 3, ch, cw)
+                    jobs[row, 7] = w
                 er = getattr(p, "erase", None) if kind == 0 else None
                 if er is not None:                                   # RandomErasing box of the image, output coordinates
                     jobs[row, 5] = er[0] | (er[1] << 16)
@@ -278,17 +373,30 @@ class InputStager:
         self._dev_jobs.copy_(self._jobs_pin[k], non_blocking=True)
         if any_jit:
             self._dev_jit.copy_(self._jit_pin[k], non_blocking=True)
+        if resize:
+            self._dev_rs_jobs.copy_(self._rs_pin[k], non_blocking=True)
+            self._dev_tab[:tab_off].copy_(self._tab_pin[k][:tab_off], non_blocking=True)
         evt = torch.cuda.Event()
         evt.record()
         self._evt[k] = evt
+        img_src = self._dev_u8
+        if resize:
+            if self._dev_rs is None:
+                self._dev_rs = torch.empty(self.n * self._side * self._side * 3, dtype=torch.uint8, device=self.dev)
+                self._dev_tmp = torch.empty(self.n * self._max_src * self._side * 3, dtype=torch.uint8, device=self.dev)
+            call("mx_resample", ptr(self._dev_u8), ptr(self._dev_rs_jobs), ptr(self._dev_tab), ptr(self._dev_tmp), ptr(self._dev_rs), n,
+                 self._max_src * self._side, stream())
+            img_src = self._dev_rs
+        if any_jit:
+            call("mx_color_jitter", ptr(img_src), ptr(self._dev_jit), ptr(self._dev_sums), n, int(jit_px[0]), stream())
+            call("mx_color_jitter", ptr(self._dev_u8), self._dev_jit.data_ptr() + 4 * 8 * self.n, self._dev_sums.data_ptr() + 8 * self.n,
+                 2 * self.n, int(jit_px[1]), stream())
         img = torch.empty(n, 3, self.crop, self.crop, dtype=torch.float32, device=self.dev)
         v1 = torch.empty(n, 3, self.view[0], self.view[1], dtype=torch.float32, device=self.dev)
         v2 = torch.empty_like(v1)
-        if any_jit:
-            call("mx_color_jitter", ptr(self._dev_u8), ptr(self._dev_jit), ptr(self._dev_sums), 3 * self.n, int(max_px), stream())
         for kind, dst in enumerate((img, v1, v2)):
-            call("mx_input_stage", ptr(self._dev_u8), self._dev_jobs.data_ptr() + 4 * 8 * kind * self.n, ptr(dst), n, dst.shape[2],
-                 dst.shape[3], stream())
+            call("mx_input_stage", ptr(img_src if kind == 0 else self._dev_u8), self._dev_jobs.data_ptr() + 4 * 8 * kind * self.n, ptr(dst), n,
+                 dst.shape[2], dst.shape[3], stream())
         out = {"img": img, "view1": v1, "view2": v2,
                "coord1": torch.tensor([p.coord1 for p in plans], dtype=torch.int64, device=self.dev),
                "coord2": torch.tensor([p.coord2 for p in plans], dtype=torch.int64, device=self.dev),
@@ -304,10 +412,12 @@ class VOC12ClsPix:
     `(img, label, view1, view2, coord1, coord2, ori_coord)` tensors on the GPU."""
 
     def __init__(self, img_name_list_path: str, voc12_root: str, labels: Optional[Dict[str, np.ndarray]] = None,
-                 crop_size: int = 448, view_size=(224, 224), augment: bool = True, device_jitter: bool = True):
+                 crop_size: int = 448, view_size=(224, 224), augment: bool = True, device_jitter: bool = True,
+                 device_resize: bool = True):
         import os
         self.names = [ln.split(" ")[0].split("/")[-1].split(".")[0] for ln in open(img_name_list_path).read().splitlines()]
         self.root, self.crop, self.view, self.augment, self.device_jitter = voc12_root, crop_size, view_size, augment, device_jitter
+        self.device_resize = device_resize and (device_jitter or not augment)
         if labels is None and os.path.exists("data/cls_labels.npy"):
             labels = np.load("data/cls_labels.npy", allow_pickle=True).item()          # src/data.py:54-57
         self.labels = labels
@@ -321,7 +431,8 @@ class VOC12ClsPix:
         name = self.names[idx]
         img = PIL.Image.open(os.path.join(self.root, "JPEGImages", name + ".jpg")).convert("RGB")
         lab = None if self.labels is None else np.asarray(self.labels[name], dtype=np.float32)
-        return name, plan_item(img, self.crop, self.view, augment=self.augment, device_jitter=self.device_jitter), lab
+        return name, plan_item(img, self.crop, self.view, augment=self.augment, device_jitter=self.device_jitter,
+                               device_resize=self.device_resize), lab
 
     __getitem__ = plan          # a torch.utils.data map-style dataset: DataLoader workers run the host half
 

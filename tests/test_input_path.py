@@ -347,3 +347,55 @@ def test_device_hue_and_blends_over_all_16m_colours():
         call("mx_color_jitter", ptr(buf), ptr(jobs), ptr(sums), 1, 4096 * 4096, stream())
         got = buf.cpu().numpy()
         assert np.array_equal(got, want), (params, int((got != want).any(-1).sum()))
+
+
+def test_resample_tables_reproduce_pil_resize():
+    """The coefficient tables (Pillow's precompute_coeffs / normalize_coeffs_8bpc restated) applied with the integer
+    arithmetic of ImagingResample give PIL.Image.resize bit for bit (numpy here, the same loops as the HIP kernels)."""
+    import PIL.Image
+    from muscle_amd import data as D
+
+    def apply(a, t, wout, hout):
+        ksh, ksv = int(t[0]), int(t[1])
+        o = 2
+        bh = t[o:o + 2 * wout].reshape(wout, 2); o += 2 * wout
+        kh = t[o:o + wout * ksh].reshape(wout, ksh); o += wout * ksh
+        bv = t[o:o + 2 * hout].reshape(hout, 2); o += 2 * hout
+        kv = t[o:o + hout * ksv].reshape(hout, ksv)
+        tmp = np.zeros((a.shape[0], wout, 3), np.uint8)
+        for xx in range(wout):
+            x0, n = bh[xx]
+            ss = (a[:, x0:x0 + n].astype(np.int64) * kh[xx, :n, None].astype(np.int64)).sum(1) + (1 << 21)
+            tmp[:, xx] = np.clip(ss >> 22, 0, 255)
+        out = np.zeros((hout, wout, 3), np.uint8)
+        for yy in range(hout):
+            y0, n = bv[yy]
+            ss = (tmp[y0:y0 + n].astype(np.int64) * kv[yy, :n, None, None].astype(np.int64)).sum(0) + (1 << 21)
+            out[yy] = np.clip(ss >> 22, 0, 255)
+        return out
+    for im, (tw, th), filt, pf in zip(_images(), [(700, 525), (448, 597), (768, 576), (500, 375), (333, 448), (448, 448)],
+                                      ["bicubic"] * 5 + ["bilinear"], [PIL.Image.BICUBIC] * 5 + [PIL.Image.BILINEAR]):
+        a = np.asarray(im)
+        t = D.resample_tables(a.shape[1], a.shape[0], tw, th, filt)
+        assert np.array_equal(apply(a, t, tw, th), np.asarray(im.resize((tw, th), resample=pf))), (im.size, tw, th)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("augment", [False, True])
+def test_device_resize_is_bit_exact_with_pil(augment):
+    """RandomResizeLong on the device (mx_resample) against PIL.Image.resize on the host: same seeds, the staged tensors
+    must be identical - alone, and followed by the device ColorJitter (whose contrast step needs the resized image's mean)."""
+    from muscle_amd import data as D
+    dev = torch.device("cuda:0")
+    ims = _images()
+    st = D.InputStager(dev, batch=len(ims))
+    for rep in range(4):
+        torch.manual_seed(300 + rep); random.seed(400 + rep)
+        host = [D.plan_item(im, augment=augment, device_jitter=False, device_resize=False) for im in ims]
+        torch.manual_seed(300 + rep); random.seed(400 + rep)
+        devp = [D.plan_item(im, augment=augment, device_jitter=augment, device_resize=True) for im in ims]
+        assert all(d.resize_to is not None and d.img_u8.shape[:2] == (im.size[1], im.size[0]) for d, im in zip(devp, ims))
+        a = {k: v.clone() for k, v in st(host).items()}
+        b = st(devp)
+        for k in ("img", "view1", "view2"):
+            assert torch.equal(a[k], b[k]), (rep, k, int((a[k] != b[k]).sum()))

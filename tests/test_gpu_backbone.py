@@ -22,8 +22,11 @@ def _build(name, seed, dev):
     return cfg, sd, bb.to(dev)
 
 
+# B7 is covered through the whole model (tests/test_gpu_model.py::test_model_forward_backward[efficientnet-b7...], which runs
+# the same backbone against the same oracle) and by the reference's B7 step fixtures; its CPU oracle pass (fp32 + fp64)
+# costs 100-150 s on the GPU box's host cores, so it is not repeated here.
 @pytest.mark.parametrize("name,n,size,training", [("efficientnet-b0", 3, 64, True), ("efficientnet-b0", 2, 72, False),
-                                                   ("efficientnet-b3", 2, 96, True), ("efficientnet-b7", 2, 64, True)])
+                                                   ("efficientnet-b3", 2, 96, True)])
 def test_backbone_forward_backward(name, n, size, training):
     from muscle_amd import engine
     from oracle import mcl_oracle as O

@@ -250,7 +250,7 @@ def test_staged_loader_yields_loop_body_batches(tmp_path):
     from muscle_amd import data as D
     lst, root, labels, names = _voc_tree(tmp_path)
     ds = D.VOC12ClsPix(lst, root, labels=labels)
-    loader = D.StagedLoader(ds, batch_size=2, device=torch.device("cuda:0"), num_workers=2, shuffle=True,
+    loader = D.StagedLoader(ds, batch_size=2, device=torch.device("cuda:0"), num_workers=1, shuffle=True,
                             generator=torch.Generator().manual_seed(3))
     assert len(loader) == 3
     seen = []

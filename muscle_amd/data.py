@@ -471,3 +471,40 @@ class StagedLoader:
             if items[0][2] is not None:
                 labels = torch.from_numpy(np.stack([it[2] for it in items]))
             yield names, self.stager([it[1] for it in items], labels=labels)
+
+
+class MSFStager:
+    """The multi-scale + flip list of `VOC12ClsDatasetMSF.__getitem__` (src/data.py:336-365) as `infer_mcl.py:123-125` feeds
+    it to the model (`img.cuda().float()`), built on the device: the decoded image crosses PCIe once as uint8; per scale
+    `mx_resample` (= `img.resize(target, PIL.Image.CUBIC)`, bit-exact) and `mx_input_stage` (color_norm, HWC -> CHW, the
+    float64 -> float32 rounding of `.float()`); the flipped copy is `np.flip(x, -1)`.  On the host the four bicubic resizes
+    of a 500 x 375 image cost ~40 ms of a core per image; here ~0.5 ms of coefficient tables."""
+
+    def __init__(self, device, max_side: int = 2048):
+        self.dev, self.side = device, max_side
+        cap = max_side * max_side * 3
+        self._src = torch.empty(cap, dtype=torch.uint8, device=device)
+        self._tmp = torch.empty(cap, dtype=torch.uint8, device=device)
+        self._dst = torch.empty(cap, dtype=torch.uint8, device=device)
+
+    def __call__(self, pil_img, scales=(0.5, 1.0, 1.5, 2.0), unit: int = 1) -> List[torch.Tensor]:
+        a = np.array(pil_img.convert("RGB"))                    # (a writable copy: torch.from_numpy wants one)
+        h, w = a.shape[:2]
+        rounded = (int(round(w / unit) * unit), int(round(h / unit) * unit))                  # data.py:347
+        if max(h, w) > self.side:
+            raise ValueError(f"image {w}x{h} exceeds MSFStager(max_side={self.side})")
+        self._src[:a.size].copy_(torch.from_numpy(a).reshape(-1), non_blocking=False)
+        out: List[torch.Tensor] = []
+        for s in scales:
+            tw, th = round(rounded[0] * s), round(rounded[1] * s)                               # data.py:351-352
+            if max(tw, th) > self.side:
+                raise ValueError(f"scale {s}: {tw}x{th} exceeds MSFStager(max_side={self.side})")
+            tab = torch.from_numpy(resample_tables(w, h, tw, th, "bicubic")).to(self.dev)
+            rs = torch.tensor([0, h, w, 0, 0, tw, th, 0], dtype=torch.int32, device=self.dev)
+            call("mx_resample", ptr(self._src), ptr(rs), ptr(tab), ptr(self._tmp), ptr(self._dst), 1, max(h * tw, th * tw), stream())
+            job = torch.tensor([0, th, tw, 0, 0, 0, 0, 0], dtype=torch.int32, device=self.dev)
+            x = torch.empty(1, 3, th, tw, dtype=torch.float32, device=self.dev)
+            call("mx_input_stage", ptr(self._dst), ptr(job), ptr(x), 1, th, tw, stream())
+            out.append(x)
+            out.append(torch.flip(x, dims=[-1]))                                               # data.py:363
+        return out

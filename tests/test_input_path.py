@@ -399,3 +399,26 @@ def test_device_resize_is_bit_exact_with_pil(augment):
         b = st(devp)
         for k in ("img", "view1", "view2"):
             assert torch.equal(a[k], b[k]), (rep, k, int((a[k] != b[k]).sum()))
+
+
+@pytest.mark.gpu
+def test_msf_list_on_the_device_equals_the_reference_dataset_arithmetic():
+    """MSFStager against VOC12ClsDatasetMSF.__getitem__'s arithmetic done on the host (PIL bicubic resize, color_norm in
+    float64, HWC_to_CHW, np.flip) followed by infer_mcl.py's .float(): bit for bit, every scale, odd sizes, both flips."""
+    import PIL.Image
+    from muscle_amd import data as D
+    dev = torch.device("cuda:0")
+    ms = D.MSFStager(dev, max_side=1400)
+    mean = np.array([[[0.485, 0.456, 0.406]]]); std = np.array([[[0.229, 0.224, 0.225]]])
+    for im in _images()[:4]:
+        got = ms(im, scales=(0.5, 1.0, 1.5, 2.0))
+        assert len(got) == 8
+        W, H = im.size
+        for i, s in enumerate((0.5, 1.0, 1.5, 2.0)):
+            target = (round(W * s), round(H * s))
+            arr = np.asarray(im.resize(target, resample=PIL.Image.BICUBIC))
+            x = np.transpose((arr / 255 - mean) / std, (2, 0, 1))                 # color_norm (float64) + HWC_to_CHW
+            want = torch.from_numpy(x.copy()).float()[None]
+            wantf = torch.from_numpy(np.flip(x, -1).copy()).float()[None]
+            assert torch.equal(got[2 * i].cpu(), want), (im.size, s)
+            assert torch.equal(got[2 * i + 1].cpu(), wantf), (im.size, s, "flip")

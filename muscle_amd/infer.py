@@ -35,15 +35,23 @@ def infer_cam(model, img_list: List[torch.Tensor], label: torch.Tensor, H: int, 
     acc_sgc = torch.zeros(K - 1, H, W, dtype=torch.float32, device=dev)
     scores = []
     with torch.no_grad():
-        for i, img in enumerate(img_list):
+        i = 0
+        while i < len(img_list):
+            img = img_list[i]
             if img.shape[0] != 1:
                 raise ValueError("each entry of img_list is one image [1,3,Hs,Ws]")
-            cam_lr, sgc_lr, _emb, score = model(img.float(), cam="cam_lr")       # NHWC [1,h,w,24]
+            # a scale and its flipped copy have the same size: one batch-2 forward instead of two batch-1 forwards (eval
+            # mode is per-sample: same maps; at these sizes a B7 forward is launch-bound, so the pass costs the same)
+            pair = i % 2 == 0 and i + 1 < len(img_list) and img_list[i + 1].shape == img.shape
+            x = torch.cat([img, img_list[i + 1]], dim=0).float() if pair else img.float()
+            cam_lr, sgc_lr, _emb, score = model(x, cam="cam_lr")                 # NHWC [b,h,w,24]
             _, h, w, lds = cam_lr.shape
             Hs, Ws = img.shape[2], img.shape[3]
-            call("mx_infer_accum", ptr(cam_lr), ptr(acc_cam), h, w, lds, K, Hs, Ws, H, W, i % 2, stream())
-            call("mx_infer_accum", ptr(sgc_lr), ptr(acc_sgc), h, w, lds, K, Hs, Ws, H, W, i % 2, stream())
-            scores.append(score[:, 1:])
+            for b in range(x.shape[0]):
+                call("mx_infer_accum", ptr(cam_lr[b]), ptr(acc_cam), h, w, lds, K, Hs, Ws, H, W, (i + b) % 2, stream())
+                call("mx_infer_accum", ptr(sgc_lr[b]), ptr(acc_sgc), h, w, lds, K, Hs, Ws, H, W, (i + b) % 2, stream())
+                scores.append(score[b:b + 1, 1:])
+            i += x.shape[0]
         call("mx_infer_norm", ptr(acc_cam), K - 1, H * W, stream())
         call("mx_infer_norm", ptr(acc_sgc), K - 1, H * W, stream())
         score = torch.sigmoid(torch.mean(torch.cat(scores, dim=0), dim=0))

@@ -50,3 +50,32 @@ t0 = time.perf_counter()
 for _ in range(20): post()
 torch.cuda.synchronize()
 print(f"post-processing (8 passes -> [20,{H},{W}] sum + min-max, one of CAM/SGC): {(time.perf_counter()-t0)/20*1e6:.0f} us", flush=True)
+
+# infer_mcl.py's loop body per image, end to end: multi-scale + flip list (built on the device by MSFStager, or on the host
+# with PIL as VOC12ClsDatasetMSF does), 8 forwards at batch 1, accumulate / normalise, the kept channels to the host.
+import PIL.Image
+from muscle_amd.data import MSFStager
+rng = np.random.default_rng(0)
+pil = PIL.Image.fromarray(rng.integers(0, 256, (375, 500, 3), dtype=np.uint8), "RGB")
+label = torch.zeros(1, 20); label[0, 3] = 1; label[0, 11] = 1
+ms = MSFStager(dev, max_side=1100)
+mean = np.array([[[0.485, 0.456, 0.406]]]); std = np.array([[[0.229, 0.224, 0.225]]])
+
+
+def host_list(im):
+    out = []
+    for s in (0.5, 1.0, 1.5, 2.0):
+        a = np.asarray(im.resize((round(im.size[0] * s), round(im.size[1] * s)), resample=PIL.Image.BICUBIC))
+        x = np.transpose((a / 255 - mean) / std, (2, 0, 1))
+        out += [torch.from_numpy(x.copy())[None], torch.from_numpy(np.flip(x, -1).copy())[None]]
+    return [t.to(dev).float() for t in out]
+
+
+for name, build in (("MSF list on the device", lambda: ms(pil)), ("MSF list on the host (PIL, one core)", lambda: host_list(pil))):
+    for _ in range(2):
+        infer.infer_cam(model, build(), label, 375, 500)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(8):
+        infer.infer_cam(model, build(), label, 375, 500)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 8
+    print(f"infer_mcl loop body, one 500x375 image, scales 0.5/1/1.5/2 x flip, {a.model}, {name}: {dt*1e3:7.1f} ms per image  {1/dt:5.1f} img/s", flush=True)

@@ -11,8 +11,13 @@ ROOT = sys.argv[1]
 sys.path.insert(0, ROOT)
 mode, out_path = sys.argv[2], sys.argv[3]
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+backend = os.environ.get("DP_BACKEND", "gloo")            # "nccl" (= RCCL): one GPU per rank, needs >= world GPUs
 if world > 1:
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        torch.cuda.set_device(rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    else:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
 
 from muscle_amd.dist import GradAverager  # noqa: E402
 
@@ -48,7 +53,7 @@ else:
     from muscle_amd import synth
     from muscle_amd.arch import net_cfg
     name, n, size, view, ep, seed = "efficientnet-b0", 4, 64, 32, 4, 5
-    dev = torch.device("cuda:0")
+    dev = torch.device("cuda", rank if (world > 1 and backend == "nccl") else 0)
     cfg = net_cfg(name, False)
     sd = synth.synth_state_dict(cfg, seed)
     model = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)

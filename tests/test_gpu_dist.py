@@ -14,8 +14,8 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
 
 
-def _run(world, tmp_path, tag):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world))
+def _run(world, tmp_path, tag, backend="gloo"):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), DP_BACKEND=backend)
     outs = [str(tmp_path / f"{tag}_{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, WORKER, ROOT, "step", outs[r]], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -24,9 +24,17 @@ def _run(world, tmp_path, tag):
     return [np.load(o) for o in outs]
 
 
-def test_two_ranks_same_batch_reproduce_single_process_update(tmp_path):
+def _gpu_count():
+    import torch
+    return torch.cuda.device_count()          # (does not initialise the GPU in this process)
+
+
+@pytest.mark.parametrize("backend", ["gloo", pytest.param("nccl", marks=pytest.mark.skipif(_gpu_count() < 2, reason="RCCL needs one GPU per rank"))])
+def test_two_ranks_same_batch_reproduce_single_process_update(tmp_path, backend):
+    """backend='nccl' is the production path (RCCL all_reduce(AVG) issued from the weight-gradient side stream): it runs
+    wherever two GPUs are visible; on the one-GPU boxes both ranks share the GPU and exchange over gloo."""
     (single,) = _run(1, tmp_path, "w1")
-    r0, r1 = _run(2, tmp_path, "w2")
+    r0, r1 = _run(2, tmp_path, "w2", backend)
     assert int(r0["early"]) > 0 and int(r1["early"]) > 0          # chunks went out while backward was still running
     # both ranks hold the same averaged gradient and took the same update (bit for bit: same reduction, same order)
     assert np.array_equal(r0["arena"], r1["arena"]) and np.array_equal(r0["params"], r1["params"])

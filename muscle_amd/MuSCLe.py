@@ -160,6 +160,11 @@ class MuSCLe(nn.Module):
             self.backbone._eval_fold = None
         return super().train(mode)
 
+    def load_state_dict(self, *args, **kwargs):
+        if getattr(self.backbone, "_eval_fold", None) is not None:
+            self.backbone._eval_fold = None          # folded copies of the old weights
+        return super().load_state_dict(*args, **kwargs)
+
     # ---- which parameters receive gradients (SURVEY.md §7 "DDP with unused parameters") ----------
     def live_parameters(self, cam_mode: str = "cam") -> List[nn.Parameter]:
         ps: List[nn.Parameter] = [self.backbone._conv_stem.weight, self.backbone._bn0.weight, self.backbone._bn0.bias]

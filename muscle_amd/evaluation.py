@@ -47,6 +47,8 @@ class RapidEval:
 
     def add(self, model, img: torch.Tensor, label: torch.Tensor, gt: torch.Tensor) -> None:
         """One image of the eval loader (train_mcl.py:290-303): img [1,3,H,W], label [1,20], gt uint8 [H,W]."""
+        if not model.training and getattr(model.backbone, "_eval_fold", None) is None and hasattr(model, "fold_eval_bn"):
+            model.fold_eval_bn()          # once per evaluation sweep: model.train() drops it again (weights change)
         with torch.no_grad():
             _, pred, _, _ = model(img.float(), cam="cam")
             pred = cam_maxnorm(pred)

@@ -29,6 +29,8 @@ def infer_cam(model, img_list: List[torch.Tensor], label: torch.Tensor, H: int, 
     if label.dim() != 2 or label.shape[0] != 1:
         raise ValueError("infer_cam handles one image per call (infer_mcl.py's DataLoader has batch_size 1)")
     model.eval()
+    if getattr(model.backbone, "_eval_fold", None) is None and hasattr(model, "fold_eval_bn"):
+        model.fold_eval_bn()              # eval BatchNorm folded into the 1x1 weights once, not per pass (train() drops it)
     dev = img_list[0].device
     K = model.classes
     acc_cam = torch.zeros(K - 1, H, W, dtype=torch.float32, device=dev)

@@ -108,3 +108,20 @@ def test_graphed_step_refuses_phase2_and_shape_change():
     step(bs[0]); step(bs[1])
     with pytest.raises(ValueError):
         step(batches(3, 64, 1, 2)[0])
+
+
+def test_repeated_steps_fit_a_fixed_batch():
+    """Sanity of the whole loop (forward, losses, backward, side-stream weight gradients, fused Adam) beyond one step: on a
+    fixed batch the classification losses must fall steadily - a wrong-signed or misrouted gradient anywhere shows here."""
+    import muscle_amd
+    torch.manual_seed(0)
+    model = build("efficientnet-b0", 5)
+    opt = muscle_amd.FusedAdam(model.parameters(), lr=1e-3, weight_decay=5e-5)
+    b = batches(8, 64, 1, 3)[0]
+    hist = []
+    for it in range(30):
+        out = muscle_amd.mcl_step(model, opt, b, 0)
+        hist.append(float(out["loss_softmargin"].detach()) + float(out["loss_focal"].detach()) + float(out["loss_pair"].detach()))
+    assert all(np.isfinite(hist)), hist
+    assert hist[-1] < 0.6 * hist[0], (hist[0], hist[-1])
+    assert np.mean(hist[-5:]) < np.mean(hist[:5])

@@ -244,8 +244,8 @@ def main():
     inst_dt = time.perf_counter() - t1
     timer.on = False
     engine.WGRAD_SIDE_STREAM = overlap
-    # Reported beside the contract value, never as it: the same K steps with the forward / data-gradient GEMMs of the
-    # MFMA-bound layers in "split" arithmetic (fp32 operands split exactly into three bf16 terms, six products on the
+    # Reported beside the contract value, never as it: the same K steps with the GEMMs of the MFMA-bound layers (forward,
+    # data gradient, weight gradient) in "split" arithmetic (fp32 operands split exactly into three bf16 terms, six products on the
     # bf16 matrix pipe, fp32 accumulation; include/muscle_hip.h mx_set_gemm_mode)
     split = None
     if not a.no_split:
@@ -263,8 +263,9 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t)
         split = {"value": a.batch * world * a.steps / dts, "unit": "images/sec", "ms_per_step": dts / a.steps * 1e3,
-                 "arithmetic": "opt-in: fwd/dgrad GEMMs with K >= 128 on v_mfma_f32_32x32x16_bf16, fp32 operands as h+m+l bf16 "
-                               "terms (exact split), 6 of 9 products, fp32 accumulate; error vs fp64 equal to the fp32-MFMA kernel's"}
+                 "arithmetic": "opt-in: the MFMA-bound fwd / dgrad (K >= 128) and weight-gradient GEMMs on v_mfma_f32_32x32x16_bf16, fp32 "
+                               "operands as h+m+l bf16 terms (exact split), 6 of 9 products, fp32 accumulate; error vs fp64 equal to "
+                               "the fp32-MFMA kernels'"}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

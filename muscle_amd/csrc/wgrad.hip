@@ -396,6 +396,148 @@ __global__ __launch_bounds__(256, (TE * TF >= 16 && XMODE == MX_BNACT) ? 3 : 4) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The tiled weight gradient in the opt-in "split" arithmetic (mx_set_gemm_mode >= 1; see gemm.hip: fp32 operands split
+// exactly into three bf16 terms, six of nine products on v_mfma_f32_32x32x16_bf16, fp32 accumulation).  The reduction
+// runs over pixel ROWS, so the bf16 fragments (8 consecutive k of one output row / column) are columns of the operand
+// slabs: a thread loads 8 rows x 4 columns, splits in registers and writes, per column, 8 bf16 along k as one 16-byte
+// chunk - the transposition costs nothing.  LDS image per operand and plane: [128 columns][32 k] bf16 (64-byte rows, the
+// four 16-byte chunks of a row XOR-ed with (column >> 2) & 3: conflict-free ds_read_b128).  128 x 128 tile, 32-row slabs,
+// one LDS stage (48 KB: 3 workgroups per CU) + register prefetch.  Same (tile, group) decomposition, partial tiles and
+// fixed-order reduce as wgrad_tile_kernel.
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef float wf32x16 __attribute__((ext_vector_type(16)));
+
+static __device__ __forceinline__ void wsplit3_pair(float x0, float x1, unsigned& h, unsigned& m, unsigned& l) {
+  const unsigned u0 = __float_as_uint(x0) & 0xffff0000u, u1 = __float_as_uint(x1) & 0xffff0000u;
+  const float r0 = x0 - __uint_as_float(u0), r1 = x1 - __uint_as_float(u1);
+  const unsigned v0 = __float_as_uint(r0) & 0xffff0000u, v1 = __float_as_uint(r1) & 0xffff0000u;
+  const float s0 = r0 - __uint_as_float(v0), s1 = r1 - __uint_as_float(v1);
+  h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+  m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+  l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+}
+
+template <int XMODE>
+__global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WtArgs a) {
+  constexpr int PLANE = 128 * 64;                           // bytes: [128 columns][32 k] bf16
+  __shared__ __attribute__((aligned(16))) unsigned char smem[6 * PLANE];     // G h/m/l, X h/m/l
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int wco = wave >> 1, wci = wave & 1;
+  const int tiles = a.tiles_co * a.tiles_ci;
+  const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+  const int group = (j / tiles) * 8 + xcd, tile = j % tiles;
+  if (group >= a.groups) return;
+  const int co0 = (tile / a.tiles_ci) * 128, ci0 = (tile % a.tiles_ci) * 128;
+  const long r_beg = (long)group * a.rows_per_group;
+  const long r_end = min((long)a.R, r_beg + a.rows_per_group);
+
+  // loader: threads 0-127 move G, 128-255 move X; thread = (4-column chunk c of 32, row group rg of 4): rows 8 rg .. 8 rg + 7
+  const bool isx = tid >= 128;
+  const int lt = tid & 127, c = lt & 31, rg = lt >> 5;
+  const int col0 = (isx ? ci0 : co0) + 4 * c;
+  const bool colok = col0 < (isx ? a.Ci : a.Co);
+  const float* base = isx ? a.X.p : a.G;
+  const int ld = isx ? a.ldx : a.ldg;
+  float4 rv[8], gt[XMODE == MX_BNACT ? 8 : 1];
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (XMODE != MX_PLAIN && isx && colok) { sc = ld4(a.X.c1 + col0); sh = ld4(a.X.c2 + col0); }
+  auto load = [&](long r0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const long r = r0 + 8 * rg + i;
+      const bool ok = colok && r < r_end;
+      rv[i] = ok ? ld4(base + r * ld + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (XMODE == MX_BNACT) gt[i] = (ok && isx && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + col0) : make_float4(1.f, 1.f, 1.f, 1.f);
+    }
+  };
+  auto store = [&](long r0) {
+    if (XMODE != MX_PLAIN && isx) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!(colok && r0 + 8 * rg + i < r_end)) continue;
+        float4 v = rv[i];
+        v.x = sc.x * v.x + sh.x; v.y = sc.y * v.y + sh.y; v.z = sc.z * v.z + sh.z; v.w = sc.w * v.w + sh.w;
+        if (XMODE == MX_BNACT) {
+          const float4 g4 = gt[XMODE == MX_BNACT ? i : 0];
+          v.x = swishf_(v.x) * g4.x; v.y = swishf_(v.y) * g4.y; v.z = swishf_(v.z) * g4.z; v.w = swishf_(v.w) * g4.w;
+        }
+        rv[i] = v;
+      }
+    }
+    unsigned char* pl = smem + (isx ? 3 * PLANE : 0);
+#pragma unroll
+    for (int jc = 0; jc < 4; ++jc) {                          // column 4 c + jc: 8 values along k -> one 16-byte chunk per plane
+      const int col = 4 * c + jc;
+      unsigned h[4], m[4], l[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float x0 = jc == 0 ? rv[2 * q].x : jc == 1 ? rv[2 * q].y : jc == 2 ? rv[2 * q].z : rv[2 * q].w;
+        const float x1 = jc == 0 ? rv[2 * q + 1].x : jc == 1 ? rv[2 * q + 1].y : jc == 2 ? rv[2 * q + 1].z : rv[2 * q + 1].w;
+        wsplit3_pair(x0, x1, h[q], m[q], l[q]);
+      }
+      const int off = col * 64 + ((rg ^ ((col >> 2) & 3)) << 4);
+      *reinterpret_cast<uint4*>(pl + off) = make_uint4(h[0], h[1], h[2], h[3]);
+      *reinterpret_cast<uint4*>(pl + PLANE + off) = make_uint4(m[0], m[1], m[2], m[3]);
+      *reinterpret_cast<uint4*>(pl + 2 * PLANE + off) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+  };
+
+  wf32x16 acc[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+
+  const int ns = (int)((r_end - r_beg + 31) / 32);
+  if (ns > 0) load(r_beg);
+  for (int s = 0; s < ns; ++s) {
+    __syncthreads();                                          // the previous slab's fragments have been read
+    store(r_beg + (long)s * 32);
+    if (s + 1 < ns) load(r_beg + (long)(s + 1) * 32);
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {                           // two 16-row MFMA steps per slab
+      wbf16x8 gv[2][3], xv[2][3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int cg = wco * 64 + 32 * e + l31, cx = wci * 64 + 32 * e + l31;
+          gv[e][p] = *reinterpret_cast<const wbf16x8*>(smem + p * PLANE + cg * 64 + (((2 * ks + hf) ^ ((cg >> 2) & 3)) << 4));
+          xv[e][p] = *reinterpret_cast<const wbf16x8*>(smem + (3 + p) * PLANE + cx * 64 + (((2 * ks + hf) ^ ((cx >> 2) & 3)) << 4));
+        }
+      constexpr int PG[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+            acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(gv[e][PG[t]], xv[f][PX[t]], acc[e][f], 0, 0, 0);
+    }
+  }
+  // acc[e][f][4 g + r] = dW[co0 + 64 wco + 32 e + 8 g + 4 hf + r][ci0 + 64 wci + 32 f + l31]
+  float* out = a.part + (a.accumulate ? 0 : (long)group * a.Co * a.Ci);
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int ci = ci0 + 64 * wci + 32 * f + l31;
+      if (ci >= a.Ci) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 64 * wco + 32 * e + 8 * (r >> 2) + 4 * hf + (r & 3);
+        if (co >= a.Co) continue;
+        float* o = out + (long)co * a.Ci + ci;
+        *o = a.accumulate ? *o + acc[e][f][r] : acc[e][f][r];
+      }
+    }
+}
+
 struct WtPlan { int te, tf, tiles_co, tiles_ci, groups, rows_per_group; };
 
 static int wt_order() {
@@ -403,8 +545,36 @@ static int wt_order() {
   return order;
 }
 
+extern "C" int mx_get_gemm_mode(void);
+
+static bool wt_use_split(int Co, int Ci) {
+  if (mx_get_gemm_mode() < 1) return false;
+  const double eff = ((double)Co / (128.0 * cdiv(Co, 128))) * ((double)Ci / (128.0 * cdiv(Ci, 128)));
+  return mx_get_gemm_mode() == 2 || eff >= 0.8;              // 128 x 128 tiles only: not where they pad much
+}
+
 static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
   if (Co % 4 || Ci % 4 || R < 1024 || (long)Co * Ci < 16384) return false;
+  if (wt_use_split(Co, Ci)) {
+    p->te = p->tf = 4;
+    p->tiles_co = cdiv(Co, 128); p->tiles_ci = cdiv(Ci, 128);
+    const int tiles = p->tiles_co * p->tiles_ci, slots = 256 * 2;
+    const int maxg = R / 256 > 0 ? R / 256 : 1;
+    int groups = 1;
+    double best_score = -1.0;
+    for (int rounds = 2; rounds <= 5; ++rounds) {
+      int g = slots * rounds / tiles;
+      if (g < 1) g = 1;
+      if (g > maxg) g = maxg;
+      if (g >= 8) g = g / 8 * 8;
+      const double fill = (double)tiles * g / ((double)slots * cdiv(tiles * g, slots));
+      const double score = fill - 0.0025 * g;
+      if (score > best_score + 1e-9) { best_score = score; groups = g; }
+    }
+    p->rows_per_group = cdiv(cdiv(R, groups), 32) * 32;
+    p->groups = cdiv(R, p->rows_per_group);
+    return true;
+  }
   // tile: least padded area, ties to the larger tile
   long best = -1;
   for (int te : {4, 2})
@@ -518,7 +688,13 @@ int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_
   a.order = wt_order();
   a.part = a.accumulate ? dW : (float*)ws;
   hipStream_t st = (hipStream_t)stream;
-  if (p.te == 4 && p.tf == 4) wt_launch<4, 4>(a, st);
+  if (wt_use_split(Co, Ci)) {
+    const dim3 grid(8 * cdiv(a.groups, 8) * a.tiles_co * a.tiles_ci);
+    a.total = grid.x;
+    if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN>), grid, dim3(256), 0, st, a);
+    else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_split_kernel<MX_BNACT>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_split_kernel<MX_AFFINE>), grid, dim3(256), 0, st, a);
+  } else if (p.te == 4 && p.tf == 4) wt_launch<4, 4>(a, st);
   else if (p.te == 4) wt_launch<4, 2>(a, st);
   else if (p.tf == 4) wt_launch<2, 4>(a, st);
   else wt_launch<2, 2>(a, st);

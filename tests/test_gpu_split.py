@@ -103,3 +103,46 @@ def test_mcl_step_golden_in_split_mode(split_everywhere, fname):
     """The reference's own step fixtures (B0, and B7 at 448x448 where the big layers take the split kernel)."""
     import test_gpu_model as tm
     tm.test_mcl_step_phase1_golden(fname, False)
+
+
+@pytest.mark.parametrize("R,Co,Ci,mode", [(25088, 384, 2304, "plain"), (12544, 2304, 384, "bnact"), (1111, 200, 136, "bnact"),
+                                          (4096, 1344, 224, "affine"), (2048, 128, 128, "plain"), (5000 + 3, 640, 384, "bnact")])
+def test_split_wgrad_matches_fp64_as_well_as_fp32_mfma(R, Co, Ci, mode):
+    """The tiled weight gradient in split arithmetic (wgrad_split_kernel: fragments along the pixel rows, transposed in
+    registers) against fp64, beside the fp32-MFMA kernel on the same inputs; deterministic; keeps a running sum."""
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(R + Co)
+    G = torch.randn(R, Co, device=DEV, generator=g)
+    X = torch.randn(R, Ci, device=DEV, generator=g)
+    kw = {}
+    Xr = X.double()
+    if mode != "plain":
+        rps = 49
+        sc = torch.rand(Ci, device=DEV, generator=g) + 0.5
+        sh = torch.randn(Ci, device=DEV, generator=g) * 0.3
+        gate = torch.rand((R + rps - 1) // rps, Ci, device=DEV, generator=g)
+        Xr = Xr * sc.double() + sh.double()
+        if mode == "bnact":
+            kw = dict(x_mode=ops.BNACT, x_scale=sc, x_shift=sh, x_gate=gate, rows_per_sample=rps)
+            Xr = Xr * torch.sigmoid(Xr) * gate.double().repeat_interleave(rps, dim=0)[:R]
+        else:
+            kw = dict(x_mode=ops.AFFINE, x_scale=sc, x_shift=sh, rows_per_sample=rps)
+    ref = G.double().t() @ Xr
+    base = torch.randn(Co, Ci, device=DEV, generator=g)
+    errs = []
+    for gm in (0, 2):
+        muscle_amd.set_gemm_mode(gm)
+        try:
+            outs = []
+            for _ in range(2):
+                dW = base.clone()
+                ops.pw_wgrad(G, X, dW, **kw)
+                outs.append(dW)
+        finally:
+            muscle_amd.set_gemm_mode(0)
+        assert torch.equal(outs[0], outs[1])
+        errs.append((outs[0].double() - base.double() - ref).abs().max().item())
+    scale = ref.abs().max().item()
+    assert errs[0] <= 2e-5 * scale, (errs, scale)
+    assert errs[1] <= 1.5 * errs[0] + 2e-7 * scale, (errs, scale)

@@ -13,9 +13,8 @@ with the same operation, so the result is identical to one all-reduce of the who
 """
 from __future__ import annotations
 
-from typing import List, Optional
+from typing import List
 
-import torch
 import torch.distributed as dist
 
 CHUNK_BYTES = 25 * 1024 * 1024

@@ -59,6 +59,12 @@ int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream)
 int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, int ldg, int ldx,
                 const float* residual, void* stream);
 
+/* mx_pw_dgrad against Wt = W^T with the BatchNorm backward apply (mx_bn_bwd_apply, plain form) folded into the operand load:
+ * dZ = coef[0][k]*G + coef[1][k]*X + coef[2][k] (coef = the [3][K] block mx_bn_bwd_finalize writes), dX = dZ * Wt^T (+ residual);
+ * dZ [M, ldg] is also WRITTEN, for the weight gradient.  dZ must not alias G or X. */
+int mx_pw_dgrad_bnbwd(const float* G, const float* X, const float* coef, const float* Wt, float* dX, float* dZ, int M, int K, int N,
+                      int ldg, int ldx, const float* residual, void* stream);
+
 /* dW[Co,Ci] += G[R,Co]^T * X'[R,Ci]: weight gradient, reduction over the R pixel rows split across blocks. */
 int mx_pw_wgrad(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
                 const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,

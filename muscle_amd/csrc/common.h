@@ -74,7 +74,10 @@ struct MxOperand {
   int mode;
   int rps;  // rows per sample
 };
-enum { MX_PLAIN = 0, MX_BNACT = 1, MX_AFFINE = 2 };
+enum { MX_PLAIN = 0, MX_BNACT = 1, MX_AFFINE = 2, MX_BNBWD = 3 };
+// mode 3 BNBWD (GEMM A operand only): v = c1[c]*p[r,c] + c2[c]*rowp[r,c] + c3[c] with c1 = coefficient table [3][cols]
+//   (c2, c3 = c1 + cols, + 2 cols) and rowp = the SECOND tensor [rows, same ld]: the BatchNorm backward apply
+//   dX = c1*g + c2*x + c3 folded into the consumer GEMM's load; the GEMM also materialises v (GemmArgs::a_out)
 
 __device__ __forceinline__ float4 mx_apply(const MxOperand& o, float4 v, long r, int c, int cols) {
   if (o.mode == MX_PLAIN) return v;

@@ -36,6 +36,7 @@ struct GemmArgs {
   int xcd_nt;               // > 0: 1-D grid, the xcd_nt N tiles of an M tile run back to back on one XCD (see kernel)
   int mt, zt;               // M tiles, reduction slices (for the 1-D grids)
   unsigned long long* stamps;   // diagnostic builds only (tools/hip/gemm_lab.hip); null in the library
+  float* a_out;             // MX_BNBWD: the prologue's result [M, lda] is also written here (by the N tile 0 workgroups)
 };
 
 // Diagnostic hook: tools/hip/gemm_lab.hip compiles this file with MX_GEMM_STAMP defined to record s_memtime stamps per
@@ -533,7 +534,7 @@ constexpr int gemm_nt_waves(int acc) { return acc <= 48 ? 4 : acc <= 64 ? 3 : 2;
 
 // ---- streaming kernel: one tile per workgroup, K in 16-wide slabs, double-buffered -----------------------------------
 template <int WM, int WN, int TM, int TN, int AMODE>
-__global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4 + (AMODE == MX_BNBWD ? 16 : 0))) void gemm_nt_kernel(GemmArgs g) {
   constexpr int BM = WM * TM * 16, BN = WN * TN * 16, LS = 20;
   constexpr int PA = (BM * 4 + 255) / 256, PB = (BN * 4 + 255) / 256;
   constexpr int SMEM = 2 * (BM + BN) * LS;
@@ -560,8 +561,9 @@ __global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kerne
   // slab movers: thread t owns rows (t + 256 i) / 4, 16-byte column chunk t % 4
   const int ck = (tid & 3) * 4;
   float4 ra[PA], rb[PB];
-  float4 gt[AMODE == MX_BNACT ? PA : 1];                    // SE gate of the row's sample, this thread's 4 channels
-  float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;  // BN scale / shift of this thread's 4 channels
+  float4 gt[(AMODE == MX_BNACT || AMODE == MX_BNBWD) ? PA : 1];   // BNACT: SE gate of the row's sample; BNBWD: the second tensor
+  float4 sc4 = make_float4(0.f, 0.f, 0.f, 0.f), sh4 = sc4;  // BN scale / shift of this thread's 4 channels (BNBWD: c1, c2)
+  float4 c34 = sc4;                                         // BNBWD: c3
   long ga_off[AMODE == MX_BNACT ? PA : 1];
   const float* pa[PA];
   const float* pb[PB];
@@ -585,10 +587,12 @@ __global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kerne
     for (int i = 0; i < PA; ++i) {
       ra[i] = (oka[i] && kin) ? ld4(pa[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (AMODE == MX_BNACT) gt[i] = (oka[i] && kin && ga_off[i] >= 0) ? ld4(g.a.rowp + ga_off[i] + k0) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (AMODE == MX_BNBWD) gt[i] = (oka[i] && kin) ? ld4(g.a.rowp + (pa[i] - g.a.p) + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     if (AMODE != MX_PLAIN) {
       sc4 = kin ? ld4(g.a.c1 + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
       sh4 = kin ? ld4(g.a.c2 + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (AMODE == MX_BNBWD) c34 = kin ? ld4(g.a.c1 + 2 * K + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) rb[i] = (okb[i] && kin) ? ld4(pb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -599,7 +603,14 @@ __global__ __launch_bounds__(256, gemm_nt_waves(TM * TN * 4)) void gemm_nt_kerne
     for (int i = 0; i < PA; ++i) {
       if ((tid + 256 * i) < BM * 4) {
         float4 v = ra[i];
-        if (AMODE != MX_PLAIN && oka[i] && kin) v = nt_prologue<AMODE>(v, sc4, sh4, gt[AMODE == MX_BNACT ? i : 0]);
+        if (AMODE == MX_BNBWD) {
+          if (oka[i] && kin) {                               // dX = c1*g + c2*x + c3 (bn_bwd_apply), also kept for the weight gradient
+            const float4 x = gt[AMODE == MX_BNBWD ? i : 0];
+            v.x = sc4.x * v.x + sh4.x * x.x + c34.x; v.y = sc4.y * v.y + sh4.y * x.y + c34.y;
+            v.z = sc4.z * v.z + sh4.z * x.z + c34.z; v.w = sc4.w * v.w + sh4.w * x.w + c34.w;
+            if (tile_n == 0) st4(g.a_out + (pa[i] - g.a.p) + k0, v);
+          }
+        } else if (AMODE != MX_PLAIN && oka[i] && kin) v = nt_prologue<AMODE>(v, sc4, sh4, gt[AMODE == MX_BNACT ? i : 0]);
         st4(As + ((tid + 256 * i) >> 2) * LS + ck, v);
       }
     }
@@ -957,6 +968,7 @@ static void launch_nt(const GemmArgs& g, int batch, hipStream_t st) {
   switch (g.a.mode) {
     case MX_PLAIN: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, MX_PLAIN>), grid, dim3(256), 0, st, a); break;
     case MX_BNACT: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, MX_BNACT>), grid, dim3(256), 0, st, a); break;
+    case MX_BNBWD: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, MX_BNBWD>), grid, dim3(256), 0, st, a); break;
     default: hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, TM, TN, MX_AFFINE>), grid, dim3(256), 0, st, a); break;
   }
 }
@@ -985,7 +997,7 @@ static int pick_nt_cfg(int M, int N) {
 }
 
 static void dispatch_nt(const GemmArgs& g, int batch, hipStream_t st) {
-  if (g_gemm_mode == 2 || (g_gemm_mode == 1 && g.K >= 128 && g.N >= 96 && (double)g.N / (64.0 * cdiv(g.N, 64)) >= 0.74)) {
+  if (g.a.mode != MX_BNBWD && (g_gemm_mode == 2 || (g_gemm_mode == 1 && g.K >= 128 && g.N >= 96 && (double)g.N / (64.0 * cdiv(g.N, 64)) >= 0.74))) {
     launch_nt_split(g, batch, st);       // MFMA-bound shapes only: K and N large enough, <= 26 % padded columns
     return;
   }
@@ -1003,7 +1015,7 @@ static void dispatch_nt(const GemmArgs& g, int batch, hipStream_t st) {
 static int check_operand(const MxOperand& o, const char* nm) {
   MX_CHECK_ARG(o.p != nullptr, "gemm: operand %s is null", nm);
   MX_CHECK_ARG(((uintptr_t)o.p & 15) == 0, "gemm: operand %s not 16-byte aligned", nm);
-  MX_CHECK_ARG(o.mode >= 0 && o.mode <= 2, "gemm: operand %s bad mode %d", nm, o.mode);
+  MX_CHECK_ARG(o.mode >= 0 && o.mode <= 3, "gemm: operand %s bad mode %d", nm, o.mode);
   if (o.mode != MX_PLAIN) {
     MX_CHECK_ARG(o.c1 && o.c2, "gemm: operand %s needs scale/shift", nm);
     MX_CHECK_ARG(o.rps > 0, "gemm: operand %s rows_per_sample must be > 0", nm);
@@ -1115,6 +1127,22 @@ int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, 
   g.c = dX; g.M = M; g.N = N; g.K = K; g.lda = ldg; g.ldb = N; g.ldc = ldx;
   g.residual = residual;
   return gemm_common(L_NN, g, 1, (hipStream_t)stream);
+}
+
+// Data gradient with the BatchNorm backward apply folded into its operand load: dZ = c1*G + c2*X + c3 per channel (coef =
+// [3][K]), dX[M,N] = dZ[M,K] * Wt[N,K]^T (+ residual); dZ [M, ldg] is ALSO written (the weight gradient reads it).
+int mx_pw_dgrad_bnbwd(const float* G, const float* X, const float* coef, const float* Wt, float* dX, float* dZ, int M, int K, int N,
+                      int ldg, int ldx, const float* residual, void* stream) {
+  MX_CHECK_ARG(G && X && coef && Wt && dX && dZ, "pw_dgrad_bnbwd: null pointer");
+  MX_CHECK_ARG(dZ != G && dZ != X, "pw_dgrad_bnbwd: dZ must not alias G or X (other N tiles still read them)");
+  MX_CHECK_ARG((((uintptr_t)X | (uintptr_t)dZ | (uintptr_t)coef) & 15) == 0 && K % 4 == 0, "pw_dgrad_bnbwd: alignment");
+  GemmArgs g{};
+  g.a = MxOperand{G, coef, coef + K, X, MX_BNBWD, 1};
+  g.b = MxOperand{Wt, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.c = dX; g.M = M; g.N = N; g.K = K; g.lda = ldg; g.ldb = K; g.ldc = ldx;
+  g.residual = residual;
+  g.a_out = dZ;
+  return gemm_common(L_NT, g, 1, (hipStream_t)stream);
 }
 
 // dW[Co,Ci] += G[R,Co]^T * X'[R,Ci] (dW must be zeroed or hold a running sum; fp32 atomics).

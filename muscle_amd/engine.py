@@ -293,6 +293,11 @@ class GradSink:
 
 
 FUSED_DW_BACKWARD = True
+# BN0 backward apply inside the expand data-gradient GEMM's operand load (the GEMM also writes dz for the weight gradient):
+# one pass over the Cexp-wide tensors less on paper, measured on MI355X (B7/448/bs32, A/B/A/B on one box) 130.2 / 130.5 ms
+# per step without against 133.0 / 133.2 with it - the second operand stream and the dz stores of the N-tile-0 workgroups
+# cost the MFMA-bound GEMMs more than the 8.5 ms pass gives back a third of.  Off; kept as an option.
+FOLD_BN0_APPLY = os.environ.get("MUSCLE_FOLD_BN0", "0") == "1"
 # Weight-gradient GEMMs on a second HIP stream (MUSCLE_WGRAD_STREAM=0 turns it off; `engine.WGRAD_SIDE_STREAM` can be
 # flipped at run time).  Nothing in the backward chain consumes them (only the optimizer and the gradient exchange do),
 # they are MFMA-bound, and the chain between two of them (BN backward, SE, depthwise) is HBM-bound.  Measured on
@@ -416,13 +421,24 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
             bn_mod = m._bn0 if b.expand else backbone._bn0
             raw2 = dw_in.view(M, dw_in.shape[3])
             gx2 = gx.view(M, dw_in.shape[3])
+            fold = fused and b.expand and FOLD_BN0_APPLY and ops.DGRAD_AS_FORWARD and b.cexp % 4 == 0
             if fused:
                 c0 = ops.bn_bwd_coeffs(part0, M, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training)
-                dz = ops.bn_bwd_apply_plain(gx2, raw2, c0, gx2)
+                if not fold:
+                    dz = ops.bn_bwd_apply_plain(gx2, raw2, c0, gx2)
             else:
                 dz = ops.bn_backward(gx2, raw2, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training,
                                      act=dw_st, out=gx2)
-            if b.expand:
+            if fold:
+                # the BN0 backward apply rides in the data-gradient GEMM's operand load (which also writes dz for the weight
+                # gradient): one pass over the Cexp-wide tensors less than bn_bwd_apply + GEMM
+                g_in, dz = ops.pw_dgrad_bnbwd(gx2, raw2, c0, m._expand_conv.weight.view(b.cexp, b.cin), b.cin,
+                                              residual=skip_res.reshape(M, b.cin) if skip_res is not None else None,
+                                              wt=tape.wt.get(id(m._expand_conv.weight)))
+                lane.wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
+                lane.flush()
+                g_out = g_in.view(N, t.H, t.W, b.cin)
+            elif b.expand:
                 lane.wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
                 g_in = ops.pw_dgrad(dz, m._expand_conv.weight.view(b.cexp, b.cin), b.cin, wt=tape.wt.get(id(m._expand_conv.weight)),
                                     residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)

@@ -101,6 +101,17 @@ def pw_dgrad(G, W, N_in, *, residual=None, out=None, wt=None):
     return out
 
 
+def pw_dgrad_bnbwd(G, X, coef, W, N_in, *, residual=None, wt=None):
+    """The BatchNorm backward apply dZ = c1*G + c2*X + c3 (coef [3, K], as bn_bwd_coeffs returns it) folded into the data
+    gradient dX = dZ W: returns (dX [M, N_in], dZ [M, K]) - dZ is materialised by the GEMM for the weight gradient."""
+    M, K = G.shape
+    out = _f32(M, N_in, device=G.device)
+    dz = torch.empty_like(G)
+    call("mx_pw_dgrad_bnbwd", ptr(G), ptr(X), ptr(coef), ptr(wt if wt is not None else transpose(W)), ptr(out), ptr(dz), M, K, N_in,
+         G.stride(0), N_in, ptr(residual), stream())
+    return out, dz
+
+
 _wgrad_ws: dict = {}
 WGRAD_TILE = os.environ.get("MUSCLE_WGRAD_TILE", "1") == "1"   # large outputs: tiled deterministic kernel (wgrad.hip) instead of the atomic TN GEMM
 WGRAD_SMALL = True       # small outputs / long reductions: one workgroup owns the whole output, deterministic partial sums

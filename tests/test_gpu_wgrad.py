@@ -95,3 +95,21 @@ def test_wgrad_tile_matches_fp64_and_is_deterministic(R, Co, Ci, mode):
     finally:
         ops.WGRAD_TILE = True
     assert (dW2 - outs[0]).abs().max().item() <= 1e-4 * scale
+
+
+def test_dgrad_with_folded_bn_backward_apply():
+    """mx_pw_dgrad_bnbwd (the BN backward apply inside the data-gradient GEMM's operand load; an option, off by default)
+    against the two separate steps it replaces: same dX, same materialised dZ."""
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(9)
+    for (M, K, N) in ((6272, 2304, 384), (3000, 288, 48), (777, 160, 960)):
+        G = torch.randn(M, K, device=DEV, generator=g)
+        X = torch.randn(M, K, device=DEV, generator=g)
+        c = torch.randn(3, K, device=DEV, generator=g)
+        W = torch.randn(K, N, device=DEV, generator=g) * K ** -0.5          # [Cexp, Cin]
+        res = torch.randn(M, N, device=DEV, generator=g)
+        dz_ref = ops.bn_bwd_apply_plain(G, X, c, torch.empty_like(G))
+        dx_ref = ops.pw_dgrad(dz_ref, W, N, residual=res)
+        dx, dz = ops.pw_dgrad_bnbwd(G, X, c, W, N, residual=res)
+        assert torch.allclose(dz, dz_ref, rtol=0, atol=2e-6 * float(dz_ref.abs().max()))
+        assert (dx - dx_ref).abs().max().item() <= 2e-5 * dx_ref.abs().max().item()

@@ -78,11 +78,16 @@ def lib() -> ctypes.CDLL:
     return _lib
 
 
+_fns: Dict[str, object] = {}
+
+
 def call(name: str, *args):
-    L = lib()
-    rc = getattr(L, name)(*args)
+    fn = _fns.get(name)
+    if fn is None:
+        fn = _fns[name] = getattr(lib(), name)
+    rc = fn(*args)
     if rc != 0:
-        raise MuscleHipError(f"{name} failed (rc={rc}): {L.mx_last_error().decode()}")
+        raise MuscleHipError(f"{name} failed (rc={rc}): {lib().mx_last_error().decode()}")
 
 
 def ptr(t: Optional[torch.Tensor]):
@@ -96,5 +101,12 @@ def ptr(t: Optional[torch.Tensor]):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream() -> int:
+    """The current HIP stream of the current device as an integer handle (follows torch.cuda.stream(...) contexts and graph
+    capture).  torch.cuda.current_stream().cuda_stream builds a Stream object per call: 2.6 us, ~1700 times per B7 step."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

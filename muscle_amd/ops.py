@@ -170,13 +170,28 @@ def bn_finalize(stats, count, bn: torch.nn.BatchNorm2d, training: bool) -> BNSta
     C = bn.num_features
     dev = bn.weight.device
     buf = _f32(4, C, device=dev)
+    b0, b1, b2, b3 = buf.unbind(0)                            # (one op instead of four indexing ops: this runs ~160 times per step)
+    base = buf.data_ptr()
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     call("mx_bn_finalize", ptr(stats), stats.shape[0] if stats is not None else 0, C, float(count), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
-         ptr(bn.running_var), mom, float(bn.eps), int(training), ptr(buf[0]), ptr(buf[1]), ptr(buf[2]), ptr(buf[3]),
-         ptr(torch.empty(2 * C, dtype=torch.float64, device=dev)) if training else None, stream())
+         ptr(bn.running_var), mom, float(bn.eps), int(training), base, base + 4 * C, base + 8 * C, base + 12 * C,
+         _acc_scratch(dev, 2 * C) if training else None, stream())
     if training:
         _nbt_pending.append(bn.num_batches_tracked)
-    return BNState(buf[0], buf[1], buf[2], buf[3])
+    return BNState(b0, b1, b2, b3)
+
+
+_acc_bufs: dict = {}
+
+
+def _acc_scratch(dev, n):
+    """fp64 scratch of the two-level statistics reduction (only touched when a layer has more than 1024 partial rows): one
+    persistent buffer per (device, stream) instead of an allocation per BatchNorm."""
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream())
+    t = _acc_bufs.get(key)
+    if t is None or t.numel() < n:
+        t = _acc_bufs[key] = torch.empty(max(n, 16384), dtype=torch.float64, device=dev)
+    return t.data_ptr()
 
 
 _nbt_pending: list = []
@@ -238,16 +253,17 @@ def bn_bwd_coeffs(part, rows, bn, st: BNState, dgamma, dbeta, training: bool):
     """dgamma/dbeta (+=) and the [3,C] coefficients (c1,c2,c3) of dX = c1*g + c2*X + c3 from partial rows part[P][2][C]."""
     P, _, C = part.shape
     c = _f32(3, C, device=part.device)
+    base = c.data_ptr()
     call("mx_bn_bwd_finalize", ptr(part), P, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
-         ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]),
-         ptr(torch.empty(2 * C, dtype=torch.float64, device=part.device)), stream())
+         ptr(dgamma), ptr(dbeta), base, base + 4 * C, base + 8 * C, _acc_scratch(part.device, 2 * C), stream())
     return c
 
 
 def bn_bwd_apply_plain(G2d, X2d, c, out):
     """dX = c1*G + c2*X + c3 (G already carries every upstream factor)."""
     rows, C = X2d.shape
-    call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), None, None, None, None, None, ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(out),
+    cb, cs = c.data_ptr(), 4 * c.shape[1]
+    call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), None, None, None, None, None, cb, cb + cs, cb + 2 * cs, ptr(out),
          rows, C, 1, stream())
     return out
 
@@ -259,8 +275,9 @@ def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNStat
     P = lib().mx_dwconv_bwd_fused_parts(N, H, Wd, C, K)
     part = _f32(P, 2, C, device=X.device) if st0 is not None else None
     scratch = _f32(P, C * K * K, device=X.device)
-    call("mx_dwconv_bwd_fused", ptr(dA), ptr(D), ptr(gate), ptr(add), ptr(st1.scale), ptr(st1.shift), ptr(c1[0]), ptr(c1[1]),
-         ptr(c1[2]), ptr(X), ptr(st0.scale) if st0 else None, ptr(st0.shift) if st0 else None, ptr(W), ptr(residual), ptr(gX),
+    cb, cs = c1.data_ptr(), 4 * c1.shape[1]
+    call("mx_dwconv_bwd_fused", ptr(dA), ptr(D), ptr(gate), ptr(add), ptr(st1.scale), ptr(st1.shift), cb, cb + cs,
+         cb + 2 * cs, ptr(X), ptr(st0.scale) if st0 else None, ptr(st0.shift) if st0 else None, ptr(W), ptr(residual), ptr(gX),
          ptr(dW), ptr(scratch), ptr(part), N, H, Wd, C, K, pad_lo, stream())
     return gX, part
 
@@ -284,8 +301,9 @@ def bn1_coeffs(pooled5, gate, add, rows, bn, st: BNState, dgamma, dbeta, trainin
     """bn1_sums + bn_bwd_coeffs in one launch: the [3,C] coefficients of the BN1 data gradient, dgamma/dbeta (+=)."""
     _, N, C = pooled5.shape
     c = _f32(3, C, device=gate.device)
+    base = c.data_ptr()
     call("mx_bn1_sums_finalize", ptr(pooled5), ptr(gate), ptr(add), N, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd),
-         int(training), ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]), stream())
+         int(training), ptr(dgamma), ptr(dbeta), base, base + 4 * C, base + 8 * C, stream())
     return c
 
 

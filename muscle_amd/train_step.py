@@ -148,7 +148,8 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
     img, label = batch["img"], batch["label"].float()
     out: Dict[str, object] = {}
     optimizer.zero_grad()
-    model.train()
+    if not model.training:             # (walking ~150 submodules costs 0.65 ms of host time per call)
+        model.train()
     n = label.shape[0]
     label_with_bg = torch.cat((torch.ones((n, 1), dtype=label.dtype, device=label.device), label), dim=1)
     if fused_er:
@@ -199,7 +200,8 @@ def muscle_step(model, optimizer, batch: Dict[str, torch.Tensor], *, lamb: float
     from . import edge
     img, label, mask = batch["img"], batch["label"].float(), batch["mask"]
     optimizer.zero_grad()
-    model.train()
+    if not model.training:             # (walking ~150 submodules costs 0.65 ms of host time per call)
+        model.train()
     n = label.shape[0]
     label_with_bg = torch.cat((torch.ones((n, 1), dtype=label.dtype, device=label.device), label), dim=1)
     seg_map, ft = model(img, cam="seg_p3" if fused else "seg", drop_u=drop_u)

@@ -345,6 +345,8 @@ class InputStager:
                     if max(th, tw) > self._side or max(h, w) > self._max_src:
                         raise ValueError(f"image {w}x{h} -> {tw}x{th} exceeds the stager's max_src / max_long")
                     t = p.tables
+                    if tab_off + t.size > tab.size:
+                        raise ValueError("resample tables exceed the stager's table buffer (a very strong downscale): raise max_src / max_long")
                     tab[tab_off:tab_off + t.size] = t
                     rsj[i] = (off, h, w, tmp_off, rs_off, tw, th, tab_off)
                     tab_off += t.size

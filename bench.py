@@ -150,7 +150,7 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="timed steps replay phase 1 from a captured hipGraph (muscle_amd.GraphedStep; one GPU, epoch < 8).  Not "
                          "the default: measured on MI355X the replay saves 0.5 ms of 136 on B7 but serialises the weight-gradient "
-                         "side stream, which is worth 3.6 ms (B7) / 6 % (B0) when launched eagerly")
+                         "side stream, which is worth 3.6 ms on B7 when launched eagerly; it is the better choice for B0-sized models")
     ap.add_argument("--eager", action="store_true", help="(the default; kept for older command lines)")
     a = ap.parse_args()
 

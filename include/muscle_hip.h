@@ -13,11 +13,17 @@
  *   - calls only enqueue work on `stream` (a hipStream_t passed as void*), never synchronise;
  *   - return 0 on success, a negative value for an argument error detected before launch, a positive
  *     hipError_t otherwise; mx_last_error() returns a thread-local message;
- *   - "+=" outputs accumulate (the caller zeroes them); they use fp32 hardware atomics, so their last bits
- *     depend on arrival order.  Per-channel BatchNorm statistics do NOT use atomics: producers write one
- *     partial row per workgroup row into `part[P][2][C]` (P from the matching mx_*_parts() helper, no zeroing
- *     needed) and the finalise entry points sum the P rows in fp64 (two levels: <= 64 row slices per channel chunk,
- *     combined with fp64 atomics into the caller's acc[2C] scratch, then one thread per channel).
+ *   - "+=" outputs accumulate into what the caller hands in (parameter gradients); every element has ONE adder.
+ *   - the training step is run-to-run deterministic: no result is joined through floating-point atomics.  Reductions
+ *     that span workgroups use one of three schemes: (i) per-channel BatchNorm statistics: producers write one partial
+ *     row per workgroup into `part[P][2][C]` (P from the matching mx_*_parts() helper, no zeroing needed) and the finalise
+ *     entry points add the P rows in fp64 in a fixed order (two levels above 1024 rows: <= 64 row slices into the caller's
+ *     acc[64][2C] scratch, then one thread per channel); (ii) "last arriver finishes": workgroups park partials in the
+ *     caller's `ws` scratch and the last one to arrive adds them in index order (mx_pool_sum, mx_se_bn1_pool,
+ *     mx_dwconv_fwd's squeeze); (iii) 64-bit fixed-point integer atomics where the terms are bounded (ER loss).
+ *   - `ws` scratch (entry points that take `void* ws, long ws_bytes`; size from the matching mx_*_ws() helper, 0 = not
+ *     needed): 16-byte aligned; for scheme (ii) its first 64 KB hold arrival counters that must be ZERO on entry and are
+ *     zero again when the launch has drained, so one zero-initialised buffer per stream can be reused for every call.
  *   - an operand "mode" selects the prologue applied while the operand is loaded:
  *        0 PLAIN   v = x
  *        1 BNACT   v = swish(scale[c]*x + shift[c]) * (gate ? gate[n,c] : 1)     n = row / rows_per_sample
@@ -65,10 +71,13 @@ int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, 
 int mx_pw_dgrad_bnbwd(const float* G, const float* X, const float* coef, const float* Wt, float* dX, float* dZ, int M, int K, int N,
                       int ldg, int ldx, const float* residual, void* stream);
 
-/* dW[Co,Ci] += G[R,Co]^T * X'[R,Ci]: weight gradient, reduction over the R pixel rows split across blocks. */
+/* dW[Co,Ci] += G[R,Co]^T * X'[R,Ci]: weight gradient, general kernel (the shapes the two below do not take).  The R pixel
+ * rows are split into slices; with more than one slice each adds into its own partial matrix in `ws` (mx_pw_wgrad_ws bytes)
+ * and the partial matrices are added to dW in slice order. */
+long mx_pw_wgrad_ws(int R, int Co, int Ci);
 int mx_pw_wgrad(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
                 const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
-                void* stream);
+                void* ws, long ws_bytes, void* stream);
 
 /* The same weight gradient for SMALL outputs and long reductions (Co*Ci <= 40960, R >= 65536: the first four stages): one
  * workgroup owns the whole output over a contiguous range of rows, partial matrices are added in a fixed order -
@@ -100,7 +109,7 @@ int mx_colstats(const float* X, long rows, int C, float* part, void* stream);
  * `momentum` (unbiased var); eval: running stats.  Writes scale = gamma*rstd, shift = beta - mean*scale, mean, rstd. */
 int mx_bn_finalize(const float* part, int P, int C, double count, const float* gamma, const float* beta, float* running_mean,
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
-                   float* mean, float* rstd, double* acc, void* stream);
+                   float* mean, float* rstd, double* acc /* [64][2C] */, void* stream);
 
 /* out = (scale[c]*P + shift[c]) [swish if act] [* gate[n,c]] [* row_scale[n]] [+ residual]
  * (BN2 + drop_connect + skip; with act + gate: the activated, SE-gated project-conv input, model.py:78-84) */
@@ -123,32 +132,36 @@ int mx_bn_bwd_apply(const float* G, const float* X, const float* row_scale, cons
                     const float* act_scale, const float* act_shift, const float* c1, const float* c2, const float* c3,
                     float* out, long rows, int C, int rows_per_sample, void* stream);
 
-/* out[n,c] += sum_hw f(X[n,hw,c]),  f = [scale*x+shift] [swish if act] [* G]: SE squeeze (model.py:82),
- * head GAP (MuSCLe.py:240) and the gate-gradient reduction of their backward. */
+/* out[n,c] = sum_hw f(X[n,hw,c]),  f = [scale*x+shift] [swish if act] [* G]: SE squeeze (model.py:82),
+ * head GAP (MuSCLe.py:240) and the gate-gradient reduction of their backward.  Overwrites `out`; ws: mx_pool_ws(.., 1). */
+long mx_pool_ws(long rows, int C, int rows_per_sample, int planes);
 int mx_pool_sum(const float* X, const float* G, const float* scale, const float* shift, int act, long rows, int C,
-                int rows_per_sample, float* out, void* stream);
+                int rows_per_sample, float* out, void* ws, long ws_bytes, void* stream);
 
-/* SE + BN1 backward reductions in one pass over (dA, X = d_raw): out5[5][N][C] += per-(sample,channel) sums of
+/* SE + BN1 backward reductions in one pass over (dA, X = d_raw): out5[5][N][C] = per-(sample,channel) sums of
  * {dA*act, dA*s', s', dA*s'*X, s'*X} with z = scale*X+shift, act = swish(z), s' = swish'(z); out5[0] is dL/dgate
- * (model.py:84).  mx_bn1_sums then forms the BatchNorm-1 backward sums for g = (dA*gate + add)*s' as one partial
- * row part[2C] (P = 1 for mx_bn_bwd_finalize) without a second pass over the tensors. */
+ * (model.py:84).  Overwrites out5; ws: mx_pool_ws(.., 5). */
 int mx_se_bn1_pool(const float* dA, const float* X, const float* scale, const float* shift, long rows, int C, int rows_per_sample,
-                   float* out5, void* stream);
-int mx_bn1_sums(const float* pooled5, const float* gate, const float* add, int N, int C, float* part, void* stream);
-/* The same sums followed by mx_bn_bwd_finalize on them, in one launch (one row per channel, nothing to reduce across
- * workgroups): dgamma/dbeta += and the coefficients c1, c2, c3 of dX = c1*g + c2*X + c3. */
-int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* add, int N, int C, double count,
-                         const float* gamma, const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
-                         float* c1, float* c2, float* c3, void* stream);
+                   float* out5, void* ws, long ws_bytes, void* stream);
+/* From those sums, in one launch and without a second pass over the tensors:
+ *   add[n,c] = inv_hw * sum_j gh[n,j] W1[j,c]  (WRITTEN: the gradient reaching d_raw through the squeeze path, model.py:82-83;
+ *              gh [N,SQ] from mx_se_bwd, W1 = _se_reduce.weight [SQ,C]),
+ *   the BatchNorm-1 backward sums for g = (dA*gate + add)*s' and mx_bn_bwd_finalize on them: dgamma/dbeta += and the
+ *   coefficients c1, c2, c3 of dX = c1*g + c2*X + c3. */
+int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* gh, const float* W1, float inv_hw, float* add,
+                         int N, int C, int SQ, double count, const float* gamma, const float* mean, const float* rstd, int training,
+                         float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream);
 
 /* ---- depthwise k x k convolution, k in {3,5}, stride in {1,2}: model.py:50-52,78; utils.py:122-145 ---- */
 
 /* Y = dwconv(act(X)), act = swish(scale*x+shift) when scale != NULL; stats (optional, training) = partial (sum Y, sum Y^2)
- * rows part[mx_dwconv_fwd_parts(N,Ho,Wo,S)][2][C]; pooled (optional, inference, excludes stats; zeroed by the caller):
- * pooled[n][c] += sum_hw swish(pool_scale[c]*Y + pool_shift[c]), the SE squeeze of model.py:81-82 under eval-mode BN1 */
+ * rows part[mx_dwconv_fwd_parts(N,Ho,Wo,S)][2][C]; pooled (optional, inference, excludes stats):
+ * pooled[n][c] = sum_hw swish(pool_scale[c]*Y + pool_shift[c]), the SE squeeze of model.py:81-82 under eval-mode BN1
+ * (ws: mx_dwconv_fwd_ws bytes, only read when pooled is given) */
 int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S);
+long mx_dwconv_fwd_ws(int N, int Ho, int Wo, int C, int S);
 int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats,
-                  const float* pool_scale, const float* pool_shift, float* pooled, int N,
+                  const float* pool_scale, const float* pool_shift, float* pooled, void* ws, long ws_bytes, int N,
                   int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
 
 /* dX = dwconv^T(dY) (+residual): gradient w.r.t. the activated input */
@@ -156,7 +169,7 @@ int mx_dwconv_bwd_data(const float* dY, const float* W, const float* residual, f
                        int K, int S, int pad_lo, int Ho, int Wo, void* stream);
 
 /* dW[C,1,K,K] += sum dY * act(X).  dw_scratch: [mx_dwconv_bwd_weight_parts(N,Ho,Wo,C,S)][C*K*K] floats for per-workgroup
- * partial rows (added by a second kernel), or NULL (every workgroup adds into dW with atomics: slow when contended). */
+ * partial rows (added in a fixed order by a second kernel). */
 int mx_dwconv_bwd_weight_parts(int N, int Ho, int Wo, int C, int S);
 int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, float* dw_scratch,
                          int N, int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream);
@@ -178,10 +191,10 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
 int mx_se_fwd(const float* pooled_sum, float inv_hw, const float* W1, const float* b1, const float* W2, const float* b2,
               float* s, float* h, float* gate, int N, int C, int SQ, void* stream);
 
-/* given ggate[n,c] = dL/dgate: add[n,c] += (dL/ds)[n,c]*inv_hw (`add` is handed in ZERO-FILLED: it is accumulated
- * across squeeze slices); dW1,db1,dW2,db2 +=; gh_scratch: N*SQ floats */
-int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W1, const float* W2,
-              float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, float* gh_scratch, int N, int C,
+/* given ggate[n,c] = dL/dgate: gh[n,j] = dL/d(se_reduce output) [N,SQ] (WRITTEN; mx_bn1_sums_finalize turns it into the
+ * pooled-path gradient `add`); dW1,db1,dW2,db2 += (each element summed over the samples by one thread, in order) */
+int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W2,
+              float* dW1, float* db1, float* dW2, float* db2, float* gh, int N, int C,
               int SQ, void* stream);
 
 /* out[(n,oy,ox), ci*9+ky*3+kx] = img[n,ci,oy*2-pad+ky,ox*2-pad+kx] (NCHW image), rows of 28 floats (27 + 0) */
@@ -272,8 +285,8 @@ int mx_bcast_add(float* X, const float* v, float alpha, long rows, int C, int ro
 /* ---- losses of the MCL step and the optimiser ---------------------------------------------------------------- */
 
 /* [N,C] classification losses with d loss / d input for unit upstream gradient:
- * mode 0 focal(p,y) gamma 2 alpha .5 (loss_multilabel.py:68-91) -> loss[0] += ; 1 MultiLabelSoftMargin(x,y)
- * (train_mcl.py:146) -> loss[0] += ; 2 Log_Sum_Exp_Pairwise(p,y) (loss_multilabel.py:24-33) -> loss[n];
+ * mode 0 focal(p,y) gamma 2 alpha .5 (loss_multilabel.py:68-91) -> loss[0] = ; 1 MultiLabelSoftMargin(x,y)
+ * (train_mcl.py:146) -> loss[0] = ; 2 Log_Sum_Exp_Pairwise(p,y) (loss_multilabel.py:24-33) -> loss[n];
  * 3 grad = sigmoid(x); 4 grad = y * x * (1 - x) (sigmoid backward, x = sigmoid output, y = upstream) */
 int mx_cls_loss(int mode, const float* x, int ldx, const float* y, int ldy, float* loss, float* grad, int ldg, int N, int C,
                 void* stream);
@@ -287,9 +300,11 @@ int mx_softmaxnorm(const float* x, const float* gy, float* out, int N, int K, lo
 
 /* ER loss (train_mcl.py:185-188): mean over rows of the top-k of |softmaxnorm(cams)-softmaxnorm(sgcs)|*lwb, exact
  * 3-pass radix select.  d [N*K*HW] scratch; krem/prefix/sum_gt/cnt_eq [N] and hcnt/hsum [N*2048] state
- * (prefix and sum_gt zeroed by the caller) are kept for mx_er_bwd. */
+ * (prefix and sum_gt zeroed by the caller) are kept for mx_er_bwd.  sum_gt and hsum are 64-bit fixed-point sums
+ * (value * 2^36; the terms are <= 1): integer atomics, so the loss has the same bits every run. */
 int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int K, long HW, long k, float* d, unsigned* krem,
-              unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss, void* stream);
+              unsigned* prefix, unsigned long long* sum_gt, unsigned* cnt_eq, unsigned* hcnt, unsigned long long* hsum, float* loss,
+              void* stream);
 /* gsgcs = d loss / d raw_sgcs * gscale * (gup ? gup[0] : 1): gup is the upstream gradient as a device scalar */
 int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsigned* prefix, const unsigned* krem,
               const unsigned* cnt_eq, const float* gup, float gscale, float* gsgcs, int N, int K, long HW, void* stream);
@@ -299,11 +314,13 @@ int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsi
 /* k_dev (optional, device int32): the top-k count read at run time instead of k / gscale's 1/(N k) - for hipGraph replays
  * of the step, where k = int(0.2 * sum(labels) * H * W) (train_mcl.py:178,188) changes with every batch */
 int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
-                 const int* k_dev, unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum,
-                 float* loss, void* stream);
+                 const int* k_dev, unsigned* krem, unsigned* prefix, unsigned long long* sum_gt, unsigned* cnt_eq, unsigned* hcnt,
+                 unsigned long long* hsum, float* loss, void* stream);
+/* ws: mx_er_lr_bwd_ws bytes (64-bit fixed-point accumulators of the band kernel; plain scratch, no counter header) */
+long mx_er_lr_bwd_ws(int N, int h, int w, int L, int K);
 int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix, const unsigned* krem,
                  const unsigned* cnt_eq, const float* gup, float gscale, const int* k_dev, float* gsgc, int N, int h, int w, int L,
-                 int K, int H, int W, void* stream);
+                 int K, int H, int W, void* ws, long ws_bytes, void* stream);
 
 /* torch.optim.Adam(weight_decay) update on flat arrays (train_mcl.py:134,199,229) */
 /* dyn (optional, device float[3] = {lr, bias_corr1, sqrt_bias_corr2}): read at run time instead of the arguments (hipGraph replays) */

@@ -55,9 +55,28 @@ static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that o
 }
 
 // F::eval(r, c, v0, v1): contributes two float4 partials for element block (row r, cols c..c+3)
+// sum of P partial float4s, `stride` floats apart, in index order (four loads in flight, one fixed association)
+__device__ __forceinline__ float4 ordered_sum4(const float* p, int P, long stride) {
+  float4 t = ld4(p);
+  int i = 1;
+  for (; i + 3 < P; i += 4) {
+    const float4 a = ld4(p + i * stride), b = ld4(p + (i + 1) * stride), c = ld4(p + (i + 2) * stride), d = ld4(p + (i + 3) * stride);
+    t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w;
+    t.x += b.x; t.y += b.y; t.z += b.z; t.w += b.w;
+    t.x += c.x; t.y += c.y; t.z += c.z; t.w += c.w;
+    t.x += d.x; t.y += d.y; t.z += d.z; t.w += d.w;
+  }
+  for (; i < P; ++i) { const float4 a = ld4(p + i * stride); t.x += a.x; t.y += a.y; t.z += a.z; t.w += a.w; }
+  return t;
+}
+
+// PER_SAMPLE: out0[sample][C] = the per-sample column sums.  A sample's rows are cut into gridDim.x row blocks; each
+// block leaves its partial in `scratch` [gridDim.x][samples][C] and the last one to arrive adds them in block order
+// (mx_last_arriver; counters [samples][gridDim.y]): same bits every run, no zero-filled output, no atomics.
 template <class F, int NOUT, bool PER_SAMPLE, typename OutT>
-__global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* out0, OutT* out1) {
+__global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* out0, OutT* out1, float* scratch, unsigned* counters) {
   __shared__ float4 sm[2][256];
+  __shared__ unsigned last_flag;
   const int tid = threadIdx.x;
   const int used = g.tcols * g.rpp;
   const int tc = tid % g.tcols, tr = tid / g.tcols;
@@ -90,24 +109,33 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
   sm[0][tid] = a0;
   sm[1][tid] = a1;
   __syncthreads();
-  if (tid < g.tcols && c4 < g.c4) {
-    float4 s0 = sm[0][tid], s1 = sm[1][tid];
+  const bool owner = tid < g.tcols && c4 < g.c4;
+  float4 s0 = make_float4(0, 0, 0, 0), s1 = s0;
+  if (owner) {
+    s0 = sm[0][tid]; s1 = sm[1][tid];
     for (int i = 1; i < g.rpp; ++i) {
       float4 t0 = sm[0][tid + i * g.tcols], t1 = sm[1][tid + i * g.tcols];
       s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w;
       s1.x += t1.x; s1.y += t1.y; s1.z += t1.z; s1.w += t1.w;
     }
-    if (PER_SAMPLE) {
-      const long o = (long)sample * g.C + 4 * c4;
-      unsafeAtomicAdd(out0 + o + 0, (OutT)s0.x); unsafeAtomicAdd(out0 + o + 1, (OutT)s0.y);
-      unsafeAtomicAdd(out0 + o + 2, (OutT)s0.z); unsafeAtomicAdd(out0 + o + 3, (OutT)s0.w);
-    } else {
+    if (!PER_SAMPLE) {
       // one partial row per row-block: part[blockIdx.x][2][C]; summed in fp64 by the finalise kernel.
       // (contended fp64 atomics on 2C addresses ran at ~1/14 of the atomic rate and were not reproducible)
       OutT* p0 = out0 + (long)blockIdx.x * 2 * g.C + 4 * c4;
       p0[0] = s0.x; p0[1] = s0.y; p0[2] = s0.z; p0[3] = s0.w;
       if (NOUT > 1) { OutT* p1 = p0 + g.C; p1[0] = s1.x; p1[1] = s1.y; p1[2] = s1.z; p1[3] = s1.w; }
     }
+  }
+  if (PER_SAMPLE) {
+    float* o = reinterpret_cast<float*>(out0) + (long)sample * g.C + 4 * c4;
+    if (gridDim.x == 1) {
+      if (owner) st4(o, s0);
+      return;
+    }
+    const long plane = (long)gridDim.z * g.C;
+    if (owner) st4(scratch + blockIdx.x * plane + (long)sample * g.C + 4 * c4, s0);
+    if (!mx_last_arriver(counters + sample * gridDim.y + blockIdx.y, gridDim.x, &last_flag)) return;
+    if (owner) st4(o, ordered_sum4(scratch + (long)sample * g.C + 4 * c4, gridDim.x, plane));
   }
 }
 
@@ -116,11 +144,36 @@ static int colreduce_parts(long rows, int C) {
   return cdiv(rows, g.rows_per_block);
 }
 
+// geometry of the per-sample reductions (mx_pool_sum, mx_se_bn1_pool): falls back to one row block per sample when the
+// launch would need more arrival counters than the scratch header holds
+static ColGeom pool_geom(long rows, int C, int rps, dim3* grid) {
+  const int N = (int)(rows / rps);
+  ColGeom g = col_geom(rows, C, rps, rps, N);
+  const int colchunks = cdiv(g.c4, g.tcols);
+  if ((long)N * colchunks > MX_WS_COUNTERS) g.rows_per_block = rps;
+  *grid = dim3(cdiv(rps, g.rows_per_block), colchunks, N);
+  return g;
+}
+
+static long pool_ws_bytes(long rows, int C, int rps, int planes) {
+  dim3 grid;
+  pool_geom(rows, C, rps, &grid);
+  if (grid.x == 1) return 0;
+  return MX_WS_COUNTER_BYTES + (long)grid.x * planes * (rows / rps) * C * 4;
+}
+
 template <class F, int NOUT, bool PER_SAMPLE, typename OutT>
-static void launch_colreduce(const F& f, long rows, int C, int rps, OutT* o0, OutT* o1, hipStream_t st) {
-  ColGeom g = col_geom(rows, C, rps, PER_SAMPLE ? rps : rows, PER_SAMPLE ? (int)(rows / rps) : 1);
-  dim3 grid(cdiv(PER_SAMPLE ? rps : rows, g.rows_per_block), cdiv(g.c4, g.tcols), PER_SAMPLE ? (int)(rows / rps) : 1);
-  hipLaunchKernelGGL((colreduce_kernel<F, NOUT, PER_SAMPLE, OutT>), grid, dim3(256), 0, st, f, g, o0, o1);
+static void launch_colreduce(const F& f, long rows, int C, int rps, OutT* o0, OutT* o1, hipStream_t st, void* ws = nullptr) {
+  if (PER_SAMPLE) {
+    dim3 grid;
+    ColGeom g = pool_geom(rows, C, rps, &grid);
+    hipLaunchKernelGGL((colreduce_kernel<F, NOUT, PER_SAMPLE, OutT>), grid, dim3(256), 0, st, f, g, o0, o1,
+                       ws ? reinterpret_cast<float*>((char*)ws + MX_WS_COUNTER_BYTES) : nullptr, reinterpret_cast<unsigned*>(ws));
+    return;
+  }
+  ColGeom g = col_geom(rows, C, rps, rows, 1);
+  dim3 grid(cdiv(rows, g.rows_per_block), cdiv(g.c4, g.tcols), 1);
+  hipLaunchKernelGGL((colreduce_kernel<F, NOUT, PER_SAMPLE, OutT>), grid, dim3(256), 0, st, f, g, o0, o1, (float*)nullptr, (unsigned*)nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -197,8 +250,10 @@ struct FPool {           // per-sample: sum act(x) ; optionally sum g*act(x)
 // which needs `add` (the SE backward) but no second pass over the tensors.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void se_bn1_pool_kernel(const float* G, const float* X, const float* a, const float* b, ColGeom g,
-                                                          float* out /*[5][N][C]*/, long plane) {
+                                                          float* out /*[5][N][C]*/, long plane, float* scratch /*[gridDim.x][5][N][C]*/,
+                                                          unsigned* counters) {
   __shared__ float4 sm[5][256];
+  __shared__ unsigned last_flag;
   const int tid = threadIdx.x;
   const int used = g.tcols * g.rpp;
   const int tc = tid % g.tcols, tr = tid / g.tcols;
@@ -245,38 +300,33 @@ __global__ __launch_bounds__(256) void se_bn1_pool_kernel(const float* G, const 
 #pragma unroll
   for (int i = 0; i < 5; ++i) sm[i][tid] = acc[i];
   __syncthreads();
-  if (tid < g.tcols && c4 < g.c4) {
+  const bool owner = tid < g.tcols && c4 < g.c4;
+  const long off = (long)sample * g.C + 4 * c4;
+  // the row blocks of a sample are joined in block order by the last one to arrive (see colreduce_kernel): no atomics
+  float* dst = gridDim.x == 1 ? out : scratch + (long)blockIdx.x * 5 * plane;
+  if (owner) {
 #pragma unroll
     for (int i = 0; i < 5; ++i) {
       float4 s0 = sm[i][tid];
       for (int k = 1; k < g.rpp; ++k) { float4 t0 = sm[i][tid + k * g.tcols]; s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w; }
-      float* o = out + i * plane + (long)sample * g.C + 4 * c4;
-      unsafeAtomicAdd(o + 0, s0.x); unsafeAtomicAdd(o + 1, s0.y); unsafeAtomicAdd(o + 2, s0.z); unsafeAtomicAdd(o + 3, s0.w);
+      st4(dst + i * plane + off, s0);
     }
   }
-}
-
-// part[1][2][C] = (sum_n gate*S1 + add*S2, sum_n gate*S3 + add*S4): the BN1 backward sums, in fp64 -> fp32 partial row
-__global__ void bn1_sums_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* add, int N, int C, float* part) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const long plane = (long)N * C;
-  double s0 = 0.0, s1 = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const long i = (long)n * C + c;
-    s0 += (double)gate[i] * pooled[plane + i] + (double)add[i] * pooled[2 * plane + i];
-    s1 += (double)gate[i] * pooled[3 * plane + i] + (double)add[i] * pooled[4 * plane + i];
+  if (gridDim.x == 1) return;
+  if (!mx_last_arriver(counters + sample * gridDim.y + blockIdx.y, gridDim.x, &last_flag)) return;
+  if (owner) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) st4(out + i * plane + off, ordered_sum4(scratch + i * plane + off, gridDim.x, 5 * plane));
   }
-  part[c] = (float)s0;
-  part[C + c] = (float)s1;
 }
 
 // ---------------------------------------------------------------------------
 // per-channel finalisation kernels (tiny)
 // ---------------------------------------------------------------------------
 // Two-level reduction of the partial rows part[P][2][C]: level 1 (this kernel, grid = channel chunks x row slices)
-// sums a slice of rows in fp64 and adds it into acc[2C] (fp64 atomics, <= 64 adders per address); level 2 is the
-// finalise kernel.  One block = 32 channels x 8 row lanes.
+// sums a slice of rows in fp64 into acc[slice][2C] (plain stores); level 2, the finalise kernel, adds the <= 64 slices in
+// slice order.  One block = 32 channels x 8 row lanes.  (The first version joined the slices with fp64 atomics.)
+constexpr int BN_MAX_SLICES = 64;
 __global__ __launch_bounds__(256) void bn_parts_reduce_kernel(const float* part, int P, int C, int rows_per_slice, double* acc) {
   __shared__ double sh[2][8][32];
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
@@ -299,18 +349,19 @@ __global__ __launch_bounds__(256) void bn_parts_reduce_kernel(const float* part,
   __syncthreads();
   if (rl != 0 || c >= C) return;
   for (int i = 1; i < 8; ++i) { a += sh[0][i][cl]; b += sh[1][i][cl]; }
-  unsafeAtomicAdd(acc + c, a);
-  unsafeAtomicAdd(acc + C + c, b);
+  acc[(long)blockIdx.y * 2 * C + c] = a;
+  acc[(long)blockIdx.y * 2 * C + C + c] = b;
 }
 
-static void launch_parts_reduce(const float* part, int P, int C, double* acc, hipStream_t st) {
+// returns the number of slices written to acc[slices][2C]
+static int launch_parts_reduce(const float* part, int P, int C, double* acc, hipStream_t st) {
   int slices = P / 32;
   if (slices < 1) slices = 1;
-  if (slices > 64) slices = 64;
+  if (slices > BN_MAX_SLICES) slices = BN_MAX_SLICES;
   int rps = (P + slices - 1) / slices;
   slices = (P + rps - 1) / rps;
-  hipMemsetAsync(acc, 0, sizeof(double) * 2 * C, st);
   hipLaunchKernelGGL(bn_parts_reduce_kernel, dim3(cdiv(C, 32), slices), dim3(256), 0, st, part, P, C, rps, acc);
+  return slices;
 }
 
 struct BnFwdFin {
@@ -347,13 +398,14 @@ __device__ __forceinline__ void bn_fwd_finalize_one(int c, double st0, double st
   rstd_out[c] = rstd;
 }
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int C, double count, const float* gamma,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int slices, int C, double count, const float* gamma,
                                    const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
                                    float* scale, float* shift, float* mean_out, float* rstd_out) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   double st0 = 0.0, st1 = 0.0;
-  if (training) { st0 = acc[c]; st1 = acc[C + c]; }
+  if (training)
+    for (int i = 0; i < slices; ++i) { st0 += acc[(long)i * 2 * C + c]; st1 += acc[(long)i * 2 * C + C + c]; }
   bn_fwd_finalize_one(c, st0, st1, count, gamma, beta, rmean, rvar, momentum, eps, training, scale, shift, mean_out, rstd_out);
 }
 
@@ -376,12 +428,14 @@ __device__ __forceinline__ void bn_bwd_finalize_one(int c, double sg, double sgx
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc, int C, double count, const float* gamma,
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc, int slices, int C, double count, const float* gamma,
                                        const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
                                        float* c1, float* c2, float* c3) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
-  bn_bwd_finalize_one(c, acc[c], acc[C + c], count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3);
+  double s0 = 0.0, s1 = 0.0;
+  for (int i = 0; i < slices; ++i) { s0 += acc[(long)i * 2 * C + c]; s1 += acc[(long)i * 2 * C + C + c]; }
+  bn_bwd_finalize_one(c, s0, s1, count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3);
 }
 
 // Up to FUSED_FINALIZE_MAX_ROWS partial rows: reduction and finalisation in ONE launch (one workgroup = 32 channels x 8 row
@@ -414,19 +468,49 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* pa
   else bn_fwd_finalize_one(c, s0, s1, f.count, f.gamma, f.beta, f.rmean, f.rvar, f.momentum, f.eps, 1, f.scale, f.shift, f.mean_out, f.rstd_out);
 }
 
-// bn1_sums + the BN1 backward finalisation in one launch (the sums are one row per channel: nothing to reduce across
-// workgroups).  Same arithmetic as bn1_sums_kernel followed by bn_reduce_finalize_kernel<true> on its single fp32 row.
-__global__ void bn1_sums_finalize_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* add, int N, int C,
-                                         BnBwdFin b) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// The pooled-path gradient of the SE block, the BN1 backward sums and their finalisation in one launch:
+//   add[n,c]  = inv_hw * sum_j gh[n,j] W1[j,c]                (d loss / d squeeze input, model.py:82-83 backward; gh from
+//               mx_se_bwd) - owned per (n, c), j in ascending order: no atomics across squeeze slices
+//   sums      = sum_n gate*S1 + add*S2, sum_n gate*S3 + add*S4 (fp64, n ascending)  -> bn_bwd_finalize_one
+// One workgroup = 64 channels x 4 sample lanes; gh [N][SQ] is staged in LDS.
+__global__ __launch_bounds__(256) void bn1_sums_finalize_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* gh,
+                                                                const float* W1, float inv_hw, float* add, int N, int C, int SQ,
+                                                                BnBwdFin b) {
+  extern __shared__ float ghs[];                      // [N][SQ], then 2 x [4][64] doubles
+  const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  for (int i = threadIdx.x; i < N * SQ; i += 256) ghs[i] = gh[i];
+  __syncthreads();
   const long plane = (long)N * C;
   double s0 = 0.0, s1 = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const long i = (long)n * C + c;
-    s0 += (double)gate[i] * pooled[plane + i] + (double)add[i] * pooled[2 * plane + i];
-    s1 += (double)gate[i] * pooled[3 * plane + i] + (double)add[i] * pooled[4 * plane + i];
+  if (c < C) {
+    for (int n0 = nl; n0 < N; n0 += 16) {             // this lane's samples n0, n0+4, n0+8, n0+12: four accumulators per W1 load
+      float a[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int j = 0; j < SQ; ++j) {
+        const float w = W1[(long)j * C + c];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { const int n = n0 + 4 * k; a[k] += (n < N ? ghs[n * SQ + j] : 0.f) * w; }
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int n = n0 + 4 * k;
+        if (n < N) {
+          const long i = (long)n * C + c;
+          const float ad = a[k] * inv_hw;
+          add[i] = ad;
+          s0 += (double)gate[i] * pooled[plane + i] + (double)ad * pooled[2 * plane + i];
+          s1 += (double)gate[i] * pooled[3 * plane + i] + (double)ad * pooled[4 * plane + i];
+        }
+      }
+    }
   }
+  double* red = reinterpret_cast<double*>(ghs + ((N * SQ + 1) & ~1));
+  __syncthreads();
+  red[nl * 64 + cl] = s0; red[256 + nl * 64 + cl] = s1;
+  __syncthreads();
+  if (nl != 0 || c >= C) return;
+  s0 = ((red[cl] + red[64 + cl]) + red[128 + cl]) + red[192 + cl];
+  s1 = ((red[256 + cl] + red[320 + cl]) + red[384 + cl]) + red[448 + cl];
   bn_bwd_finalize_one(c, (double)(float)s0, (double)(float)s1, b.count, b.gamma, b.mean, b.rstd, b.training, b.dgamma, b.dbeta,
                       b.c1, b.c2, b.c3);
 }
@@ -498,15 +582,16 @@ int mx_bn_finalize(const float* part, int P, int C, double count, const float* g
                    float* mean, float* rstd, double* acc, void* stream) {
   MX_CHECK_ARG(C > 0 && gamma && beta && running_mean && running_var && scale && shift && mean && rstd,
                "bn_finalize: null argument");
-  MX_CHECK_ARG(!training || (part && P > 0 && count > 0 && acc), "bn_finalize: training needs partial statistics, count and acc[2C]");
+  MX_CHECK_ARG(!training || (part && P > 0 && count > 0 && acc), "bn_finalize: training needs partial statistics, count and acc[64][2C]");
   if (training && P <= FUSED_FINALIZE_MAX_ROWS) {
     BnFwdFin f{count, gamma, beta, running_mean, running_var, momentum, eps, 1, scale, shift, mean, rstd};
     hipLaunchKernelGGL(bn_reduce_finalize_kernel<false>, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, part, P, C, f, BnBwdFin{});
     MX_LAUNCH_CHECK();
     return MX_OK;
   }
-  if (training) launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, C, count, gamma,
+  int slices = 0;
+  if (training) slices = launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, slices, C, count, gamma,
                      beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd);
   MX_LAUNCH_CHECK();
   return MX_OK;
@@ -545,8 +630,8 @@ int mx_bn_bwd_finalize(const float* part, int P, int C, double count, const floa
     MX_LAUNCH_CHECK();
     return MX_OK;
   }
-  launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, C, count, gamma,
+  const int slices = launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, slices, C, count, gamma,
                      mean, rstd, training, dgamma, dbeta, c1, c2, c3);
   MX_LAUNCH_CHECK();
   return MX_OK;
@@ -564,46 +649,52 @@ int mx_bn_bwd_apply(const float* G, const float* X, const float* row_scale, cons
   return MX_OK;
 }
 
-// out[n,c] += sum_hw f(X[n,hw,c]) with f = [affine a,b] [swish] [* G]; used for the SE squeeze
-// (model.py:82), the global average pool of the head (MuSCLe.py:240) and their backward reductions.
-// out[5][N][C] (zero-filled by the caller) += the five per-(sample, channel) sums described at se_bn1_pool_kernel
+// bytes of scratch mx_pool_sum (planes = 1) / mx_se_bn1_pool (planes = 5) need; 0 = one row block per sample, no scratch
+long mx_pool_ws(long rows, int C, int rows_per_sample, int planes) {
+  if (rows <= 0 || C <= 0 || C % 4 || rows_per_sample <= 0 || rows % rows_per_sample || (planes != 1 && planes != 5)) return MX_EARG;
+  return pool_ws_bytes(rows, C, rows_per_sample, planes);
+}
+
+// out5[5][N][C] = the five per-(sample, channel) sums described at se_bn1_pool_kernel (overwritten, deterministic)
 int mx_se_bn1_pool(const float* dA, const float* X, const float* scale, const float* shift, long rows, int C, int rows_per_sample,
-                   float* out5, void* stream) {
+                   float* out5, void* ws, long ws_bytes, void* stream) {
   MX_CHECK_ARG(dA && X && scale && shift && out5 && rows > 0 && C % 4 == 0 && rows_per_sample > 0 && rows % rows_per_sample == 0,
                "se_bn1_pool: bad args");
   const int N = (int)(rows / rows_per_sample);
-  ColGeom g = col_geom(rows, C, rows_per_sample, rows_per_sample, N);
-  dim3 grid(cdiv(rows_per_sample, g.rows_per_block), cdiv(g.c4, g.tcols), N);
-  hipLaunchKernelGGL(se_bn1_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, dA, X, scale, shift, g, out5, (long)N * C);
+  dim3 grid;
+  ColGeom g = pool_geom(rows, C, rows_per_sample, &grid);
+  const long need = pool_ws_bytes(rows, C, rows_per_sample, 5);
+  MX_CHECK_ARG(need == 0 || (ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0), "se_bn1_pool: workspace of %ld bytes required (mx_pool_ws)", need);
+  hipLaunchKernelGGL(se_bn1_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, dA, X, scale, shift, g, out5, (long)N * C,
+                     need ? reinterpret_cast<float*>((char*)ws + MX_WS_COUNTER_BYTES) : nullptr, reinterpret_cast<unsigned*>(ws));
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
-// part[2C] (one partial row for mx_bn_bwd_finalize with P = 1) from the pooled sums, the SE gate and the SE backward `add`
-int mx_bn1_sums(const float* pooled5, const float* gate, const float* add, int N, int C, float* part, void* stream) {
-  MX_CHECK_ARG(pooled5 && gate && add && part && N > 0 && C > 0, "bn1_sums: bad args");
-  hipLaunchKernelGGL(bn1_sums_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, pooled5, gate, add, N, C, part);
-  MX_LAUNCH_CHECK();
-  return MX_OK;
-}
-
-int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* add, int N, int C, double count,
-                         const float* gamma, const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
-                         float* c1, float* c2, float* c3, void* stream) {
-  MX_CHECK_ARG(pooled5 && gate && add && N > 0 && C > 0 && count > 0, "bn1_sums_finalize: bad args");
+int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* gh, const float* W1, float inv_hw, float* add,
+                         int N, int C, int SQ, double count, const float* gamma, const float* mean, const float* rstd, int training,
+                         float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream) {
+  MX_CHECK_ARG(pooled5 && gate && gh && W1 && add && N > 0 && C > 0 && SQ > 0 && count > 0, "bn1_sums_finalize: bad args");
   MX_CHECK_ARG(gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3, "bn1_sums_finalize: null pointer");
+  const size_t shb = (size_t)((N * SQ + 1) & ~1) * sizeof(float) + 512 * sizeof(double);
+  MX_CHECK_ARG(shb <= 64 * 1024, "bn1_sums_finalize: N*SQ = %d too large for LDS staging", N * SQ);
   BnBwdFin b{count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3};
-  hipLaunchKernelGGL(bn1_sums_finalize_kernel, dim3(cdiv(C, 64)), dim3(64), 0, (hipStream_t)stream, pooled5, gate, add, N, C, b);
+  hipLaunchKernelGGL(bn1_sums_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), shb, (hipStream_t)stream, pooled5, gate, gh, W1, inv_hw,
+                     add, N, C, SQ, b);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
+// out[n,c] = sum_hw f(X[n,hw,c]) with f = [affine a,b] [swish] [* G] (overwritten, deterministic); used for the SE squeeze
+// (model.py:82), the global average pool of the head (MuSCLe.py:240) and their backward reductions.
 int mx_pool_sum(const float* X, const float* G, const float* scale, const float* shift, int act, long rows, int C,
-                int rows_per_sample, float* out, void* stream) {
+                int rows_per_sample, float* out, void* ws, long ws_bytes, void* stream) {
   MX_CHECK_ARG(X && out && rows > 0 && C % 4 == 0 && rows_per_sample > 0 && rows % rows_per_sample == 0,
                "pool_sum: bad args rows=%ld C=%d rps=%d", rows, C, rows_per_sample);
+  const long need = pool_ws_bytes(rows, C, rows_per_sample, 1);
+  MX_CHECK_ARG(need == 0 || (ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0), "pool_sum: workspace of %ld bytes required (mx_pool_ws)", need);
   FPool f{X, G, scale, shift, C, act};
-  launch_colreduce<FPool, 1, true, float>(f, rows, C, rows_per_sample, out, out, (hipStream_t)stream);
+  launch_colreduce<FPool, 1, true, float>(f, rows, C, rows_per_sample, out, out, (hipStream_t)stream, need ? ws : nullptr);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

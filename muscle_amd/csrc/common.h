@@ -28,6 +28,9 @@ void mx_set_error(const char* fmt, ...);
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// dW[e] += sum_g part[g][e] in a fixed order (wgrad.hip); n = elements per partial matrix, a multiple of 4
+void mx_launch_parts_reduce(const float* part, int groups, int n, float* dW, hipStream_t st);
+
 // ---------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------
@@ -55,6 +58,32 @@ __device__ __forceinline__ float wave_min(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, 64));
   return v;
+}
+
+// ---------------------------------------------------------------------------
+// Ordered cross-workgroup reductions without a second launch ("last arriver finishes").
+// Every workgroup of a group stores its partial result to global scratch, then calls mx_last_arriver(): exactly one
+// caller per group - the one that arrives last - gets true; it then reads ALL partials of the group and adds them in
+// index order, so the result does not depend on which workgroup came last (fp32 atomics gave sums whose last bits
+// moved from run to run).  `counter` must be 0 before the launch and is 0 again afterwards (the last arriver resets it).
+// Scratch layout used by the entry points that take `ws`: [MX_WS_COUNTER_BYTES of counters][partials].
+// ---------------------------------------------------------------------------
+#define MX_WS_COUNTER_BYTES 65536
+#define MX_WS_COUNTERS (MX_WS_COUNTER_BYTES / 4)
+
+__device__ __forceinline__ bool mx_last_arriver(unsigned* counter, unsigned total, unsigned* lds_flag) {
+  __threadfence();                    // release: this thread's partials are visible device-wide before the count moves
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned prev = atomicAdd(counter, 1u);
+    const unsigned last = (prev == total - 1u) ? 1u : 0u;
+    if (last) *counter = 0u;          // everyone has arrived: ready for the next launch
+    *lds_flag = last;
+  }
+  __syncthreads();
+  const bool last = *lds_flag != 0u;
+  if (last) __threadfence();          // acquire: the other workgroups' partials
+  return last;
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -26,7 +26,9 @@ struct DwArgs {
   float* stats;        // fwd: partial statistics [N*tiles][2][C] or null
   const float* ps;     // fwd, inference: BN1 scale / shift of the OUTPUT (running statistics) ...
   const float* pb;
-  float* pooled;       // ... and the SE squeeze sums pooled[n][c] += sum_hw swish(ps*y + pb) (zeroed by the caller), or null
+  float* pooled;       // ... and the SE squeeze sums pooled[n][c] = sum_hw swish(ps*y + pb), or null
+  float* poolpart;     // per-tile partial squeeze rows [tiles][N][C] and the arrival counters [N][channel chunks] (mx_last_arriver)
+  unsigned* counters;
   int N, H, W, Ho, Wo, C, pad;
   int tiles_x, tiles_y;
   int tiles_per_block;   // bwd_weight
@@ -97,14 +99,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   static_assert(TH * (TW / OX) * C4B == 256, "thread mapping");
   __shared__ float4 tile[IH * IW * C4B];
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
-  __shared__ float red[2 * CB];
+  __shared__ __attribute__((aligned(16))) float red[4][2 * CB];     // one row per wave: the four waves are added in wave order (LDS atomics gave sums
+  __shared__ unsigned last_flag;       // whose last bit depended on which wave came first)
   const int tid = threadIdx.x;
   const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
   const int c0 = blockIdx.y * CB, n = blockIdx.z;
   const int oy0 = ty * TH, ox0 = tx * TW;
   dw_stage_weights<K>(a, wl, c0, tid);
   dw_stage_input<K, S, TH, TW>(a, tile, n, oy0, ox0, c0, tid);
-  if (tid < 2 * CB) red[tid] = 0.f;
   __syncthreads();
 
   const int c4 = tid % C4B, q = tid / C4B;
@@ -129,6 +131,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     }
   }
   const int c = c0 + 4 * c4, oy = oy0 + oyl;
+  const int wave = tid >> 6;
   float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
   if (c < a.C && oy < a.Ho) {
 #pragma unroll
@@ -159,30 +162,49 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     for (int o = 8; o < 64; o <<= 1) {
       p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64); p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
     }
-    if ((tid & 63) < C4B) {
-      atomicAdd(&red[4 * c4 + 0], p.x); atomicAdd(&red[4 * c4 + 1], p.y); atomicAdd(&red[4 * c4 + 2], p.z); atomicAdd(&red[4 * c4 + 3], p.w);
-    }
+    if ((tid & 63) < C4B) st4(&red[wave][4 * c4], p);
     __syncthreads();
-    if (tid < CB && c0 + tid < a.C) unsafeAtomicAdd(a.pooled + (long)n * a.C + c0 + tid, red[tid]);
+    const bool own = tid < CB && c0 + tid < a.C;
+    const float v = own ? ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid] : 0.f;
+    if (gridDim.x == 1) {
+      if (own) a.pooled[(long)n * a.C + c0 + tid] = v;
+      return;
+    }
+    // the tiles of a sample are joined by the last workgroup to arrive, in tile order (no atomics: the squeeze, and with it
+    // the whole eval forward, gives the same bits whatever the batch size and the run)
+    if (own) a.poolpart[((long)blockIdx.x * gridDim.z + n) * a.C + c0 + tid] = v;
+    if (!mx_last_arriver(a.counters + n * gridDim.y + blockIdx.y, gridDim.x, &last_flag)) return;
+    const int cl = tid & 31, rl = tid >> 5;
+    float t = 0.f;
+    if (c0 + cl < a.C)
+      for (int pt = rl; pt < (int)gridDim.x; pt += 8) t += a.poolpart[((long)pt * gridDim.z + n) * a.C + c0 + cl];
+    __syncthreads();
+    (&red[0][0])[rl * 32 + cl] = t;
+    __syncthreads();
+    if (own) {
+      const float* r = &red[0][0];
+      float u = r[tid];
+#pragma unroll
+      for (int k = 1; k < 8; ++k) u += r[k * 32 + tid];
+      a.pooled[(long)n * a.C + c0 + tid] = u;
+    }
     return;
   }
   if (a.stats) {
-    // lanes with equal c4 sit 8 apart: fold the wave first, then one LDS atomic per (wave, channel)
+    // lanes with equal c4 sit 8 apart: fold the wave first, then one LDS row per wave, added in wave order
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
       s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
       sq.x += __shfl_xor(sq.x, o, 64); sq.y += __shfl_xor(sq.y, o, 64); sq.z += __shfl_xor(sq.z, o, 64); sq.w += __shfl_xor(sq.w, o, 64);
     }
-    if ((tid & 63) < C4B) {
-      atomicAdd(&red[4 * c4 + 0], s.x); atomicAdd(&red[4 * c4 + 1], s.y); atomicAdd(&red[4 * c4 + 2], s.z); atomicAdd(&red[4 * c4 + 3], s.w);
-      atomicAdd(&red[CB + 4 * c4 + 0], sq.x); atomicAdd(&red[CB + 4 * c4 + 1], sq.y);
-      atomicAdd(&red[CB + 4 * c4 + 2], sq.z); atomicAdd(&red[CB + 4 * c4 + 3], sq.w);
-    }
+    if ((tid & 63) < C4B) { st4(&red[wave][4 * c4], s); st4(&red[wave][CB + 4 * c4], sq); }
     __syncthreads();
-    if (tid < CB && c0 + tid < a.C) {
-      float* prow = a.stats + ((long)n * gridDim.x + blockIdx.x) * 2 * a.C;   // one partial row per (sample, tile)
-      prow[c0 + tid] = red[tid];
-      prow[a.C + c0 + tid] = red[CB + tid];
+    if (tid < 2 * CB) {
+      const int cc = tid % CB;
+      if (c0 + cc < a.C) {
+        float* prow = a.stats + ((long)n * gridDim.x + blockIdx.x) * 2 * a.C;   // one partial row per (sample, tile)
+        prow[(tid / CB) * a.C + c0 + cc] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
+      }
     }
   }
 }
@@ -268,7 +290,7 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwArgs a) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
   static_assert(TH * (TW / OX) * C4B == 256, "thread mapping");
   __shared__ float4 tile[IH * IW * C4B];
-  __shared__ float red[K * K * CB];
+  static_assert(IH * IW * C4B * 4 >= 4 * K * K * CB, "the per-wave partial rows reuse the tile");
   const int tid = threadIdx.x;
   const int c0 = blockIdx.y * CB;
   const int c4 = tid % C4B, q = tid / C4B;
@@ -311,8 +333,11 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwArgs a) {
       }
     }
   }
-  for (int i = tid; i < K * K * CB; i += 256) red[i] = 0.f;
+  // leave: fold each wave, one partial row per wave in the (now free) tile memory, the four rows added in wave order
+  // (LDS atomics here made the last bit of dW depend on which wave arrived first)
   __syncthreads();
+  float* slots = reinterpret_cast<float*>(tile);          // [4][K*K*CB]
+  const int wave = tid >> 6;
 #pragma unroll
   for (int t = 0; t < K * K; ++t) {
     float4 p = part[t];
@@ -320,19 +345,16 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(DwArgs a) {
     for (int o = 8; o < 64; o <<= 1) {
       p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64); p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
     }
-    if ((tid & 63) < C4B) {
-      atomicAdd(&red[t * CB + 4 * c4 + 0], p.x); atomicAdd(&red[t * CB + 4 * c4 + 1], p.y);
-      atomicAdd(&red[t * CB + 4 * c4 + 2], p.z); atomicAdd(&red[t * CB + 4 * c4 + 3], p.w);
-    }
+    if ((tid & 63) < C4B) st4(slots + (wave * K * K + t) * CB + 4 * c4, p);
   }
   __syncthreads();
   for (int i = tid; i < K * K * CB; i += 256) {
     int cc = i % CB, tap = i / CB;
     if (c0 + cc >= a.C) continue;
+    const float v = ((slots[i] + slots[K * K * CB + i]) + slots[2 * K * K * CB + i]) + slots[3 * K * K * CB + i];
     // a.stats = scratch [gridDim.x][C*K*K]: one partial row per workgroup, added by dw_parts_reduce_kernel (up to 228
     // workgroups per channel chunk used to add into the same 16*K*K addresses: contended atomics, 323 us for a 5x5 layer)
-    if (a.stats) a.stats[(long)blockIdx.x * a.C * K * K + (long)(c0 + cc) * K * K + tap] = red[i];
-    else unsafeAtomicAdd(a.y + (long)(c0 + cc) * K * K + tap, red[i]);
+    a.stats[(long)blockIdx.x * a.C * K * K + (long)(c0 + cc) * K * K + tap] = v;
   }
 }
 
@@ -372,9 +394,9 @@ __global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fu
   // (round 1 PMC: the two-array kernel sat at SQ_WAIT_ANY 45-60 %, 1.5-1.9 TB/s).
   constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256, CH = (K == 5) ? 4 : 3;
   static_assert(PER % CH == 0, "staging chunks");
-  __shared__ float4 td[TOT];     // dd with halo
+  __shared__ float4 td[TOT];     // dd with halo; at the end the per-wave partial rows of dW and of the BN0 sums
+  static_assert(TOT * 4 >= 4 * K * K * CB, "the per-wave partial rows reuse the staged tile");
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
-  __shared__ float red[K * K * CB];
   __shared__ __attribute__((aligned(16))) float cst[9 * CB];   // a1 b1 c1 c2 c3 a0 b0 | gate add (per tile)
   const int tid = threadIdx.x, c0 = blockIdx.y * CB;
   const int c4 = tid % C4B;                        // staging: 4 channels per thread
@@ -530,25 +552,26 @@ __global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fu
     }
   }
   // leave: dW and the BN0 sums as this workgroup's partial rows (global atomics here would have every workgroup of a
-  // channel chunk contend on the same K*K*32 addresses: measured ~20 us per workgroup)
+  // channel chunk contend on the same K*K*32 addresses: measured ~20 us per workgroup).  Inside the workgroup each wave
+  // folds its lanes and writes one row into the (now free) tile memory; the four rows are added in wave order.
   __syncthreads();
-  for (int i = tid; i < K * K * CB; i += 256) red[i] = 0.f;
-  __syncthreads();
+  float* slots = reinterpret_cast<float*>(td);             // [4][K*K*CB]
+  const int wave = tid >> 6;
 #pragma unroll
   for (int t = 0; t < K * K; ++t) {
     float2 p = part[t];
     p.x += __shfl_xor(p.x, 16, 64); p.y += __shfl_xor(p.y, 16, 64);
     p.x += __shfl_xor(p.x, 32, 64); p.y += __shfl_xor(p.y, 32, 64);
-    if ((tid & 63) < C2B) { atomicAdd(&red[t * CB + 2 * c2 + 0], p.x); atomicAdd(&red[t * CB + 2 * c2 + 1], p.y); }
+    if ((tid & 63) < C2B) *reinterpret_cast<float2*>(slots + (wave * K * K + t) * CB + 2 * c2) = p;
   }
   __syncthreads();
   for (int i = tid; i < K * K * CB; i += 256) {
     int cc = i % CB, tap = i / CB;
-    if (c0 + cc < a.C) a.dwpart[(long)blockIdx.x * a.C * K * K + (long)(c0 + cc) * K * K + tap] = red[i];
+    if (c0 + cc < a.C)
+      a.dwpart[(long)blockIdx.x * a.C * K * K + (long)(c0 + cc) * K * K + tap] =
+          ((slots[i] + slots[K * K * CB + i]) + slots[2 * K * K * CB + i]) + slots[3 * K * K * CB + i];
   }
   if (a.part) {
-    __syncthreads();
-    if (tid < 2 * CB) red[tid] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int o = 16; o < 64; o <<= 1) {
@@ -556,31 +579,45 @@ __global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fu
       s1.x += __shfl_xor(s1.x, o, 64); s1.y += __shfl_xor(s1.y, o, 64);
     }
     if ((tid & 63) < C2B) {
-      atomicAdd(&red[2 * c2 + 0], s0.x); atomicAdd(&red[2 * c2 + 1], s0.y);
-      atomicAdd(&red[CB + 2 * c2 + 0], s1.x); atomicAdd(&red[CB + 2 * c2 + 1], s1.y);
+      *reinterpret_cast<float2*>(slots + wave * 2 * CB + 2 * c2) = s0;
+      *reinterpret_cast<float2*>(slots + wave * 2 * CB + CB + 2 * c2) = s1;
     }
     __syncthreads();
-    if (tid < CB && c0 + tid < a.C) {
-      float* prow = a.part + (long)blockIdx.x * 2 * a.C;
-      prow[c0 + tid] = red[tid];
-      prow[a.C + c0 + tid] = red[CB + tid];
+    if (tid < 2 * CB) {
+      const int cc = tid % CB;
+      if (c0 + cc < a.C)
+        a.part[(long)blockIdx.x * 2 * a.C + (tid / CB) * a.C + c0 + cc] =
+            ((slots[tid] + slots[2 * CB + tid]) + slots[4 * CB + tid]) + slots[6 * CB + tid];
     }
   }
 }
 
-// dW[i] += sum_g part[g][i]; blockIdx.y takes a slice of the rows so a small C*K*K still fills the chip
-__global__ __launch_bounds__(256) void dw_parts_reduce_kernel(const float* __restrict__ part, int P, int rows_per_slice, int n,
-                                                              float* __restrict__ dW) {
-  int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  int g = blockIdx.y * rows_per_slice;
-  const int g_end = min(P, g + rows_per_slice);
+// dW[i] += sum_g part[g][i]: one workgroup = 16 consecutive elements x 16 row lanes (lane l adds rows l, l+16, ... with four
+// loads in flight), the 16 lane sums are added in lane order: one owner per element, no atomics, same bits every run.
+__global__ __launch_bounds__(256) void dw_parts_reduce_kernel(const float* __restrict__ part, int P, int n, float* __restrict__ dW) {
+  __shared__ float red[16][17];
+  const int el = threadIdx.x & 15, gl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + el;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  for (; g + 4 <= g_end; g += 4) {
-    s0 += part[(long)g * n + i]; s1 += part[(long)(g + 1) * n + i]; s2 += part[(long)(g + 2) * n + i]; s3 += part[(long)(g + 3) * n + i];
+  if (i < n) {
+    int g = gl;
+    for (; g + 48 < P; g += 64) {
+      s0 += part[(long)g * n + i]; s1 += part[(long)(g + 16) * n + i]; s2 += part[(long)(g + 32) * n + i]; s3 += part[(long)(g + 48) * n + i];
+    }
+    for (; g < P; g += 16) s0 += part[(long)g * n + i];
   }
-  for (; g < g_end; ++g) s0 += part[(long)g * n + i];
-  unsafeAtomicAdd(dW + i, (s0 + s1) + (s2 + s3));
+  red[gl][el] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (gl == 0 && i < n) {
+    float t = red[0][el];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) t += red[k][el];
+    dW[i] += t;
+  }
+}
+
+static void launch_dw_parts_reduce(const float* part, int P, int n, float* dW, hipStream_t st) {
+  hipLaunchKernelGGL(dw_parts_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, P, n, dW);
 }
 
 static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int* tiles_y, int* tpb, int* groups) {
@@ -636,8 +673,16 @@ int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S) {
   return N * cdiv(Ho, 8) * cdiv(Wo, S == 1 ? 16 : 8);
 }
 
+// bytes of scratch mx_dwconv_fwd needs when it also produces the SE squeeze sums (`pooled`); 0 = none
+long mx_dwconv_fwd_ws(int N, int Ho, int Wo, int C, int S) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (S != 1 && S != 2)) return MX_EARG;
+  const long tiles = (long)cdiv(Ho, 8) * cdiv(Wo, S == 1 ? 16 : 8);
+  if (tiles == 1) return 0;
+  return MX_WS_COUNTER_BYTES + tiles * N * C * 4;
+}
+
 int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats,
-                  const float* pool_scale, const float* pool_shift, float* pooled, int N,
+                  const float* pool_scale, const float* pool_shift, float* pooled, void* ws, long ws_bytes, int N,
                   int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
   DwArgs a{};
   a.x = X; a.sc = scale; a.sh = shift; a.w = W; a.y = Y; a.stats = stats;
@@ -649,6 +694,13 @@ int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const 
   const int TH = 8, TW = (S == 1) ? 16 : 8;
   a.tiles_x = cdiv(Wo, TW); a.tiles_y = cdiv(Ho, TH);
   dim3 grid(a.tiles_x * a.tiles_y, cdiv(C, CB), N);
+  if (pooled && grid.x > 1) {
+    const long need = mx_dwconv_fwd_ws(N, Ho, Wo, C, S);
+    MX_CHECK_ARG(ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0, "dwconv_fwd: pooled needs %ld bytes of scratch (mx_dwconv_fwd_ws)", need);
+    MX_CHECK_ARG((long)N * grid.y <= MX_WS_COUNTERS, "dwconv_fwd: N=%d x %d channel chunks exceed the %d arrival counters", N, (int)grid.y, MX_WS_COUNTERS);
+    a.counters = reinterpret_cast<unsigned*>(ws);
+    a.poolpart = reinterpret_cast<float*>((char*)ws + MX_WS_COUNTER_BYTES);
+  }
   DW_DISPATCH(FWD_S1, FWD_S2, K, S, grid, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();
   return MX_OK;
@@ -690,28 +742,21 @@ int mx_dwconv_bwd_weight_parts(int N, int Ho, int Wo, int C, int S) {
   return rows;
 }
 
-// dw_scratch: [mx_dwconv_bwd_weight_parts][C*K*K] floats (per-workgroup partial rows, reduced by a second kernel), or
-// NULL: every workgroup adds into dW with atomics (slow when many workgroups share a channel chunk)
+// dw_scratch: [mx_dwconv_bwd_weight_parts][C*K*K] floats (per-workgroup partial rows, added in a fixed order by a second kernel)
 int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift, const float* dY, float* dW, float* dw_scratch,
                          int N, int H, int Wd, int C, int K, int S, int pad_lo, int Ho, int Wo, void* stream) {
   DwArgs a{};
   a.x = X; a.sc = scale; a.sh = shift; a.dy = dY; a.y = dW; a.stats = dw_scratch;
   a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
-  MX_CHECK_ARG(X && dY && dW, "dwconv_bwd_weight: null pointer");
+  MX_CHECK_ARG(X && dY && dW && dw_scratch, "dwconv_bwd_weight: null pointer");
   if (int e = dw_check(a, K, S, "dwconv_bwd_weight")) return e;
   int rows;
   dw_bww_geom(N, Ho, Wo, C, S, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &rows);
   dim3 grid(rows, cdiv(C, CB), 1);
   DW_DISPATCH(BWW_S1, BWW_S2, K, S, grid, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();
-  if (dw_scratch) {
-    const int n = C * K * K, nb = cdiv(n, 256);
-    int slices = nb >= 512 ? 1 : cdiv(512, nb);
-    if (slices > cdiv(rows, 8)) slices = cdiv(rows, 8);
-    const int rps = cdiv(rows, slices);
-    hipLaunchKernelGGL(dw_parts_reduce_kernel, dim3(nb, cdiv(rows, rps)), dim3(256), 0, (hipStream_t)stream, dw_scratch, rows, rps, n, dW);
-    MX_LAUNCH_CHECK();
-  }
+  launch_dw_parts_reduce(dw_scratch, rows, C * K * K, dW, (hipStream_t)stream);
+  MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
@@ -744,14 +789,7 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
   if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();
-  {
-    const int n = C * K * K, nb = cdiv(n, 256);
-    int slices = nb >= 512 ? 1 : cdiv(512, nb);
-    if (slices > cdiv(groups, 8)) slices = cdiv(groups, 8);
-    const int rps = cdiv(groups, slices);
-    hipLaunchKernelGGL(dw_parts_reduce_kernel, dim3(nb, cdiv(groups, rps)), dim3(256), 0, (hipStream_t)stream, dw_scratch, groups, rps,
-                       n, dW);
-  }
+  launch_dw_parts_reduce(dw_scratch, groups, C * K * K, dW, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

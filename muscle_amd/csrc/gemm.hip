@@ -37,6 +37,7 @@ struct GemmArgs {
   int mt, zt;               // M tiles, reduction slices (for the 1-D grids)
   unsigned long long* stamps;   // diagnostic builds only (tools/hip/gemm_lab.hip); null in the library
   float* a_out;             // MX_BNBWD: the prologue's result [M, lda] is also written here (by the N tile 0 workgroups)
+  float* ws;                // TN: scratch for the per-slice partial matrices [slices][M][N]
 };
 
 // Diagnostic hook: tools/hip/gemm_lab.hip compiles this file with MX_GEMM_STAMP defined to record s_memtime stamps per
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(256, gemm_min_waves(TM * TN * 16, BK)) void gemm_ke
   if (LAYOUT == L_TN) {
     kbeg = z * g.ksplit;
     kend = min(g.K, kbeg + g.ksplit);
+    C += z * g.sc;          // sc != 0: every reduction slice adds into its own (zeroed) partial matrix, joined in slice order
   } else {
     A += z * g.sa; B += z * g.sb; C += z * g.sc;
   }
@@ -1023,6 +1025,22 @@ static int check_operand(const MxOperand& o, const char* nm) {
   return MX_OK;
 }
 
+// TN (weight gradient): the pixel reduction is split so the grid fills the chip (>= ~1024 blocks), >= 512 rows per slice
+static int tn_splits(int M, int N, int K, int* ksplit) {
+  const TileCfg tc = kCfgs[pick_cfg(L_TN, M, N, K)];
+  long tiles = (long)cdiv(M, tc.bm) * cdiv(N, tc.bn);
+  // workgroup target of the split (tuning override MX_GEMM_SPLIT_TARGET; swept 1024/1536/2048/3072/4096 on the final
+  // code: 150.7 / 149.6 / 148.9 / 149.8 / 149.6 ms per step)
+  static const long split_target = getenv("MX_GEMM_SPLIT_TARGET") ? atol(getenv("MX_GEMM_SPLIT_TARGET")) : 2048;
+  int splits = (int)((split_target + tiles - 1) / tiles);
+  int maxs = cdiv(K, 512);
+  if (splits > maxs) splits = maxs;
+  if (splits < 1) splits = 1;
+  int ks = cdiv(cdiv(K, splits), 32) * 32;
+  *ksplit = ks;
+  return cdiv(K, ks);
+}
+
 static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
   if (int e = check_operand(g.a, "A")) return e;
   if (int e = check_operand(g.b, "B")) return e;
@@ -1042,20 +1060,19 @@ static int gemm_common(int layout, GemmArgs& g, int batch, hipStream_t st) {
   } else {
     MX_CHECK_ARG(g.M % 4 == 0 && g.N % 4 == 0, "gemm TN: M=%d and N=%d must be multiples of 4", g.M, g.N);
     MX_CHECK_ARG(batch == 1, "gemm TN: not batched");
-    // split the pixel reduction so the grid fills the chip (>= ~1024 blocks), >= 512 rows per split
-    const TileCfg tc = kCfgs[pick_cfg(L_TN, g.M, g.N, g.K)];
-    long tiles = (long)cdiv(g.M, tc.bm) * cdiv(g.N, tc.bn);
-    // workgroup target of the split (tuning override MX_GEMM_SPLIT_TARGET; swept 1024/1536/2048/3072/4096 on the final
-    // code: 150.7 / 149.6 / 148.9 / 149.8 / 149.6 ms per step)
-    static const long split_target = getenv("MX_GEMM_SPLIT_TARGET") ? atol(getenv("MX_GEMM_SPLIT_TARGET")) : 2048;
-    int splits = (int)((split_target + tiles - 1) / tiles);
-    int maxs = cdiv(g.K, 512);
-    if (splits > maxs) splits = maxs;
-    if (splits < 1) splits = 1;
-    int ks = cdiv(cdiv(g.K, splits), 32) * 32;
-    g.ksplit = ks;
-    splits = cdiv(g.K, ks);
-    dispatch<L_TN>(g, splits, st);
+    const int splits = tn_splits(g.M, g.N, g.K, &g.ksplit);
+    if (splits > 1) {
+      // deterministic join: slice z accumulates into partial matrix z of the scratch (one adder per element), a second
+      // kernel adds the partial matrices to dW in slice order.  (The slices used to meet in dW through fp32 atomics.)
+      float* dW = g.c;
+      g.c = g.ws; g.sc = (long)g.M * g.N; g.ldc = g.N;
+      hipMemsetAsync(g.ws, 0, sizeof(float) * (size_t)splits * g.M * g.N, st);
+      dispatch<L_TN>(g, splits, st);
+      MX_LAUNCH_CHECK();
+      mx_launch_parts_reduce(g.ws, splits, g.M * g.N, dW, st);
+    } else {
+      dispatch<L_TN>(g, 1, st);
+    }
   }
   MX_LAUNCH_CHECK();
   return MX_OK;
@@ -1145,14 +1162,27 @@ int mx_pw_dgrad_bnbwd(const float* G, const float* X, const float* coef, const f
   return gemm_common(L_NT, g, 1, (hipStream_t)stream);
 }
 
-// dW[Co,Ci] += G[R,Co]^T * X'[R,Ci] (dW must be zeroed or hold a running sum; fp32 atomics).
+// bytes of scratch mx_pw_wgrad needs for this shape (0: a single reduction slice adds straight into dW)
+long mx_pw_wgrad_ws(int R, int Co, int Ci) {
+  if (R <= 0 || Co <= 0 || Ci <= 0 || Co % 4 || Ci % 4) return MX_EARG;
+  int ks;
+  const int splits = tn_splits(Co, Ci, R, &ks);
+  return splits > 1 ? (long)splits * Co * Ci * 4 : 0;
+}
+
+// dW[Co,Ci] += G[R,Co]^T * X'[R,Ci] (dW must be zeroed or hold a running sum); the general kernel for the shapes
+// mx_pw_wgrad_small / _tile do not take.  Deterministic: see gemm_common.
 int mx_pw_wgrad(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
                 const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
-                void* stream) {
+                void* ws, long ws_bytes, void* stream) {
+  const long need = mx_pw_wgrad_ws(R, Co, Ci);
+  MX_CHECK_ARG(need >= 0, "pw_wgrad: bad extents R=%d Co=%d Ci=%d", R, Co, Ci);
+  MX_CHECK_ARG(need == 0 || (ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0), "pw_wgrad: %ld bytes of scratch required (mx_pw_wgrad_ws)", need);
   GemmArgs g{};
   g.a = MxOperand{G, nullptr, nullptr, nullptr, MX_PLAIN, 1};
   g.b = MxOperand{X, x_scale, x_shift, x_gate, x_mode, rows_per_sample};
   g.c = dW; g.M = Co; g.N = Ci; g.K = R; g.lda = ldg; g.ldb = ldx; g.ldc = Ci;
+  g.ws = (float*)ws;
   return gemm_common(L_TN, g, 1, (hipStream_t)stream);
 }
 

@@ -9,9 +9,51 @@
 // ---------------------------------------------------------------------------
 // small [N, C] classification losses.  mode 0 focal(p,y); 1 soft-margin(x,y); 2 pairwise(p,y);
 // 3 sigmoid forward (out = sigmoid(x)); 4 sigmoid backward (out = g * s * (1-s), x = s, y = g)
-// loss: focal / softmargin -> scalar (atomic accumulate into loss[0]); pairwise -> loss[n]
+// loss: focal / softmargin -> scalar loss[0] (overwritten); pairwise -> loss[n]
 // grad: d loss / d input for a unit upstream gradient (pairwise: per-sample loss_n)
 // ---------------------------------------------------------------------------
+// modes 0 / 1 (scalar losses): ONE workgroup, a wave per sample (strided), per-sample terms parked in LDS and added in
+// sample order by one thread - the loss has the same bits every run (the per-sample workgroups used to meet in an atomic)
+constexpr int CLS_MAXN = 1024;
+__global__ __launch_bounds__(1024) void cls_scalar_loss_kernel(int mode, const float* x, int ldx, const float* y, int ldy, float* loss,
+                                                               float* grad, int ldg, int N, int C) {
+  __shared__ float ln[CLS_MAXN];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, NW = blockDim.x >> 6;
+  for (int n = wave; n < N; n += NW) {
+    const float* xr = x + (long)n * ldx;
+    const float* yr = y + (long)n * ldy;
+    float acc = 0.f;
+    if (mode == 0) {
+      for (int c = lane; c < C; c += 64) {
+        float p = xr[c], t = yr[c];
+        float pt = t * p + (1.f - t) * (1.f - p);
+        float om = 1.f - pt, lg = logf(pt + 1e-9f);
+        acc += -0.5f * om * om * lg;
+        float dpt = -0.5f * (-2.f * om * lg + om * om / (pt + 1e-9f));
+        grad[(long)n * ldg + c] = dpt * (2.f * t - 1.f) / N;
+      }
+      acc = wave_sum(acc) / N;
+    } else {
+      for (int c = lane; c < C; c += 64) {
+        float v = xr[c], t = yr[c];
+        // log sigmoid(v) = min(v,0) - log1p(exp(-|v|))
+        float ls = fminf(v, 0.f) - log1pf(__expf(-fabsf(v)));
+        float lsn = fminf(-v, 0.f) - log1pf(__expf(-fabsf(v)));
+        acc += -(t * ls + (1.f - t) * lsn);
+        grad[(long)n * ldg + c] = (sigmoidf_(v) - t) / ((float)C * N);
+      }
+      acc = wave_sum(acc) / ((float)C * N);
+    }
+    if (lane == 0) ln[n] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int n = 0; n < N; ++n) t += ln[n];
+    loss[0] = t;
+  }
+}
+
 __global__ __launch_bounds__(64) void cls_loss_kernel(int mode, const float* x, int ldx, const float* y, int ldy, float* loss,
                                                       float* grad, int ldg, int N, int C) {
   const int n = blockIdx.x, lane = threadIdx.x;
@@ -19,31 +61,7 @@ __global__ __launch_bounds__(64) void cls_loss_kernel(int mode, const float* x, 
   const float* yr = y + (long)n * ldy;
   if (mode == 3) { for (int c = lane; c < C; c += 64) grad[(long)n * ldg + c] = sigmoidf_(xr[c]); return; }
   if (mode == 4) { for (int c = lane; c < C; c += 64) { float s = xr[c]; grad[(long)n * ldg + c] = yr[c] * s * (1.f - s); } return; }
-  if (mode == 0) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      float p = xr[c], t = yr[c];
-      float pt = t * p + (1.f - t) * (1.f - p);
-      float om = 1.f - pt, lg = logf(pt + 1e-9f);
-      acc += -0.5f * om * om * lg;
-      float dpt = -0.5f * (-2.f * om * lg + om * om / (pt + 1e-9f));
-      grad[(long)n * ldg + c] = dpt * (2.f * t - 1.f) / N;
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) atomicAdd(loss, acc / N);
-  } else if (mode == 1) {
-    float acc = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      float v = xr[c], t = yr[c];
-      // log sigmoid(v) = min(v,0) - log1p(exp(-|v|))
-      float ls = fminf(v, 0.f) - log1pf(__expf(-fabsf(v)));
-      float lsn = fminf(-v, 0.f) - log1pf(__expf(-fabsf(v)));
-      acc += -(t * ls + (1.f - t) * lsn);
-      grad[(long)n * ldg + c] = (sigmoidf_(v) - t) / ((float)C * N);
-    }
-    acc = wave_sum(acc);
-    if (lane == 0) atomicAdd(loss, acc / ((float)C * N));
-  } else {
+  {
     float sn = 0.f, sp = 0.f;
     for (int c = lane; c < C; c += 64) {
       float p = xr[c], t = yr[c];
@@ -77,11 +95,11 @@ __global__ __launch_bounds__(1024) void imc_kernel(const float* emb, const float
   __shared__ float Wm[IMC_MAXN][IMC_MAXN + 1];   // first S, then the symmetric pair weights
   __shared__ unsigned char Pm[IMC_MAXN][IMC_MAXN], Gm[IMC_MAXN][IMC_MAXN];
   __shared__ float nrm[IMC_MAXN], rowk1[IMC_MAXN], rowk2[IMC_MAXN];
-  __shared__ float lossacc, validacc;
+  __shared__ float rowloss[IMC_MAXN];            // per anchor row, added in row order by one thread (was an LDS atomic)
+  __shared__ unsigned char rowvalid[IMC_MAXN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NW = blockDim.x >> 6, NT = blockDim.x;          // one workgroup of 16 waves: every phase strides over waves / threads
   float* E = ws;
-  if (tid == 0) { lossacc = 0.f; validacc = 0.f; }
   for (int i = wave; i < N; i += NW) {
     float s = 0.f;
     for (int d = lane; d < D; d += 64) { float v = emb[(long)i * D + d]; s += v * v; }
@@ -117,9 +135,9 @@ __global__ __launch_bounds__(1024) void imc_kernel(const float* emb, const float
       if (Gm[i][j]) { sn += Wm[i][j]; ++vn; }
     }
     bool valid = vp >= 1 && vn >= 1 && vn > vp;
+    rowloss[i] = valid ? -logf(sp / (sp + sn)) / N : 0.f;
+    rowvalid[i] = valid;
     if (valid) {
-      atomicAdd(&lossacc, -logf(sp / (sp + sn)) / N);
-      atomicAdd(&validacc, 1.f);
       rowk1[i] = (-1.f / sp + 1.f / (sp + sn)) / N;   // d/d sp
       rowk2[i] = (1.f / (sp + sn)) / N;               // d/d sn
     } else {
@@ -162,7 +180,12 @@ __global__ __launch_bounds__(1024) void imc_kernel(const float* emb, const float
     }
   }
   __syncthreads();
-  if (tid == 0) { out[0] = lossacc; out[1] = validacc; }
+  if (tid == 0) {
+    float l = 0.f, v = 0.f;
+    for (int i = 0; i < N; ++i)
+      if (rowvalid[i]) { l += rowloss[i]; v += 1.f; }
+    out[0] = l; out[1] = v;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -225,13 +248,21 @@ __global__ __launch_bounds__(256) void er_diff_kernel(const float* cams, const f
 }
 
 constexpr int RBINS = 2048;
+// Bin sums are kept in 64-bit FIXED POINT (value * 2^36, values are |softmax difference| * mask <= 1; rows of < 2^24
+// elements): integer addition is associative, so the histogram - and with it the loss - has the same bits whatever order
+// the workgroups and their LDS / global atomics land in; fp32 atomics moved the last bits of loss_er from run to run.
+// 2^-36 per element is far below the fp32 round-off of the sum it replaces.
+#define ER_FIX_SCALE 68719476736.0f       /* 2^36 */
+#define ER_FIX_INV (1.0 / 68719476736.0)
+typedef unsigned long long er_fix_t;
+__device__ __forceinline__ er_fix_t er_fix(float v) { return (er_fix_t)(v * ER_FIX_SCALE); }
 // histogram of one radix digit over the elements whose higher digits equal prefix[n]
 __global__ __launch_bounds__(256) void er_hist_kernel(const float* d, long row_len, int shift, int nbits, unsigned himask,
-                                                      const unsigned* prefix, unsigned* hcnt, float* hsum) {
+                                                      const unsigned* prefix, unsigned* hcnt, er_fix_t* hsum) {
   __shared__ unsigned lc[RBINS];
-  __shared__ float ls[RBINS];
+  __shared__ er_fix_t ls[RBINS];
   const int n = blockIdx.y;
-  for (int i = threadIdx.x; i < RBINS; i += 256) { lc[i] = 0; ls[i] = 0.f; }
+  for (int i = threadIdx.x; i < RBINS; i += 256) { lc[i] = 0; ls[i] = 0; }
   __syncthreads();
   const unsigned pf = prefix[n], dm = (1u << nbits) - 1u;
   const float* row = d + n * row_len;
@@ -243,28 +274,28 @@ __global__ __launch_bounds__(256) void er_hist_kernel(const float* d, long row_l
     if (key != 0u && (key & himask) == pf) {     // exact zeros (masked channels) cannot change the top-k sum
       unsigned b = (key >> shift) & dm;
       atomicAdd(&lc[b], 1u);
-      atomicAdd(&ls[b], v);
+      atomicAdd(&ls[b], er_fix(v));
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < RBINS; i += 256)
-    if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); unsafeAtomicAdd(&hsum[n * RBINS + i], ls[i]); }
+    if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); atomicAdd(&hsum[n * RBINS + i], ls[i]); }
 }
 
 // per row: pick the digit of the k-th largest; state = {krem (still to take), prefix, sum_gt, cnt_eq}.
 // One wave per row: lane l owns the l-th chunk of bins counted from the top; a wave scan of the chunk counts finds the
 // chunk in which the running count reaches k, and only that lane walks its bins.  (One thread per row walking up to
 // 2048 bins through dependent global loads took 340 us per pass, three passes per step.)
-__global__ __launch_bounds__(64) void er_scan_kernel(const unsigned* hcnt, const float* hsum, int shift, int nbits, unsigned* krem,
-                                                     unsigned* prefix, float* sum_gt, unsigned* cnt_eq, int N) {
+__global__ __launch_bounds__(64) void er_scan_kernel(const unsigned* hcnt, const er_fix_t* hsum, int shift, int nbits, unsigned* krem,
+                                                     unsigned* prefix, er_fix_t* sum_gt, unsigned* cnt_eq, int N) {
   const int n = blockIdx.x, lane = threadIdx.x;
   if (n >= N) return;
   const int nb = 1 << nbits, per = nb / 64;          // nbits is 10 or 11
   const unsigned* hc = hcnt + (long)n * RBINS;
-  const float* hs = hsum + (long)n * RBINS;
+  const er_fix_t* hs = hsum + (long)n * RBINS;
   const int top = nb - 1 - lane * per;               // this lane's bins: top, top-1, ..., top-per+1
   unsigned cl = 0;
-  float sl = 0.f;
+  er_fix_t sl = 0;
   for (int i = 0; i < per; ++i) { cl += hc[top - i]; sl += hs[top - i]; }
   unsigned incl = cl;                                // inclusive scan over lanes (from the top bin down)
 #pragma unroll
@@ -275,11 +306,13 @@ __global__ __launch_bounds__(64) void er_scan_kernel(const unsigned* hcnt, const
   const unsigned k0 = krem[n];
   const unsigned long long m = __ballot(incl >= k0);
   const int L = m ? (__ffsll((long long)m) - 1) : 63;  // no chunk reaches k: the walk ends at bin 0, which lane 63 owns
-  const float s_above = wave_sum(lane < L ? sl : 0.f);
+  er_fix_t s_above = lane < L ? sl : 0;                // integer wave sum: exact
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s_above += (er_fix_t)__shfl_xor((long long)s_above, o, 64);
   const unsigned k_above = __shfl(incl - cl, L, 64);
   if (lane != L) return;
   unsigned k = k0 - k_above;
-  float s = sum_gt[n] + s_above;
+  er_fix_t s = sum_gt[n] + s_above;
   int b = top;
   for (; b > 0 && b > top - per; --b) {
     unsigned c = hc[b];
@@ -301,13 +334,14 @@ __global__ void er_krem_init_kernel(unsigned* krem, int N, const int* k_dev) {
   for (int n = threadIdx.x; n < N; n += 64) krem[n] = (unsigned)k_dev[0];
 }
 
-__global__ void er_final_kernel(const unsigned* krem, const unsigned* prefix, const float* sum_gt, int N, float inv_nk, float* loss,
+__global__ void er_final_kernel(const unsigned* krem, const unsigned* prefix, const er_fix_t* sum_gt, int N, float inv_nk, float* loss,
                                 const int* k_dev) {
   if (k_dev) inv_nk = 1.0f / ((float)N * (float)k_dev[0]);
-  float acc = 0.f;
-  for (int n = threadIdx.x; n < N; n += 64) acc += sum_gt[n] + (float)krem[n] * __uint_as_float(prefix[n]);
-  acc = wave_sum(acc);
-  if (threadIdx.x == 0) loss[0] = acc * inv_nk;
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < N; n += 64) acc += (double)sum_gt[n] * ER_FIX_INV + (double)krem[n] * (double)__uint_as_float(prefix[n]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (threadIdx.x == 0) loss[0] = (float)(acc * (double)inv_nk);
 }
 
 // gradient w.r.t. raw sgcs: selected elements get -sign(c - s) * m / (N k) (ties at tau share krem/cnt_eq),
@@ -382,7 +416,13 @@ int mx_cls_loss(int mode, const float* x, int ldx, const float* y, int ldy, floa
                 void* stream) {
   MX_CHECK_ARG(mode >= 0 && mode <= 4 && x && y && grad && N > 0 && C > 0, "cls_loss: bad args");
   MX_CHECK_ARG(mode >= 3 || loss, "cls_loss: loss output required");
-  hipLaunchKernelGGL(cls_loss_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mode, x, ldx, y, ldy, loss, grad, ldg, N, C);
+  if (mode <= 1) {
+    MX_CHECK_ARG(N <= CLS_MAXN, "cls_loss: N=%d (<= %d)", N, CLS_MAXN);
+    hipLaunchKernelGGL(cls_scalar_loss_kernel, dim3(1), dim3(N >= 16 ? 1024 : 64 * N), 0, (hipStream_t)stream, mode, x, ldx, y, ldy, loss,
+                       grad, ldg, N, C);
+  } else {
+    hipLaunchKernelGGL(cls_loss_kernel, dim3(N), dim3(64), 0, (hipStream_t)stream, mode, x, ldx, y, ldy, loss, grad, ldg, N, C);
+  }
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -403,9 +443,9 @@ int mx_softmaxnorm(const float* x, const float* gy, float* out, int N, int K, lo
 }
 
 // ER forward.  workspace layout (caller-allocated, zero-filled): d [N*K*HW] floats, then
-//   state: krem[N] u32, prefix[N] u32, sum_gt[N] f32, cnt_eq[N] u32, hcnt[N*2048] u32, hsum[N*2048] f32
+//   state: krem[N] u32, prefix[N] u32, sum_gt[N] u64 (fixed point), cnt_eq[N] u32, hcnt[N*2048] u32, hsum[N*2048] u64
 int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int K, long HW, long k, float* d, unsigned* krem,
-              unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum, float* loss, void* stream) {
+              unsigned* prefix, unsigned long long* sum_gt, unsigned* cnt_eq, unsigned* hcnt, unsigned long long* hsum, float* loss, void* stream) {
   MX_CHECK_ARG(cams && sgcs && lwb && d && krem && prefix && sum_gt && cnt_eq && hcnt && hsum && loss, "er_fwd: null pointer");
   MX_CHECK_ARG(N > 0 && K >= 2 && K <= KMAX && HW > 0, "er_fwd: bad extents");
   MX_CHECK_ARG(k >= 1 && k <= (long)K * HW, "er_fwd: k=%ld out of range for rows of %ld (torch.topk would raise)", k, (long)K * HW);
@@ -423,7 +463,7 @@ int mx_er_fwd(const float* cams, const float* sgcs, const float* lwb, int N, int
   if (chunks > 512) chunks = 512;
   for (int ps = 0; ps < 3; ++ps) {
     hipMemsetAsync(hcnt, 0, sizeof(unsigned) * N * RBINS, st);
-    hipMemsetAsync(hsum, 0, sizeof(float) * N * RBINS, st);
+    hipMemsetAsync(hsum, 0, sizeof(er_fix_t) * N * RBINS, st);
     hipLaunchKernelGGL(er_hist_kernel, dim3(chunks, N), dim3(256), 0, st, d, row_len, shifts[ps], bits[ps], himask[ps], prefix,
                        hcnt, hsum);
     hipLaunchKernelGGL(er_scan_kernel, dim3(N), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
@@ -519,11 +559,11 @@ __device__ __forceinline__ int lr_pixel(const float* cam, const float* sgc, int 
 
 __global__ __launch_bounds__(256) void er_lr_hist_kernel(const float* cam, const float* sgc, const float* lwb, int h, int w, int L,
                                                          int K, int H, int W, int shift, int nbits, unsigned himask,
-                                                         const unsigned* prefix, unsigned* hcnt, float* hsum) {
+                                                         const unsigned* prefix, unsigned* hcnt, er_fix_t* hsum) {
   __shared__ unsigned lc[RBINS];
-  __shared__ float ls[RBINS];
+  __shared__ er_fix_t ls[RBINS];
   const int n = blockIdx.y;
-  for (int i = threadIdx.x; i < RBINS; i += 256) { lc[i] = 0; ls[i] = 0.f; }
+  for (int i = threadIdx.x; i < RBINS; i += 256) { lc[i] = 0; ls[i] = 0; }
   __syncthreads();
   const unsigned pf = prefix[n], dm = (1u << nbits) - 1u;
   const long HW = (long)H * W;
@@ -541,13 +581,13 @@ __global__ __launch_bounds__(256) void er_lr_hist_kernel(const float* cam, const
       if (key != 0u && (key & himask) == pf) {
         unsigned bb = (key >> shift) & dm;
         atomicAdd(&lc[bb], 1u);
-        atomicAdd(&ls[bb], v);
+        atomicAdd(&ls[bb], er_fix(v));
       }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < RBINS; i += 256)
-    if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); unsafeAtomicAdd(&hsum[n * RBINS + i], ls[i]); }
+    if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); atomicAdd(&hsum[n * RBINS + i], ls[i]); }
 }
 
 // gradient w.r.t. the low-res SGC: one workgroup per low-res cell gathers from the full-res pixels it feeds
@@ -606,15 +646,18 @@ __global__ __launch_bounds__(256) void er_lr_bwd_kernel(const float* cam, const 
 
 // The same gradient with every full-resolution pixel evaluated ONCE (the gather kernel above evaluates each pixel for
 // each of the up to four low-res cells it feeds).  One workgroup = a band of `ty` rows x 256 columns, thread = column.
-// ty is chosen so that a band spans less than one low-res row: its pixels touch at most three low-res rows, which are
+// ty is chosen so that a band spans less than one low-res row spacing: its pixels touch at most three low-res rows, which are
 // three register slots per class; the column direction goes through LDS atomics, then one global atomic per touched
-// (cell, class).  gsgc must be zero-filled.
+// (cell, class).  Both levels add 64-bit FIXED-POINT integers (the unscaled per-pixel terms are O(1): value * 2^40), so
+// the sums do not depend on the order the atomics land in; er_lr_bwd_finish_kernel converts and applies the common factor
+// 1 / (N k) * upstream.  gacc must be zero-filled.
+#define ER_BWD_FIX 1099511627776.0f        /* 2^40 */
 template <int KT>
 __global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, const float* sgc, const float* lwb,
                                                              const unsigned* prefix, const unsigned* krem, const unsigned* cnt_eq,
-                                                             const float* gup, float gscale, const int* k_dev, float* gsgc, int h, int w, int L,
+                                                             unsigned long long* gacc, int h, int w, int L,
                                                              int H, int W, int ty) {
-  extern __shared__ float lacc[];                 // [3][ncx][KT]
+  extern __shared__ unsigned long long lacc[];                 // [3][ncx][KT]
   const int n = blockIdx.z, Y0 = blockIdx.y * ty, X = blockIdx.x * 256 + threadIdx.x;
   const int Y1 = min(H, Y0 + ty);
   int cb, t1, xb, xe, t2;
@@ -623,10 +666,8 @@ __global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, c
   lr_coord(blockIdx.x * 256, w, W, xb, t2, tw);
   lr_coord(min(W - 1, blockIdx.x * 256 + 255), w, W, t1, xe, tw);
   const int ncx = xe - xb + 1;
-  for (int i = threadIdx.x; i < 3 * ncx * KT; i += 256) lacc[i] = 0.f;
+  for (int i = threadIdx.x; i < 3 * ncx * KT; i += 256) lacc[i] = 0ull;
   __syncthreads();
-  if (k_dev) gscale = 1.0f / ((float)gridDim.z * (float)k_dev[0]);
-  if (gup) gscale *= gup[0];
   float S[3][KT];
 #pragma unroll
   for (int r = 0; r < 3; ++r)
@@ -650,7 +691,7 @@ __global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, c
         unsigned key = __float_as_uint(fabsf(df) * m[k]);
         float ww = (key > tk) ? 1.f : ((key == tk) ? tiew : 0.f);
         float sg = (df > 0.f) ? 1.f : ((df < 0.f) ? -1.f : 0.f);
-        g[k] = -sg * m[k] * ww * gscale;
+        g[k] = -sg * m[k] * ww;
       }
       float g0 = g[0];
 #pragma unroll
@@ -680,20 +721,29 @@ __global__ __launch_bounds__(256) void er_lr_bwd_band_kernel(const float* cam, c
       for (int k = 1; k < KT; ++k) {
         const float v = S[r][k];
         if (v != 0.f) {
-          atomicAdd(&lacc[(r * ncx + (x0 - xb)) * KT + k], u0 * v);
-          if (u1 != 0.f) atomicAdd(&lacc[(r * ncx + (x1 - xb)) * KT + k], u1 * v);
+          atomicAdd(&lacc[(r * ncx + (x0 - xb)) * KT + k], (unsigned long long)(long long)(u0 * v * ER_BWD_FIX));
+          if (u1 != 0.f) atomicAdd(&lacc[(r * ncx + (x1 - xb)) * KT + k], (unsigned long long)(long long)(u1 * v * ER_BWD_FIX));
         }
       }
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 3 * ncx * KT; i += 256) {
-    const float v = lacc[i];
-    if (v == 0.f) continue;
+    const unsigned long long v = lacc[i];
+    if (v == 0ull) continue;
     const int k = i % KT, cx = (i / KT) % ncx, r = i / (KT * ncx);
     const int cy = cb + r;
-    if (cy < h) unsafeAtomicAdd(&gsgc[(((long)n * h + cy) * w + xb + cx) * L + k], v);
+    if (cy < h) atomicAdd(&gacc[(((long)n * h + cy) * w + xb + cx) * L + k], v);
   }
+}
+
+// gsgc = fixed-point sums * 2^-40 * gscale * upstream
+__global__ __launch_bounds__(256) void er_lr_bwd_finish_kernel(const unsigned long long* gacc, const float* gup, float gscale, const int* k_dev,
+                                                               int N, float* gsgc, long total) {
+  if (k_dev) gscale = 1.0f / ((float)N * (float)k_dev[0]);
+  if (gup) gscale *= gup[0];
+  const double f = (double)gscale / (double)ER_BWD_FIX;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) gsgc[i] = (float)((double)(long long)gacc[i] * f);
 }
 
 extern "C" {
@@ -701,8 +751,8 @@ extern "C" {
 // ER loss from the low-res NHWC maps cam/sgc [N,h,w,L] for an H x W image (train_mcl.py:175-188 + MuSCLe.py:256-257 fused).
 // state buffers as mx_er_fwd (prefix and sum_gt zeroed by the caller); nothing of size H*W is allocated.
 int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
-                 const int* k_dev, unsigned* krem, unsigned* prefix, float* sum_gt, unsigned* cnt_eq, unsigned* hcnt, float* hsum,
-                 float* loss, void* stream) {
+                 const int* k_dev, unsigned* krem, unsigned* prefix, unsigned long long* sum_gt, unsigned* cnt_eq, unsigned* hcnt,
+                 unsigned long long* hsum, float* loss, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && krem && prefix && sum_gt && cnt_eq && hcnt && hsum && loss, "er_lr_fwd: null pointer");
   MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L % 4 == 0 && H > 0 && W > 0, "er_lr_fwd: bad extents (L must be a multiple of 4)");
   MX_CHECK_ARG((((uintptr_t)cam | (uintptr_t)sgc) & 15) == 0, "er_lr_fwd: maps must be 16-byte aligned");
@@ -718,7 +768,7 @@ int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, in
   if (chunks > 256) chunks = 256;
   for (int ps = 0; ps < 3; ++ps) {
     hipMemsetAsync(hcnt, 0, sizeof(unsigned) * N * RBINS, st);
-    hipMemsetAsync(hsum, 0, sizeof(float) * N * RBINS, st);
+    hipMemsetAsync(hsum, 0, sizeof(er_fix_t) * N * RBINS, st);
     hipLaunchKernelGGL(er_lr_hist_kernel, dim3(chunks, N), dim3(256), 0, st, cam, sgc, lwb, h, w, L, K, H, W, shifts[ps], bits[ps],
                        himask[ps], prefix, hcnt, hsum);
     hipLaunchKernelGGL(er_scan_kernel, dim3(N), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
@@ -729,27 +779,36 @@ int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, in
   return MX_OK;
 }
 
+// bytes of scratch mx_er_lr_bwd needs (64-bit accumulators of the 21-class band kernel; 0 for other class counts)
+long mx_er_lr_bwd_ws(int N, int h, int w, int L, int K) {
+  if (N <= 0 || h <= 0 || w <= 0 || L <= 0) return MX_EARG;
+  return K == 21 ? (long)N * h * w * L * 8 : 0;
+}
+
 int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix, const unsigned* krem,
                  const unsigned* cnt_eq, const float* gup, float gscale, const int* k_dev, float* gsgc, int N, int h, int w, int L,
-                 int K, int H, int W, void* stream) {
+                 int K, int H, int W, void* ws, long ws_bytes, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && prefix && krem && cnt_eq && gsgc, "er_lr_bwd: null pointer");
   MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L % 4 == 0 && L <= 256 && H > 0 && W > 0, "er_lr_bwd: bad extents (L must be a multiple of 4)");
   MX_CHECK_ARG((((uintptr_t)cam | (uintptr_t)sgc) & 15) == 0, "er_lr_bwd: maps must be 16-byte aligned");
   if (K == 21) {
+    const long total = (long)N * h * w * L;
+    MX_CHECK_ARG(ws && ws_bytes >= total * 8 && ((uintptr_t)ws & 7) == 0, "er_lr_bwd: %ld bytes of scratch required (mx_er_lr_bwd_ws)", total * 8);
     // rows per band: the largest count that keeps a band within one low-res row spacing (at most three low-res rows touched)
     int ty = (h > 1) ? (H - 1) / (h - 1) : H;
     if (ty < 1) ty = 1;
     if (ty > 32) ty = 32;
-    int xb0, xe0, t;                                 // widest low-res column span of a 256-column segment (host copy of lr_coord)
-    (void)xb0; (void)t;
-    const double sx = (W > 1) ? (double)(w - 1) / (double)(W - 1) : 0.0;
-    xe0 = (int)(sx * 255.0) + 3;
+    const double sx = (W > 1) ? (double)(w - 1) / (double)(W - 1) : 0.0;   // widest low-res column span of a 256-column segment
+    int xe0 = (int)(sx * 255.0) + 3;
     if (xe0 > w) xe0 = w;
-    const size_t sh = (size_t)3 * (xe0 + 1) * 21 * sizeof(float);
+    const size_t sh = (size_t)3 * (xe0 + 1) * 21 * sizeof(unsigned long long);
     MX_CHECK_ARG(sh <= 64 * 1024, "er_lr_bwd: low-res span per segment too wide (%d columns)", xe0);
-    hipMemsetAsync(gsgc, 0, sizeof(float) * (size_t)N * h * w * L, (hipStream_t)stream);
+    hipMemsetAsync(ws, 0, (size_t)total * 8, (hipStream_t)stream);
     hipLaunchKernelGGL(er_lr_bwd_band_kernel<21>, dim3(cdiv(W, 256), cdiv(H, ty), N), dim3(256), sh, (hipStream_t)stream, cam, sgc,
-                       lwb, prefix, krem, cnt_eq, gup, gscale, k_dev, gsgc, h, w, L, H, W, ty);
+                       lwb, prefix, krem, cnt_eq, (unsigned long long*)ws, h, w, L, H, W, ty);
+    long nb = (total + 255) / 256;
+    hipLaunchKernelGGL(er_lr_bwd_finish_kernel, dim3((int)(nb < 2048 ? nb : 2048)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned long long*)ws, gup, gscale, k_dev, N, gsgc, total);
   } else {
     hipLaunchKernelGGL(er_lr_bwd_kernel, dim3(h * w, N), dim3(256), 0, (hipStream_t)stream, cam, sgc, lwb, prefix, krem, cnt_eq, gup,
                        gscale, k_dev, gsgc, h, w, L, K, H, W);

@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void se_fwd_expand_kernel(const float* h, cons
 }
 
 // ---- backward --------------------------------------------------------------------------------------
-// (A) g_r[n,j] = sum_c ge[n,c] W2[c,j] with ge = ggate*gate*(1-gate);  gh[n,j] = g_r * swish'(h);  db1[j] += gh.
+// (A) g_r[n,j] = sum_c ge[n,c] W2[c,j] with ge = ggate*gate*(1-gate);  gh[n,j] = g_r * swish'(h)   (db1 leaves kernel B).
 //     One wave per (n, four consecutive j): W2 is [C,SQ] row-major, so a lane's load is one 16-byte piece of row c
 //     (a wave per single j fetched 4 useful bytes per 64-byte request).  SQ is a multiple of 4 for every EfficientNet width.
 __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* ggate, const float* gate, const float* h, const float* W2,
-                                                       float* gh, float* db1, int C, int SQ) {
+                                                       float* gh, int C, int SQ) {
   const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = (blockIdx.y * 4 + wave) * 4;
   if (j >= SQ) return;
@@ -64,13 +64,12 @@ __global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* ggate, const
     const float a = lane == 0 ? acc.x : lane == 1 ? acc.y : lane == 2 ? acc.z : acc.w;
     const float v = a * swish_gradf_(h[(long)n * SQ + j + lane]);
     gh[(long)n * SQ + j + lane] = v;
-    unsafeAtomicAdd(db1 + j + lane, v);
   }
 }
 
 // the same with one squeeze unit per wave, for widths whose SQ is not a multiple of 4 (B0 ... B6)
 __global__ __launch_bounds__(256) void se_bwd_a1_kernel(const float* ggate, const float* gate, const float* h, const float* W2,
-                                                       float* gh, float* db1, int C, int SQ) {
+                                                       float* gh, int C, int SQ) {
   const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int j = blockIdx.y * 4 + wave;
   if (j >= SQ) return;
@@ -85,16 +84,17 @@ __global__ __launch_bounds__(256) void se_bwd_a1_kernel(const float* ggate, cons
   if (lane == 0) {
     float v = acc * swish_gradf_(h[(long)n * SQ + j]);
     gh[(long)n * SQ + j] = v;
-    unsafeAtomicAdd(db1 + j, v);
   }
 }
 
 // (B) thread = channel c, block row = chunk of SE_JB squeeze units: dW2[c,j] += sum_n ge[n,c] r[n,j];
-//     dW1[j,c] += sum_n gh[n,j] s[n,c] (both owned, no atomics); add[n,c] += inv_hw * sum_{j in chunk} gh[n,j] W1[j,c]
-//     (fp32 atomics across the <= 40 chunks of 4 squeeze units; `add` is zero-filled by the entry point); db2 by chunk 0.
+//     dW1[j,c] += sum_n gh[n,j] s[n,c]; db2 by chunk 0; db1[j] += sum_n gh[n,j] by the first threads of channel block 0.
+//     Everything is owned by one thread and summed over n in ascending order: no atomics, same bits every run.
+//     (The pooled-path gradient add[n,c] = inv_hw * sum_j gh[n,j] W1[j,c] used to leave here through fp32 atomics across
+//     the squeeze chunks; it is now formed, per (n, c) in one thread, by mx_bn1_sums_finalize, its first consumer.)
 constexpr int SE_NB = 32, SE_JB = 4;
 __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* ggate, const float* gate, const float* s, const float* h,
-                                                       const float* gh, const float* W1, float inv_hw, float* add, float* dW1,
+                                                       const float* gh, float* dW1, float* db1,
                                                        float* dW2, float* db2, int N, int C, int SQ) {
   extern __shared__ float sh[];          // r[N][SE_JB], ghs[N][SE_JB]
   float* r = sh;
@@ -107,14 +107,19 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* ggate, const
     ghs[i] = ok ? gh[(long)n * SQ + j0 + jj] : 0.f;
   }
   __syncthreads();
+  if (blockIdx.x == 0 && threadIdx.x < jn) {
+    float a = 0.f;
+    for (int n = 0; n < N; ++n) a += ghs[n * SE_JB + threadIdx.x];
+    db1[j0 + threadIdx.x] += a;
+  }
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= C) return;
   for (int n0 = 0; n0 < N; n0 += SE_NB) {
-    float ge[SE_NB], sv[SE_NB], acc[SE_NB];
+    float ge[SE_NB], sv[SE_NB];
     float sb = 0.f;
 #pragma unroll
     for (int n = 0; n < SE_NB; ++n) {
-      ge[n] = sv[n] = acc[n] = 0.f;
+      ge[n] = sv[n] = 0.f;
       if (n0 + n < N) {
         float g = gate[(long)(n0 + n) * C + c];
         ge[n] = ggate[(long)(n0 + n) * C + c] * g * (1.f - g);
@@ -125,21 +130,15 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* ggate, const
     if (blockIdx.y == 0) db2[c] += sb;
     for (int jj = 0; jj < jn; ++jj) {
       float a2 = 0.f, a1 = 0.f;
-      const float w = W1[(long)(j0 + jj) * C + c];
 #pragma unroll
       for (int n = 0; n < SE_NB; ++n) {
         const int nn = (n0 + n < N) ? n0 + n : 0;     // ge/sv are 0 beyond N
         a2 += ge[n] * r[nn * SE_JB + jj];
-        const float g = ghs[nn * SE_JB + jj];
-        a1 += g * sv[n];
-        acc[n] += g * w;
+        a1 += ghs[nn * SE_JB + jj] * sv[n];
       }
       dW2[(long)c * SQ + j0 + jj] += a2;
       dW1[(long)(j0 + jj) * C + c] += a1;
     }
-#pragma unroll
-    for (int n = 0; n < SE_NB; ++n)
-      if (n0 + n < N) unsafeAtomicAdd(add + (long)(n0 + n) * C + c, acc[n] * inv_hw);
   }
 }
 
@@ -184,24 +183,21 @@ int mx_se_fwd(const float* pooled_sum, float inv_hw, const float* W1, const floa
   return MX_OK;
 }
 
-int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W1, const float* W2,
-              float inv_hw, float* add, float* dW1, float* db1, float* dW2, float* db2, float* gh_scratch, int N, int C,
+int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W2,
+              float* dW1, float* db1, float* dW2, float* db2, float* gh, int N, int C,
               int SQ, void* stream) {
-  MX_CHECK_ARG(ggate && gate && s && h && W1 && W2 && add && dW1 && db1 && dW2 && db2, "se_bwd: null pointer");
+  MX_CHECK_ARG(ggate && gate && s && h && W2 && dW1 && db1 && dW2 && db2, "se_bwd: null pointer");
   MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd: bad extents N=%d C=%d SQ=%d", N, C, SQ);
-  MX_CHECK_ARG(gh_scratch != nullptr, "se_bwd: gh_scratch [N*SQ] required");
+  MX_CHECK_ARG(gh != nullptr, "se_bwd: gh [N*SQ] required");
 
   size_t shb = (size_t)2 * N * SE_JB * sizeof(float);
   MX_CHECK_ARG(shb <= 48 * 1024, "se_bwd: N=%d too large for LDS staging", N);
-  // `add` is accumulated with atomics across the squeeze slices: the CALLER hands it in zero-filled
   if (SQ % 4 == 0 && ((uintptr_t)W2 & 15) == 0)
-    hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 16)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
-                       C, SQ);
+    hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 16)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh, C, SQ);
   else
-    hipLaunchKernelGGL(se_bwd_a1_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh_scratch, db1,
-                       C, SQ);
-  hipLaunchKernelGGL(se_bwd_b_kernel, dim3(cdiv(C, 256), cdiv(SQ, SE_JB)), dim3(256), shb, (hipStream_t)stream, ggate, gate, s, h, gh_scratch, W1,
-                     inv_hw, add, dW1, dW2, db2, N, C, SQ);
+    hipLaunchKernelGGL(se_bwd_a1_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh, C, SQ);
+  hipLaunchKernelGGL(se_bwd_b_kernel, dim3(cdiv(C, 256), cdiv(SQ, SE_JB)), dim3(256), shb, (hipStream_t)stream, ggate, gate, s, h, gh,
+                     dW1, db1, dW2, db2, N, C, SQ);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

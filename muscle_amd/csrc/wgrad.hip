@@ -178,6 +178,10 @@ static int wg_pad16(int c) {           // smallest stride >= c (rounded to 16) t
 
 struct WgPlan { int nw, wco, wci, tco, tci, groups, rows_per_wg, SG, SX; long lds_bytes; };
 
+void mx_launch_parts_reduce(const float* part, int groups, int n, float* dW, hipStream_t st) {
+  hipLaunchKernelGGL(wgrad_parts_reduce_kernel, dim3(cdiv(n, 64)), dim3(256), 0, st, part, groups, n, dW);
+}
+
 static bool wg_plan(int R, int Co, int Ci, WgPlan* p) {
   const int cot = cdiv(Co, 16), cit = cdiv(Ci, 16);
   if (Co % 4 || Ci % 4 || (long)Co * Ci > 40960 || R < 65536) return false;

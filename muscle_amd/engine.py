@@ -14,7 +14,7 @@ e_raw, d_raw, p_raw, out (and `a` where materialised) are what exists in HBM; th
 
 Per block, backward:
     g_out --BN2 bwd (reduce, finalise, apply)--> dp --pw_wgrad / pw_dgrad--> dA
-    (dA, d_raw) --se_bn1_pool (one pass: SE gate gradient + BN1 backward sums per sample)--> se_bwd --> add, c1..c3
+    (dA, d_raw) --se_bn1_pool (one pass: SE gate gradient + BN1 backward sums per sample)--> se_bwd --> gh --bn1_coeffs--> add, c1..c3
     stride 1: dwconv_bwd_fused[BN1 data gradient on the fly; dW, dX, *swish'(bn0), BN0 sums] --> gz
     stride 2: bn_bwd_apply --> dwconv_bwd_weight, dwconv_bwd_data --> ge --BN0 bwd reduce
     gz --BN0 finalise + apply--> de --pw_wgrad / pw_dgrad (+skip gradient)--> g_in
@@ -394,24 +394,25 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         # sums; the excitation backward then gives the pooled-path term `add`, and the BN1 sums follow without
         # touching the big tensors again.
         pooled5 = ops.se_bn1_pool(ga, d2, t.bn1, hw)
-        add = ops.se_bwd(pooled5[0], t.gate, t.s, t.h, m._se_reduce.weight.view(b.se, b.cexp), m._se_expand.weight.view(b.cexp, b.se),
-                         1.0 / hw, sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
-                         sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias))
+        gh = ops.se_bwd(pooled5[0], t.gate, t.s, t.h, m._se_expand.weight.view(b.cexp, b.se),
+                        sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
+                        sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias))
+        # pooled-path gradient `add`, the BN1 backward sums and their finalisation: one launch, no second pass over the tensors
+        c1, add = ops.bn1_coeffs(pooled5, t.gate, gh, m._se_reduce.weight.view(b.se, b.cexp), 1.0 / hw, Mo, m._bn1, t.bn1,
+                                 sink.of(m._bn1.weight), sink.of(m._bn1.bias), training)
         dw_in, dw_st = (t.e_raw, t.bn0) if b.expand else (t.x, t.x_st)
         skip_res = g_out if b.skip else None            # d out / d x through the identity branch
         fused = FUSED_DW_BACKWARD and b.stride == 1 and b.pad_lo == (b.kernel - 1) // 2
         if fused:
             # stride 1: BN1 data gradient, depthwise weight + data gradients and the BN0 backward sums in one kernel
-            c1 = ops.bn1_coeffs(pooled5, t.gate, add, Mo, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training)
             gx, part0 = ops.dwconv_bwd_fused(ga.view(N, t.Ho, t.Wo, b.cexp), t.d_raw, t.gate, add, t.bn1, c1, dw_in, dw_st,
                                              m._depthwise_conv.weight, sink.of(m._depthwise_conv.weight), b.kernel, b.pad_lo,
                                              residual=None if dw_st is not None else skip_res)
             del ga
         else:
             # BN1 backward with g = (ga*gate + add) * swish'(bn1(d_raw)), in place over ga
-            dd = ops.bn_backward_from_sums(ga, d2, m._bn1, t.bn1, sink.of(m._bn1.weight), sink.of(m._bn1.bias), training,
-                                           ops.bn1_sums(pooled5, t.gate, add), gate=t.gate, gate_add=add, rows_per_sample=hw,
-                                           out=ga).view(N, t.Ho, t.Wo, b.cexp)
+            dd = ops.bn_backward_from_coeffs(ga, d2, t.bn1, c1, gate=t.gate, gate_add=add, rows_per_sample=hw,
+                                             out=ga).view(N, t.Ho, t.Wo, b.cexp)
             ops.dwconv_bwd_weight(dw_in, dd, sink.of(m._depthwise_conv.weight), b.kernel, b.stride, b.pad_lo, st=dw_st)
             gx = ops.dwconv_bwd_data(dd, m._depthwise_conv.weight, b.kernel, b.stride, b.pad_lo, t.H, t.W,
                                      residual=None if dw_st is not None else skip_res)

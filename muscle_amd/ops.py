@@ -27,27 +27,25 @@ def _f32(*shape, device):
     return torch.empty(shape, dtype=torch.float32, device=device)
 
 
-# Zero-initialised accumulators (pooled sums, SE / BN1 partials): ~230 per B7 step, each a 5 us fill launch of its own.
-# They are carved out of 32 MB slabs that one memset clears (keyed by stream: a slab is only valid behind its memset).
-_zslabs: dict = {}
-_ZSLAB_FLOATS = 8 << 20
+# Scratch for the entry points that take `ws` (include/muscle_hip.h): one persistent, zero-initialised buffer per
+# (device, stream) - the arrival counters in its first 64 KB are left zero by every launch, so it can be handed to one call
+# after the other.  A buffer that has to grow is REPLACED but never freed: a captured hipGraph has the old pointer baked in.
+_scratch_bufs: dict = {}
+_scratch_retired: list = []
 
 
-def _zeros(*shape, device):
-    n = 1
-    for d in shape:
-        n *= d
-    n4 = (n + 3) // 4 * 4
-    if n4 > _ZSLAB_FLOATS // 4 or torch.cuda.is_current_stream_capturing():
-        return torch.zeros(shape, dtype=torch.float32, device=device)   # (captured graphs must re-clear at every replay)
+def _scratch(device, nbytes):
+    """(pointer, size) of this stream's scratch, at least nbytes large; (None, 0) when nbytes == 0."""
+    if nbytes <= 0:
+        return None, 0
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
-    ent = _zslabs.get(key)
-    if ent is None or ent[1] + n4 > _ZSLAB_FLOATS:
-        ent = [torch.zeros(_ZSLAB_FLOATS, dtype=torch.float32, device=device), 0]
-        _zslabs[key] = ent
-    out = ent[0][ent[1]:ent[1] + n].view(shape)
-    ent[1] += n4
-    return out
+    buf = _scratch_bufs.get(key)
+    if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            _scratch_retired.append(buf)
+        buf = torch.zeros(max(int(nbytes), 64 << 20), dtype=torch.uint8, device=device)
+        _scratch_bufs[key] = buf
+    return buf.data_ptr(), buf.numel()
 
 
 # ---- GEMMs ------------------------------------------------------------------------------------
@@ -113,6 +111,7 @@ def pw_dgrad_bnbwd(G, X, coef, W, N_in, *, residual=None, wt=None):
 
 
 _wgrad_ws: dict = {}
+_wgrad_ws_retired: list = []      # outgrown workspaces stay alive: captured graphs keep writing to them
 WGRAD_TILE = os.environ.get("MUSCLE_WGRAD_TILE", "1") == "1"   # large outputs: tiled deterministic kernel (wgrad.hip) instead of the atomic TN GEMM
 WGRAD_SMALL = True       # small outputs / long reductions: one workgroup owns the whole output, deterministic partial sums
 
@@ -121,6 +120,8 @@ def _wgrad_workspace(device, nbytes):
     key = (device.index if device.index is not None else torch.cuda.current_device(), stream())
     ws = _wgrad_ws.get(key)
     if ws is None or ws.numel() < nbytes:
+        if ws is not None:
+            _wgrad_ws_retired.append(ws)
         ws = torch.empty(max(nbytes, 64 << 20), dtype=torch.uint8, device=device)
         _wgrad_ws[key] = ws
     return ws
@@ -144,8 +145,10 @@ def pw_wgrad(G, X, dW, *, x_mode=PLAIN, x_scale=None, x_shift=None, x_gate=None,
             call("mx_pw_wgrad_tile", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),
                  R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())
             return
+    need = lib().mx_pw_wgrad_ws(R, Co, Ci)
+    ws = _wgrad_workspace(G.device, need) if need > 0 else None
     call("mx_pw_wgrad", ptr(G), ptr(X), x_mode, ptr(x_scale), ptr(x_shift), ptr(x_gate), rows_per_sample, ptr(dW),
-         R, Co, Ci, G.stride(0), X.stride(0), stream())
+         R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0, stream())
 
 
 def bgemm(layout, A, B, out, M, N, K, *, relu=False):
@@ -175,7 +178,7 @@ def bn_finalize(stats, count, bn: torch.nn.BatchNorm2d, training: bool) -> BNSta
     mom = 0.0 if bn.momentum is None else float(bn.momentum)
     call("mx_bn_finalize", ptr(stats), stats.shape[0] if stats is not None else 0, C, float(count), ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
          ptr(bn.running_var), mom, float(bn.eps), int(training), base, base + 4 * C, base + 8 * C, base + 12 * C,
-         _acc_scratch(dev, 2 * C) if training else None, stream())
+         _acc_scratch(dev, 128 * C) if training else None, stream())
     if training:
         _nbt_pending.append(bn.num_batches_tracked)
     return BNState(b0, b1, b2, b3)
@@ -185,12 +188,14 @@ _acc_bufs: dict = {}
 
 
 def _acc_scratch(dev, n):
-    """fp64 scratch of the two-level statistics reduction (only touched when a layer has more than 1024 partial rows): one
-    persistent buffer per (device, stream) instead of an allocation per BatchNorm."""
+    """fp64 scratch acc[64][2C] of the two-level statistics reduction (only touched when a layer has more than 1024 partial
+    rows): one persistent buffer per (device, stream) instead of an allocation per BatchNorm; outgrown ones are kept."""
     key = (dev.index if dev.index is not None else torch.cuda.current_device(), stream())
     t = _acc_bufs.get(key)
     if t is None or t.numel() < n:
-        t = _acc_bufs[key] = torch.empty(max(n, 16384), dtype=torch.float64, device=dev)
+        if t is not None:
+            _scratch_retired.append(t)
+        t = _acc_bufs[key] = torch.empty(max(n, 128 * 4096), dtype=torch.float64, device=dev)
     return t.data_ptr()
 
 
@@ -229,7 +234,7 @@ def bn_backward(G2d, X2d, bn: torch.nn.BatchNorm2d, st: BNState, dgamma, dbeta, 
     c = _f32(3, C, device=X2d.device)
     call("mx_bn_bwd_finalize", ptr(sums), P, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
          ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]),
-         ptr(torch.empty(2 * C, dtype=torch.float64, device=X2d.device)), stream())
+         _acc_scratch(X2d.device, 128 * C), stream())
     if out is None:
         out = torch.empty_like(X2d)
     call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), ptr(row_scale), ptr(gate), ptr(gate_add), ptr(a_sc), ptr(a_sh),
@@ -237,15 +242,12 @@ def bn_backward(G2d, X2d, bn: torch.nn.BatchNorm2d, st: BNState, dgamma, dbeta, 
     return out
 
 
-def bn_backward_from_sums(G2d, X2d, bn, st: BNState, dgamma, dbeta, training: bool, part, *, gate, gate_add, rows_per_sample, out):
-    """As bn_backward for g = (G*gate + gate_add)*swish'(bn(X)), with the reduction already available as one partial row."""
+def bn_backward_from_coeffs(G2d, X2d, st: BNState, c, *, gate, gate_add, rows_per_sample, out):
+    """dX of BatchNorm-1 for g = (G*gate + gate_add)*swish'(bn(X)) with the coefficients c [3,C] already known (bn1_coeffs)."""
     rows, C = X2d.shape
-    c = _f32(3, C, device=X2d.device)
-    call("mx_bn_bwd_finalize", ptr(part), 1, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
-         ptr(dgamma), ptr(dbeta), ptr(c[0]), ptr(c[1]), ptr(c[2]),
-         ptr(torch.empty(2 * C, dtype=torch.float64, device=X2d.device)), stream())
+    cb, cs = c.data_ptr(), 4 * C
     call("mx_bn_bwd_apply", ptr(G2d), ptr(X2d), None, ptr(gate), ptr(gate_add), ptr(st.scale), ptr(st.shift),
-         ptr(c[0]), ptr(c[1]), ptr(c[2]), ptr(out), rows, C, rows_per_sample, stream())
+         cb, cb + cs, cb + 2 * cs, ptr(out), rows, C, rows_per_sample, stream())
     return out
 
 
@@ -255,7 +257,7 @@ def bn_bwd_coeffs(part, rows, bn, st: BNState, dgamma, dbeta, training: bool):
     c = _f32(3, C, device=part.device)
     base = c.data_ptr()
     call("mx_bn_bwd_finalize", ptr(part), P, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training),
-         ptr(dgamma), ptr(dbeta), base, base + 4 * C, base + 8 * C, _acc_scratch(part.device, 2 * C), stream())
+         ptr(dgamma), ptr(dbeta), base, base + 4 * C, base + 8 * C, _acc_scratch(part.device, 128 * C), stream())
     return c
 
 
@@ -285,33 +287,31 @@ def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNStat
 def se_bn1_pool(dA2d, X2d, st: BNState, rows_per_sample):
     rows, C = X2d.shape
     N = rows // rows_per_sample
-    out = _zeros(5, N, C, device=X2d.device)
-    call("mx_se_bn1_pool", ptr(dA2d), ptr(X2d), ptr(st.scale), ptr(st.shift), rows, C, rows_per_sample, ptr(out), stream())
+    out = _f32(5, N, C, device=X2d.device)
+    ws, wsn = _scratch(X2d.device, lib().mx_pool_ws(rows, C, rows_per_sample, 5))
+    call("mx_se_bn1_pool", ptr(dA2d), ptr(X2d), ptr(st.scale), ptr(st.shift), rows, C, rows_per_sample, ptr(out), ws, wsn, stream())
     return out
 
 
-def bn1_sums(pooled5, gate, add):
+def bn1_coeffs(pooled5, gate, gh, W1, inv_hw, rows, bn, st: BNState, dgamma, dbeta, training: bool):
+    """From the pooled sums and the SE backward's gh [N,SQ]: the pooled-path gradient add [N,C], the BatchNorm-1 backward sums,
+    dgamma/dbeta (+=) and the [3,C] coefficients of the BN1 data gradient, in one launch.  Returns (c, add)."""
     _, N, C = pooled5.shape
-    part = _f32(1, 2, C, device=gate.device)
-    call("mx_bn1_sums", ptr(pooled5), ptr(gate), ptr(add), N, C, ptr(part), stream())
-    return part
-
-
-def bn1_coeffs(pooled5, gate, add, rows, bn, st: BNState, dgamma, dbeta, training: bool):
-    """bn1_sums + bn_bwd_coeffs in one launch: the [3,C] coefficients of the BN1 data gradient, dgamma/dbeta (+=)."""
-    _, N, C = pooled5.shape
+    SQ = W1.shape[0]
     c = _f32(3, C, device=gate.device)
+    add = torch.empty_like(gate)
     base = c.data_ptr()
-    call("mx_bn1_sums_finalize", ptr(pooled5), ptr(gate), ptr(add), N, C, float(rows), ptr(bn.weight), ptr(st.mean), ptr(st.rstd),
-         int(training), ptr(dgamma), ptr(dbeta), base, base + 4 * C, base + 8 * C, stream())
-    return c
+    call("mx_bn1_sums_finalize", ptr(pooled5), ptr(gate), ptr(gh), ptr(W1), float(inv_hw), ptr(add), N, C, SQ, float(rows),
+         ptr(bn.weight), ptr(st.mean), ptr(st.rstd), int(training), ptr(dgamma), ptr(dbeta), base, base + 4 * C, base + 8 * C, stream())
+    return c, add
 
 
 def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=False):
     rows, C = X2d.shape
-    out = _zeros(rows // rows_per_sample, C, device=X2d.device)
+    out = _f32(rows // rows_per_sample, C, device=X2d.device)
+    ws, wsn = _scratch(X2d.device, lib().mx_pool_ws(rows, C, rows_per_sample, 1))
     call("mx_pool_sum", ptr(X2d), ptr(G), ptr(st.scale) if st else None, ptr(st.shift) if st else None, int(act), rows, C,
-         rows_per_sample, ptr(out), stream())
+         rows_per_sample, ptr(out), ws, wsn, stream())
     return out
 
 
@@ -321,9 +321,10 @@ def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, want
     N, H, Wd, C = X.shape
     Y = _f32(N, Ho, Wo, C, device=X.device)
     stats = _f32(lib().mx_dwconv_fwd_parts(N, Ho, Wo, S), 2, C, device=X.device) if want_stats else None
-    pooled = _zeros(N, C, device=X.device) if pool is not None else None
+    pooled = _f32(N, C, device=X.device) if pool is not None else None
+    ws, wsn = _scratch(X.device, lib().mx_dwconv_fwd_ws(N, Ho, Wo, C, S)) if pool is not None else (None, 0)
     call("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),
-         ptr(pool[0]) if pool is not None else None, ptr(pool[1]) if pool is not None else None, ptr(pooled),
+         ptr(pool[0]) if pool is not None else None, ptr(pool[1]) if pool is not None else None, ptr(pooled), ws, wsn,
          N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
     if pool is not None:
         return Y, pooled
@@ -356,14 +357,15 @@ def se_fwd(pooled, inv_hw, W1, b1, W2, b2):
     return s, h, gate
 
 
-def se_bwd(ggate, gate, s, h, W1, W2, inv_hw, dW1, db1, dW2, db2):
+def se_bwd(ggate, gate, s, h, W2, dW1, db1, dW2, db2):
+    """SE excitation backward: parameter gradients (+=) and gh [N,SQ] = dL/d(se_reduce output), from which bn1_coeffs forms
+    the pooled-path gradient."""
     N, C = ggate.shape
-    SQ = W1.shape[0]
-    add = _zeros(N, C, device=ggate.device)          # accumulated with atomics: handed in zero-filled
+    SQ = W2.shape[1]
     gh = torch.empty_like(h)
-    call("mx_se_bwd", ptr(ggate), ptr(gate), ptr(s), ptr(h), ptr(W1), ptr(W2), float(inv_hw), ptr(add), ptr(dW1), ptr(db1),
-         ptr(dW2), ptr(db2), ptr(gh), N, C, SQ, stream())
-    return add
+    call("mx_se_bwd", ptr(ggate), ptr(gate), ptr(s), ptr(h), ptr(W2), ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), ptr(gh), N, C, SQ,
+         stream())
+    return gh
 
 
 def stem_im2col(img, Ho, Wo, pad_lo):

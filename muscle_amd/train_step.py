@@ -8,7 +8,7 @@ from typing import Dict, Optional
 import torch
 
 from . import loss_multilabel as L
-from ._lib import call, ptr, stream
+from ._lib import call, lib, ptr, stream
 
 _RBINS = 2048
 
@@ -51,9 +51,9 @@ class _ERLoss(torch.autograd.Function):
         dev = raw_cams.device
         d = torch.empty(N * K * HW, dtype=torch.float32, device=dev)
         st_u = torch.zeros(3, N, dtype=torch.int32, device=dev)          # krem, prefix, cnt_eq
-        sum_gt = torch.zeros(N, dtype=torch.float32, device=dev)
+        sum_gt = torch.zeros(N, dtype=torch.int64, device=dev)           # 64-bit fixed point (include/muscle_hip.h)
         hcnt = torch.empty(N * _RBINS, dtype=torch.int32, device=dev)
-        hsum = torch.empty(N * _RBINS, dtype=torch.float32, device=dev)
+        hsum = torch.empty(N * _RBINS, dtype=torch.int64, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         call("mx_er_fwd", ptr(raw_cams), ptr(raw_sgcs), ptr(lwb), N, K, HW, int(k), ptr(d), ptr(st_u[0]), ptr(st_u[1]),
              ptr(sum_gt), ptr(st_u[2]), ptr(hcnt), ptr(hsum), ptr(loss), stream())
@@ -88,9 +88,9 @@ class _ERLossLowRes(torch.autograd.Function):
             raise RuntimeError(f"selected index k={k} out of range for rows of {K * H * W} (torch.topk raises the same)")
         dev = cam_lr.device
         st_u = torch.zeros(3, N, dtype=torch.int32, device=dev)          # krem, prefix, cnt_eq
-        sum_gt = torch.zeros(N, dtype=torch.float32, device=dev)
+        sum_gt = torch.zeros(N, dtype=torch.int64, device=dev)           # 64-bit fixed point (include/muscle_hip.h)
         hcnt = torch.empty(N * _RBINS, dtype=torch.int32, device=dev)
-        hsum = torch.empty(N * _RBINS, dtype=torch.float32, device=dev)
+        hsum = torch.empty(N * _RBINS, dtype=torch.int64, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
         call("mx_er_lr_fwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), N, h, w, L, K, H, W, int(k), ptr(k_dev), ptr(st_u[0]), ptr(st_u[1]),
              ptr(sum_gt), ptr(st_u[2]), ptr(hcnt), ptr(hsum), ptr(loss), stream())
@@ -106,8 +106,11 @@ class _ERLossLowRes(torch.autograd.Function):
         N, h, w, L = cam_lr.shape
         out = torch.empty_like(sgc_lr)
         gup = g.contiguous().float().reshape(1)
+        need = lib().mx_er_lr_bwd_ws(N, h, w, L, lwb.shape[1])
+        ws = torch.empty(max(need, 8), dtype=torch.uint8, device=out.device)
         call("mx_er_lr_bwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), ptr(st_u[1]), ptr(st_u[0]), ptr(st_u[2]), ptr(gup),
-             (1.0 / (N * k) if ctx.k_dev is None else 0.0), ptr(ctx.k_dev), ptr(out), N, h, w, L, lwb.shape[1], H, W, stream())
+             (1.0 / (N * k) if ctx.k_dev is None else 0.0), ptr(ctx.k_dev), ptr(out), N, h, w, L, lwb.shape[1], H, W,
+             ws.data_ptr(), need, stream())
         return None, out, None, None, None, None
 
 

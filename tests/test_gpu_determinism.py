@@ -1,0 +1,72 @@
+"""Run-to-run determinism of the training step (missing #1): the reference CPU path gives the same bits every
+run (src/efficientnet_pytorch/model.py:81-82 SE squeeze, src/MuSCLe.py:240 GAP are plain sums); the build joined several
+reductions through fp32 atomics until round 3.  Two fresh models fed the same batch must now agree BIT FOR BIT in every loss
+term, in the whole gradient arena, in the BatchNorm buffers and in the parameters after the Adam step.  This is a
+self-comparison: it runs last (tests/conftest.py)."""
+import numpy as np
+import pytest
+import torch
+
+import muscle_amd
+from muscle_amd import synth
+from muscle_amd.arch import net_cfg
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+LOSSES = ("loss_focal", "loss_softmargin", "loss_pair", "loss_er", "loss_imc", "loss_pixpro", "loss_emd")
+
+
+def _one_step(name, n, size, view, ep, seed, disturb):
+    cfg = net_cfg(name, False)
+    sd = synth.synth_state_dict(cfg, seed)
+    model = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.to(DEV)
+    opt = muscle_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=5e-5)
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synth_batch(n, size, view, seed).items()}
+    torch.manual_seed(3)
+    du = {b.index: torch.rand(n).to(DEV) for b in cfg.blocks if b.skip and b.drop_rate}
+    bg = None
+    if disturb:
+        # a second stream keeps the chip busy with unrelated work, so workgroups of the step land in a different order
+        bg = torch.cuda.Stream()
+        with torch.cuda.stream(bg):
+            junk = torch.randn(4096, 4096, device=DEV)
+            for _ in range(20):
+                junk = junk * 1.0001 + 0.5
+    out = muscle_amd.mcl_step(model, opt, batch, ep, drop_u=du)
+    torch.cuda.synchronize()
+    losses = np.array([float(out[k]) for k in LOSSES], dtype=np.float32)
+    arena = model.last_grad_sink.arena.cpu().numpy().copy()
+    params = torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()
+    bufs = torch.cat([b.detach().reshape(-1).float() for b in model.buffers()]).cpu().numpy()
+    return losses, arena, params, bufs
+
+
+@pytest.mark.parametrize("name,n,size,view,ep", [("efficientnet-b0", 4, 64, 32, 4), ("efficientnet-b3", 4, 96, 48, 4)])
+def test_step_phase1_is_bit_reproducible(name, n, size, view, ep):
+    a = _one_step(name, n, size, view, ep, 5, disturb=False)
+    b = _one_step(name, n, size, view, ep, 5, disturb=True)
+    c = _one_step(name, n, size, view, ep, 5, disturb=False)
+    for tag, x, y, z in zip(("losses", "gradient arena", "parameters", "buffers"), a, b, c):
+        assert np.array_equal(x, y) and np.array_equal(x, z), (tag, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
+
+
+def test_eval_forward_is_bit_reproducible_and_batch_invariant():
+    """Inference (BASELINE.json configs[4]): the folded eval forward has no batch statistics, so a row of a batch equals the
+    same image run alone, bit for bit, now that the SE squeeze / GAP sums are joined in a fixed order."""
+    name, seed = "efficientnet-b3", 11
+    cfg = net_cfg(name, False)
+    sd = synth.synth_state_dict(cfg, seed)
+    model = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()}, strict=True)
+    model.to(DEV).eval()
+    x = torch.from_numpy(synth.normal(seed, "x", (6, 3, 160, 128)).astype(np.float32)).to(DEV)
+    with torch.no_grad():
+        full = [t.clone() for t in model(x, cam="cam_lr")]
+        again = model(x, cam="cam_lr")
+        one = model(x[4:5], cam="cam_lr")
+    for f, g in zip(full, again):
+        assert torch.equal(f, g)
+    for f, o in zip(full, one):
+        assert torch.equal(f[4:5], o)

@@ -38,8 +38,10 @@ def test_two_ranks_same_batch_reproduce_single_process_update(tmp_path, backend)
     assert int(r0["early"]) > 0 and int(r1["early"]) > 0          # chunks went out while backward was still running
     # both ranks hold the same averaged gradient and took the same update (bit for bit: same reduction, same order)
     assert np.array_equal(r0["arena"], r1["arena"]) and np.array_equal(r0["params"], r1["params"])
-    np.testing.assert_allclose(r0["losses"], single["losses"], rtol=1e-5)
-    # averaged gradient == the single-process gradient up to the run-to-run noise of the fp32 atomics in backward
+    # losses are replica-local: the contract tolerance between two fp32 implementations (1e-4) is the
+    # bar here; that a run reproduces its own bits is tests/test_gpu_determinism.py's subject, not this test's
+    np.testing.assert_allclose(r0["losses"], single["losses"], rtol=1e-4)
+    # averaged gradient == the single-process gradient
     g, gs = r0["arena"].astype(np.float64), single["arena"].astype(np.float64)
     scale = np.abs(gs).max()
     assert np.abs(g - gs).max() <= 2e-3 * scale, np.abs(g - gs).max() / scale

@@ -151,7 +151,9 @@ class MuSCLe(nn.Module):
     def fold_eval_bn(self):
         """Fold the eval-mode BatchNorms into the 1x1 convolution weights ONCE (CAM generation, infer_mcl.py:107-125: the
         model is loaded and only ever run in eval mode).  Without this call the no-grad eval forward folds per forward.
-        The cache is dropped by train(); call again after loading other weights."""
+        The cache is dropped by train() and carries a fingerprint (storage address + in-place version of every source
+        tensor): a forward that finds other weights underneath - loaded through a submodule, edited in place, moved to
+        another device - refolds by itself."""
         self.backbone._eval_fold = engine.fold_eval_bn(self.backbone, self.cfg)
         return self
 

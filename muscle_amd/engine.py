@@ -92,6 +92,24 @@ def _bn_affine(bn: torch.nn.BatchNorm2d):
     return s, bn.bias.detach() - s * bn.running_mean
 
 
+def _fold_sources(backbone, cfg: NetCfg):
+    """Every tensor the inference fold is computed from."""
+    for b in cfg.blocks:
+        m = _blk(backbone, b.index)
+        if b.expand:
+            yield m._expand_conv.weight
+            yield from (m._bn0.weight, m._bn0.bias, m._bn0.running_mean, m._bn0.running_var)
+        yield from (m._bn1.weight, m._bn1.bias, m._bn1.running_mean, m._bn1.running_var)
+        yield m._project_conv.weight
+        yield from (m._bn2.weight, m._bn2.bias, m._bn2.running_mean, m._bn2.running_var)
+
+
+def fold_fingerprint(backbone, cfg: NetCfg):
+    """(storage address, in-place version) of every source tensor: moves when weights are loaded through ANY module
+    (load_state_dict copies in place), edited in place, or moved to another device."""
+    return tuple((t.data_ptr(), t._version) for t in _fold_sources(backbone, cfg))
+
+
 def fold_eval_bn(backbone, cfg: NetCfg):
     """Inference-only constants of every block (infer_mcl.py:107-125 runs the model in eval mode): BN0 folded into the
     expand weight (+ bias), BN2 folded into the project weight (+ bias), BN1 as scale / shift for the depthwise kernel's
@@ -115,6 +133,7 @@ def fold_eval_bn(backbone, cfg: NetCfg):
     cmax = max(b.cexp for b in cfg.blocks)
     out["one"] = torch.ones(cmax, dtype=torch.float32, device=dev)
     out["zero"] = torch.zeros(cmax, dtype=torch.float32, device=dev)
+    out["fingerprint"] = fold_fingerprint(backbone, cfg)
     return out
 
 
@@ -202,7 +221,12 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
     x, x_st, h, w = tape.stem_raw, tape.stem_bn, H0, W0
     fold = None
     if not training and not save and EVAL_FOLD:
-        fold = getattr(backbone, "_eval_fold", None) or fold_eval_bn(backbone, cfg)
+        fold = getattr(backbone, "_eval_fold", None)
+        if fold is not None and fold["fingerprint"] != fold_fingerprint(backbone, cfg):
+            # the cached fold is of other weights (a submodule's load_state_dict, an in-place edit, .to(device)): redo it
+            fold = backbone._eval_fold = fold_eval_bn(backbone, cfg)
+        elif fold is None:
+            fold = fold_eval_bn(backbone, cfg)
     for b in cfg.blocks:
         m = _blk(backbone, b.index)
         ho, wo = b.out_size(h), b.out_size(w)

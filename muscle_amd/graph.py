@@ -50,8 +50,22 @@ class GraphedStep:
     def _body(self, batch):
         return mcl_step(self.model, self.opt, batch, self.ep, valid_channel=batch["label"].float().sum())
 
+    def close(self):
+        """Hand the optimizer back to host-side scalars (after the last replay: e.g. before the ep >= 8 iterations, which
+        run through mcl_step).  Also what leaving a `with GraphedStep(...) as step:` block does."""
+        self.opt.use_device_scalars(False)
+        self.graph = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __call__(self, batch: Dict[str, torch.Tensor]):
         self.calls += 1
+        self.opt.sync_lr()                          # an lr scheduler may have stepped since the last call
         if self.graph is None and self.calls <= self.warmup:
             return self._body(batch)
         if self.graph is None:

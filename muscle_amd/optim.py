@@ -153,15 +153,29 @@ class FusedAdam(torch.optim.Optimizer):
             ps, offs, sizes, steps = group["params"], group["_offs"], group["_sizes"], group["_steps"]
             arena, m, v = group["_arena"], group["_m"], group["_v"]
             dyn, touched = None, []
-            if not self._device_scalars:
+            use_dev = self._device_scalars
+            capturing = torch.cuda.is_current_stream_capturing()
+            if not use_dev:
                 group.pop("_dyn", None)          # a later device-scalar step re-seeds its count from the host's
             else:
                 live = [steps[q] for q, p in enumerate(ps) if p.grad is not None]
                 if not live:
                     continue
                 if min(live) != max(live):
-                    raise RuntimeError("FusedAdam device scalars need one step count for all parameters with gradients")
+                    # e.g. phase 2 of the MCL step never gives fc.weight a gradient, so from the first ep >= 8 iteration
+                    # on its count trails the others.  One device-side count cannot express that: an eager step falls
+                    # back to the host-side scalars of each run (exactly torch.optim.Adam); a capture cannot.
+                    if capturing:
+                        raise RuntimeError("FusedAdam device scalars need one step count for all parameters with gradients "
+                                           "to be captured into a graph")
+                    use_dev = False
+            if use_dev:
                 st = self._dev_state(group, live[0])
+                if not capturing:
+                    # an eager step knows the truth on the host: the count (replays and host-scalar steps may have
+                    # moved it) and the scheduler's current lr
+                    st["t"].fill_(float(live[0]))
+                    st["lr"].fill_(float(group["lr"]))
                 # same expressions as the host path (double, then rounded to float by the kernel argument)
                 st["t"].add_(1.0)
                 st["dyn"][0] = st["lr"]

@@ -769,6 +769,12 @@ def main_fullsize(src, tree):
     gen_forward_eval(src, "efficientnet-b7", 2, 448, 448, 33, "forward_b7_eval_448.npz")
 
 
+def main_config2(src, tree):
+    """BASELINE.json configs[1]'s workload shape (B0 at 448x448; the batch is 4 of the 16 rows so the fixture stays small):
+    the reference's own loop body, epoch-4 gates."""
+    gen_step(src, tree, "efficientnet-b0", 4, 448, 224, 4, 5, "step_b0_448_ep4.npz", cam_stride=16)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -793,12 +799,16 @@ def main():
     gen_irn_units(src)
     gen_eval_units(src)
     main_fullsize(src, tree)
+    main_config2(src, tree)
     gen_input_units(src)
 
 
 if __name__ == "__main__":
     if "--input" in sys.argv:
         gen_input_units(load_reference())
+    elif "--config2" in sys.argv:
+        torch.set_num_threads(8)
+        main_config2(load_reference(), train_script_ast())
     elif "--fullsize" in sys.argv:
         torch.set_num_threads(8)
         main_fullsize(load_reference(), train_script_ast())

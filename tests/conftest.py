@@ -10,6 +10,42 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "both_arith: golden / oracle parity test that runs in both GEMM arithmetics by default "
+                                       "(exact-fp32 MFMA and the split-bf16 mode of mx_set_gemm_mode(1))")
+
+
+def pytest_addoption(parser):
+    parser.addoption("--arith", default=os.environ.get("MUSCLE_TEST_ARITH", "marked"),
+                     choices=["marked", "fp32", "split", "both"],
+                     help="GEMM arithmetic of the GPU tests: 'marked' (default) = fp32 everywhere + split for the tests marked "
+                          "both_arith; 'fp32' / 'split' = every test in that mode only; 'both' = every test in both modes")
+
+
+# Every GPU test takes this (autouse) fixture.  Its parameter is the mode handed to muscle_amd.set_gemm_mode() for the
+# duration of the test: 0 = exact-fp32 MFMA, 1 = the split arithmetic for the MFMA-bound shapes.
+@pytest.fixture(autouse=True)
+def gemm_arith(request):
+    mode = getattr(request, "param", 0)
+    if not mode or "gpu" not in request.keywords or not _has_gpu():
+        yield 0
+        return
+    import muscle_amd
+    muscle_amd.set_gemm_mode(mode)
+    try:
+        yield mode
+    finally:
+        muscle_amd.set_gemm_mode(0)
+
+
+def pytest_generate_tests(metafunc):
+    if "gemm_arith" not in metafunc.fixturenames or metafunc.definition.get_closest_marker("gpu") is None:
+        return
+    opt = metafunc.config.getoption("--arith")
+    marked = metafunc.definition.get_closest_marker("both_arith") is not None
+    if opt == "both" or (opt == "marked" and marked):
+        metafunc.parametrize("gemm_arith", [0, 1], indirect=True, ids=["fp32", "split"])
+    elif opt == "split":
+        metafunc.parametrize("gemm_arith", [1], indirect=True, ids=["split"])
 
 
 def _has_gpu():

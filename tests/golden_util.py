@@ -58,3 +58,14 @@ def geometry_from_draws(coord1, draws):
 def rel_err(a, b):
     a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+_CACHE = {}
+
+
+def cached(key, fn):
+    """One CPU oracle run per (test, case) and process: the tests marked `both_arith` run twice (tests/conftest.py), and
+    the fp32 + fp64 oracle passes (tens of seconds on the host cores) do not depend on the GPU's GEMM arithmetic."""
+    if key not in _CACHE:
+        _CACHE[key] = fn()
+    return _CACHE[key]

@@ -14,7 +14,7 @@ from muscle_amd import synth
 from muscle_amd.arch import net_cfg
 from test_gpu_model import build, close, DEV, T
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.both_arith]
 
 
 def _calibrate(model, cfg, x, n):

@@ -9,7 +9,7 @@ import golden_util as gu
 from muscle_amd import synth
 from muscle_amd.arch import net_cfg
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.both_arith]
 
 
 def _build(name, seed, dev):
@@ -35,19 +35,23 @@ def test_backbone_forward_backward(name, n, size, training):
     cfg, sd, bb = _build(name, seed, dev)
     x = torch.from_numpy(synth.normal(seed, "x", (n, 3, size, size)).astype(np.float32))
     du = gu.drop_draws(cfg, n, 5)
-    net = O.OracleNet(name, sd)
-    net.train() if training else net.eval()
-    feats = net.features(x, du)
-    taps = cfg.taps
-    probes = {i: torch.from_numpy(synth.normal(seed, f"probe{i}", tuple(feats[i].shape)).astype(np.float32))
-              for i in (taps[0], taps[2], taps[4], taps[6])}
-    loss = sum((feats[i] * p).sum() for i, p in probes.items())
-    loss.backward()
-    # fp64 oracle: tells round-off-only gradients (BN-cancelled parameters) from real ones
-    net64 = O.OracleNet(name, sd, dtype=torch.float64)
-    net64.train() if training else net64.eval()
-    f64 = net64.features(x.double(), du)
-    sum((f64[i] * p.double()).sum() for i, p in probes.items()).backward()
+    def oracle():
+        net = O.OracleNet(name, sd)
+        net.train() if training else net.eval()
+        feats = net.features(x, du)
+        taps = cfg.taps
+        probes = {i: torch.from_numpy(synth.normal(seed, f"probe{i}", tuple(feats[i].shape)).astype(np.float32))
+                  for i in (taps[0], taps[2], taps[4], taps[6])}
+        loss = sum((feats[i] * p).sum() for i, p in probes.items())
+        loss.backward()
+        # fp64 oracle: tells round-off-only gradients (BN-cancelled parameters) from real ones
+        net64 = O.OracleNet(name, sd, dtype=torch.float64)
+        net64.train() if training else net64.eval()
+        f64 = net64.features(x.double(), du)
+        sum((f64[i] * p.double()).sum() for i, p in probes.items()).backward()
+        return net, [f.detach() for f in feats], probes, net64
+
+    net, feats, probes, net64 = gu.cached(("backbone", name, n, size, training), oracle)
 
     tape = engine.backbone_forward(bb, cfg, x.to(dev), training, {k: v.to(dev) for k, v in du.items()})
     for i, f in enumerate(feats):

@@ -12,7 +12,7 @@ from muscle_amd.arch import net_cfg
 from test_gpu_model import close, DEV, T, check_grads
 from test_oracle_golden import field_unit_inputs
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.both_arith]
 
 
 def build_dec(name, seed):
@@ -30,14 +30,18 @@ def test_seg_forward_backward_vs_oracle():
     cfg, sd, model = build_dec(name, seed)
     x = T(synth.normal(seed, "x", (n, 3, size, size)).astype(np.float32))
     du = gu.drop_draws(cfg, n, 5)
-    nets = []
-    for dt in (torch.float32, torch.float64):
-        net = O.OracleDecNet(name, sd, dtype=dt)
-        net.train()
-        outs = net.forward_seg(x.to(dt), du)
-        probes = [T(synth.normal(seed, f"probe{i}", tuple(o.shape)).astype(np.float32)).to(dt) for i, o in enumerate(outs)]
-        sum((o * p).sum() for o, p in zip(outs, probes)).backward()
-        nets.append((net, outs))
+    def oracle():
+        nets = []
+        for dt in (torch.float32, torch.float64):
+            net = O.OracleDecNet(name, sd, dtype=dt)
+            net.train()
+            outs = net.forward_seg(x.to(dt), du)
+            probes = [T(synth.normal(seed, f"probe{i}", tuple(o.shape)).astype(np.float32)).to(dt) for i, o in enumerate(outs)]
+            sum((o * p).sum() for o, p in zip(outs, probes)).backward()
+            nets.append((net, [o.detach() for o in outs]))
+        return nets
+
+    nets = gu.cached(("seg", name, n, size, seed), oracle)
     (net32, outs32), (net64, _) = nets
     model.train()
     got = model(x.to(DEV), cam="seg", drop_u={k: v.to(DEV) for k, v in du.items()})

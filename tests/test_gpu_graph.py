@@ -110,6 +110,59 @@ def test_graphed_step_refuses_phase2_and_shape_change():
         step(batches(3, 64, 1, 2)[0])
 
 
+@pytest.mark.parametrize("close_first", [False, True])
+def test_graphed_phase1_then_eager_phase2(close_first):
+    """The documented flow: GraphedStep for the ep < 8 iterations, mcl_step from ep 8 on with the SAME
+    optimizer.  Phase 2 runs in 'pix' mode, which never gives fc.weight a gradient, so from the second ep-8 iteration on
+    the live parameters no longer share one step count: an eager step must then take torch.optim.Adam's per-parameter
+    scalars on the host instead of raising (round-2 advisor finding), whether or not GraphedStep.close() was called."""
+    import muscle_amd
+    name, n, size, view, seed = "efficientnet-b0", 4, 64, 32, 5
+    full = {k: T(v).to(DEV) for k, v in synth.synth_batch(n, size, view, seed).items()}
+    ref, gra = build(name, seed), build(name, seed)
+    o_ref = muscle_amd.FusedAdam(ref.parameters(), lr=1e-4, weight_decay=5e-5)
+    o_gra = muscle_amd.FusedAdam(gra.parameters(), lr=1e-4, weight_decay=5e-5)
+    torch.manual_seed(7)
+    for _ in range(3):
+        muscle_amd.mcl_step(ref, o_ref, full, 7)
+    for _ in range(2):
+        muscle_amd.mcl_step(ref, o_ref, full, 8)
+    step = muscle_amd.GraphedStep(gra, o_gra, 7, warmup=1)
+    torch.manual_seed(7)
+    for _ in range(3):
+        step(full)
+    assert step.replays == 2
+    if close_first:
+        step.close()
+    for _ in range(2):
+        out = muscle_amd.mcl_step(gra, o_gra, full, 8)          # second iteration: fc.weight is one step behind
+    assert all(np.isfinite(float(v)) for v in out.values())
+    sa, sb = o_ref.state_dict()["state"], o_gra.state_dict()["state"]
+    assert {k: v["step"] for k, v in sa.items()} == {k: v["step"] for k, v in sb.items()}
+    assert len({v["step"] for v in sb.values()}) == 2           # fc.weight: 4 steps, everything else live: 5
+    pr, pg = dict(ref.named_parameters()), dict(gra.named_parameters())
+    num = sum(float((pr[k].detach() - pg[k].detach()).double().pow(2).sum()) for k in pr)
+    den = sum(float(pr[k].detach().double().pow(2).sum()) for k in pr)
+    assert (num / den) ** 0.5 <= 1e-4
+
+
+def test_graphed_step_follows_the_lr_scheduler_in_warmup():
+    """A second GraphedStep on an optimizer whose device scalars already exist must run its eager warm-up steps with the
+    CURRENT lr (round-2 advisor finding: the device-side lr was only refreshed right before a replay)."""
+    import muscle_amd
+    m = build("efficientnet-b0", 5)
+    o = muscle_amd.FusedAdam(m.parameters(), lr=1e-4)
+    bs = batches(2, 64, 3, 1)
+    s1 = muscle_amd.GraphedStep(m, o, 0, warmup=1)
+    s1(bs[0]); s1(bs[1])
+    o.param_groups[0]["lr"] = 0.0                  # the scheduler's product at the epoch boundary
+    before = torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone()
+    s2 = muscle_amd.GraphedStep(m, o, 4, warmup=1)
+    s2(bs[2])                                      # eager warm-up step of the new gate: lr 0 -> parameters must not move
+    after = torch.cat([p.detach().reshape(-1) for p in m.parameters()])
+    assert torch.equal(before, after)
+
+
 def test_repeated_steps_fit_a_fixed_batch():
     """Sanity of the whole loop (forward, losses, backward, side-stream weight gradients, fused Adam) beyond one step: on a
     fixed batch the classification losses must fall steadily - a wrong-signed or misrouted gradient anywhere shows here."""

@@ -9,7 +9,7 @@ import torch
 from muscle_amd import synth
 from muscle_amd.arch import net_cfg
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.both_arith]
 DEV = "cuda:0"
 T = lambda a: torch.from_numpy(np.asarray(a))  # noqa: E731
 

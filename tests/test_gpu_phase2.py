@@ -9,7 +9,7 @@ from muscle_amd import synth
 from muscle_amd.arch import net_cfg
 from test_gpu_model import build, close, DEV, T, U, SEED
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.both_arith]
 
 
 def test_maxnorm_golden_and_backward():

@@ -6,7 +6,10 @@
 
 One "step" = one iteration of the train_mcl.py loop body (muscle_amd.mcl_step) on a synthetic batch that is
 already resident in HBM.  Rank 0 prints ONE JSON line.  Extra objects:
-  roofline     — dominant kernel family (fp32-MFMA pointwise GEMMs), timed live with HIP events on the launch stream
+  roofline     — dominant kernel family (the pointwise-conv GEMMs), timed live with HIP events on the launch stream; every
+                 launch is priced against the peak of the pipe it ran on (fp32 MFMA, or bf16 MFMA / 6 for split arithmetic)
+  fp32_mfma / split_mfma — the same K steps in the OTHER GEMM arithmetic (config.arithmetic names the one `value` was measured in)
+  configs      — short runs of BASELINE.json configs[1] (B0 / 448 / batch 16) and of step-full (epoch-12 gates), N=1 only
   cpu_baseline — the CPU oracle (oracle/mcl_oracle.py, a port of the reference) timed on this host, N=1 only
 """
 import argparse
@@ -24,10 +27,19 @@ from muscle_amd import arch, synth  # noqa: E402
 
 GEMM_CALLS = ("mx_pw_fwd", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile")
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # same guide, dense bf16 MFMA (no sparsity)
+SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0    # split arithmetic: six bf16 products per fp32 product -> 416.7 fp32-equivalent
+ARITH_MODE = {"fp32": 0, "split": 1}
+ARITH_TEXT = {
+    "fp32": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) for every GEMM",
+    "split": "fp32 operands split exactly into three bf16 terms (x = h + m + l), six of the nine cross products on "
+             "v_mfma_f32_32x32x16_bf16 with fp32 accumulation, for the MFMA-bound forward / data-gradient (K >= 128) and "
+             "weight-gradient GEMMs; the others on exact-fp32 MFMA; error vs fp64 equal to the fp32-MFMA kernels' (DESIGN.md section 3)"}
 HBM_PEAK_GBPS = 8000.0                # same guide: HBM3E spec; 6290 GB/s is what a float4 copy achieves
 # whole-step ceilings per GPU for B7 / 448x448 step-A: exact-fp32 MFMA and HBM (minimum-materialisation schedule)
 STEP_CEILING_MFMA_IMGS = 600.0
 STEP_CEILING_HBM_IMGS = 974.0
+DEFAULT_ARITH = "split"
 
 
 def make_batch(n, size, view, seed, dev):
@@ -48,7 +60,7 @@ class GemmTimer:
     """HIP events around every pointwise-GEMM launch, recorded on the stream the kernel is enqueued on."""
 
     def __init__(self):
-        self.pairs = []
+        self.pairs = []       # (event, event, flop of the launch, ran in split arithmetic?)
         self.dw = []          # (event, event, algorithmic bytes) of the fused depthwise backward: the slowest HBM-bound kernel
         self.on = False
 
@@ -57,13 +69,26 @@ class GemmTimer:
         inner = _lib.call
         me = self
 
+        def shape_of(name, a):
+            """(flop, kind, M, N, K) of a GEMM entry point from its argument list (include/muscle_hip.h)."""
+            if name == "mx_pw_fwd":
+                M, K, N = a[8], a[9], a[10]
+                return 2.0 * M * K * N, 0, M, N, K
+            if name == "mx_pw_dgrad":
+                M, K, N = a[3], a[4], a[5]
+                return 2.0 * M * K * N, -1, M, N, K             # NN kernel: never split
+            R, Co, Ci = a[8], a[9], a[10]
+            return 2.0 * R * Co * Ci, (1 if name == "mx_pw_wgrad_tile" else -1), Co, Ci, R
+
         def timed(name, *a):
             if me.on and name in GEMM_CALLS:
+                flop, kind, M, N, K = shape_of(name, a)
+                split = kind >= 0 and bool(_lib.lib().mx_gemm_uses_split(kind, M, N, K))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 inner(name, *a)
                 e1.record()
-                me.pairs.append((e0, e1))
+                me.pairs.append((e0, e1, flop, split))
             elif me.on and name == "mx_dwconv_bwd_fused":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -81,7 +106,16 @@ class GemmTimer:
                 mod.call = timed
 
     def total_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.pairs), len(self.pairs)
+        return sum(a.elapsed_time(b) for a, b, _, _ in self.pairs), len(self.pairs)
+
+    def blended_peak(self):
+        """(peak TFLOP/s the timed launches could reach if each ran at the peak of ITS pipe, share of the flop that ran split)."""
+        f_all = sum(f for _, _, f, _ in self.pairs)
+        f_split = sum(f for _, _, f, sp in self.pairs if sp)
+        if f_all <= 0:
+            return MFMA_F32_PEAK_TFLOPS, 0.0
+        t_ideal = f_split / SPLIT_PEAK_TFLOPS + (f_all - f_split) / MFMA_F32_PEAK_TFLOPS
+        return f_all / t_ideal, f_split / f_all
 
     def dw_summary(self):
         """Per kernel size of the fused depthwise backward: launches, ms, GB/s of its algorithmic 4 passes."""
@@ -136,6 +170,42 @@ def cpu_baseline(model_name, size, view, ep, seconds_budget=25.0):
                         "sample": f"{cnt0} timed steps (2 warm-up), efficientnet-b0 224x224, batch {n}, {sec0:.3f} s/step"}}
 
 
+def _calibrate_bn(model, x):
+    """phase 2 runs in eval mode (train_mcl.py:196): give the random-init model BatchNorm running statistics of its own
+    activations (one train-mode pass at momentum 1.0), as SURVEY 8(c) prescribes for eval-mode work"""
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    saved = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        model(x, cam="pix")
+    for m, mo in zip(bns, saved):
+        m.momentum = mo
+
+
+def short_run(model_name, batch_n, size, epoch, warm, steps, dev, seed):
+    """A short eager run of another BASELINE.json configuration on this GPU (same code path as the headline measurement),
+    so that its figure is driver-timed too."""
+    import muscle_amd
+    torch.manual_seed(0)
+    model = muscle_amd.MuSCLe(21, model_name, layers=3, last_pooling=False).to(dev)
+    opt = muscle_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=5e-5)
+    batch = make_batch(batch_n, size, size // 2, seed, dev)
+    if epoch >= 8:
+        _calibrate_bn(model, batch["view1"])
+    for _ in range(warm):
+        muscle_amd.mcl_step(model, opt, batch, epoch, valid_channel=batch["label"].sum())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        muscle_amd.mcl_step(model, opt, batch, epoch, valid_channel=batch["label"].sum())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": batch_n * steps / dt, "unit": "images/sec", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warm,
+            "workload": f"{model_name} {size}x{size} batch {batch_n}, epoch-{epoch} gates"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -146,7 +216,11 @@ def main():
     ap.add_argument("--size", type=int, default=448)
     ap.add_argument("--epoch", type=int, default=4, help="epoch gate semantics of train_mcl.py (4: cls+ER+IMC)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-split", action="store_true", help="skip the extra K steps in split-MFMA arithmetic (reported as split_mfma)")
+    ap.add_argument("--arith", choices=["split", "fp32"], default=os.environ.get("MUSCLE_BENCH_ARITH", DEFAULT_ARITH),
+                    help="GEMM arithmetic of the timed steps (config.arithmetic); the other one is timed as well and reported beside it")
+    ap.add_argument("--no-split", "--no-other-arith", dest="no_other", action="store_true",
+                    help="skip the extra K steps in the other GEMM arithmetic")
+    ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs[1] and step-full")
     ap.add_argument("--graph", action="store_true",
                     help="timed steps replay phase 1 from a captured hipGraph (muscle_amd.GraphedStep; one GPU, epoch < 8).  Not "
                          "the default: measured on MI355X the replay saves 0.5 ms of 136 on B7 but serialises the weight-gradient "
@@ -183,13 +257,16 @@ def main():
     opt = muscle_amd.FusedAdam(model.parameters(), lr=1e-4, weight_decay=5e-5)
     view = a.size // 2
     batch = make_batch(a.batch, a.size, view, 1000 + rank, dev)
-    vc = int(batch["label"].sum().item())
     hook = GradAverager().attach(model) if world > 1 else None     # chunks go out as backward fills the arena
     timer = GemmTimer()
     timer.install()
+    other = "fp32" if a.arith == "split" else "split"
+    muscle_amd.set_gemm_mode(ARITH_MODE[a.arith])
 
     def step():
-        return muscle_amd.mcl_step(model, opt, batch, a.epoch, valid_channel=vc, grad_hook=hook)
+        # ER's top-k count int(0.2 * label.sum() * H * W) (train_mcl.py:178,188) is taken INSIDE the step, on the device (the
+        # reference reads it back every iteration; a count precomputed outside the timed region would be work skipped)
+        return muscle_amd.mcl_step(model, opt, batch, a.epoch, valid_channel=batch["label"].sum(), grad_hook=hook)
 
     if a.graph and (world > 1 or a.epoch >= 8):
         raise SystemExit("--graph covers phase 1 on one GPU (epoch < 8)")
@@ -201,17 +278,7 @@ def main():
         step = lambda: gstep(batch)                # noqa: E731  (copies the batch into the static buffers, replays)
 
     if a.epoch >= 8:
-        # phase 2 runs in eval mode (train_mcl.py:196): give the random-init model BatchNorm running statistics of its
-        # own activations (one train-mode pass at momentum 1.0), as SURVEY 8(c) prescribes for eval-mode work
-        bns = [m for m in model.modules() if isinstance(m, torch.nn.BatchNorm2d)]
-        saved = [m.momentum for m in bns]
-        for m in bns:
-            m.momentum = 1.0
-        model.train()
-        with torch.no_grad():
-            model(batch["view1"], cam="pix")
-        for m, mo in zip(bns, saved):
-            m.momentum = mo
+        _calibrate_bn(model, batch["view1"])
     for _ in range(a.warmup):
         step()
 
@@ -244,12 +311,10 @@ def main():
     inst_dt = time.perf_counter() - t1
     timer.on = False
     engine.WGRAD_SIDE_STREAM = overlap
-    # Reported beside the contract value, never as it: the same K steps with the GEMMs of the MFMA-bound layers (forward,
-    # data gradient, weight gradient) in "split" arithmetic (fp32 operands split exactly into three bf16 terms, six products on the
-    # bf16 matrix pipe, fp32 accumulation; include/muscle_hip.h mx_set_gemm_mode)
-    split = None
-    if not a.no_split:
-        muscle_amd.set_gemm_mode(1)
+    # Beside the contract value: the same K steps in the OTHER GEMM arithmetic (include/muscle_hip.h mx_set_gemm_mode)
+    beside = None
+    if not a.no_other:
+        muscle_amd.set_gemm_mode(ARITH_MODE[other])
         eager_step()
         barrier()
         t2 = time.perf_counter()
@@ -257,15 +322,13 @@ def main():
             eager_step()
         barrier()
         dts = time.perf_counter() - t2
-        muscle_amd.set_gemm_mode(0)
+        muscle_amd.set_gemm_mode(ARITH_MODE[a.arith])
         if world > 1:
             t = torch.tensor([dts], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t)
-        split = {"value": a.batch * world * a.steps / dts, "unit": "images/sec", "ms_per_step": dts / a.steps * 1e3,
-                 "arithmetic": "opt-in: the MFMA-bound fwd / dgrad (K >= 128) and weight-gradient GEMMs on v_mfma_f32_32x32x16_bf16, fp32 "
-                               "operands as h+m+l bf16 terms (exact split), 6 of 9 products, fp32 accumulate; error vs fp64 equal to "
-                               "the fp32-MFMA kernels'"}
+        beside = {"value": a.batch * world * a.steps / dts, "unit": "images/sec", "ms_per_step": dts / a.steps * 1e3,
+                  "arithmetic": ARITH_TEXT[other]}
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -287,6 +350,7 @@ def main():
         flops_img += 2 * 2 * mv["pointwise"] + 4 * mv["pointwise"] + 2 * 2 * stem_v + 2 * stem_v
     flops = flops_img * a.batch * inst_steps
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
+    peak, split_share = timer.blended_peak()
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (a.model, a.size, a.batch, full) == ("efficientnet-b7", 448, 32, False):
@@ -304,16 +368,25 @@ def main():
                                f"MuSCLe({a.model}, last_pooling=False, 21 classes), random-init weights",
                    "per_gpu_batch": a.batch, "global_batch": a.batch * world, "image": f"{a.size}x{a.size}",
                    "parallelism": f"dp{world}" if world > 1 else "single", "optimizer": "Adam(lr=1e-4, wd=5e-5) fused",
-                   "launch": ("hipGraph replay" if a.graph else "eager") + (", weight-gradient GEMMs on a second stream" if overlap else "")},
+                   "launch": ("hipGraph replay" if a.graph else "eager") + (", weight-gradient GEMMs on a second stream" if overlap else ""),
+                   "arithmetic": f"{a.arith}: {ARITH_TEXT[a.arith]}"},
         "losses": {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in out.items()},
-        "roofline": {"bound": "mfma", "kernel": "gemm_nt_kernel<*> / gemm_kernel<*> (exact-fp32 MFMA pointwise convs: fwd + dgrad on v_mfma_f32_16x16x4_f32, wgrad on 32x32x2; stem)",
-                     "achieved": achieved, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": (achieved / MFMA_F32_PEAK_TFLOPS) if achieved else None, "traffic": traffic,
+        "roofline": {"bound": "mfma",
+                     "kernel": "gemm_nt_kernel<*> / gemm_nt_split_kernel<*> / wgrad_tile_kernel<*> / wgrad_split_kernel<*> / wgrad_small_kernel<*> / "
+                               "gemm_kernel<*> (the pointwise-conv GEMMs: forward, data gradient, weight gradient; stem)",
+                     "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": (achieved / peak) if achieved else None, "traffic": traffic,
+                     "peak_is": f"flop-weighted over the timed launches: {split_share:.3f} of the flop ran in split arithmetic on the bf16 "
+                                f"pipe (peak {MFMA_BF16_PEAK_TFLOPS:.0f} / 6 = {SPLIT_PEAK_TFLOPS:.1f} TFLOP/s fp32-equivalent), the rest on "
+                                f"exact-fp32 MFMA (peak {MFMA_F32_PEAK_TFLOPS})",
+                     "flop_share_split": split_share,
                      "measured_over": f"{inst_steps} eager steps right after the timed region (HIP events per launch, weight-gradient "
                                       f"side stream off; {inst_dt / inst_steps * 1e3:.1f} ms/step in that mode)",
                      "launches_per_step": gemm_launches // max(inst_steps, 1),
                      "avg_launch_us": gemm_ms * 1e3 / max(gemm_launches, 1),
                      "time_share_of_step": gemm_ms * 1e-3 / inst_dt,
+                     "gemm_ms_per_step": gemm_ms / max(inst_steps, 1),
+                     "non_gemm_ms_per_step": (inst_dt * 1e3 - gemm_ms) / max(inst_steps, 1),
                      "algorithmic_gflop_per_image": flops_img / 1e9},
     }
     if (a.model, a.size, full) == ("efficientnet-b7", 448, False):
@@ -321,8 +394,8 @@ def main():
         per_gpu = imgs / dt / world
         res["roofline"]["step_frac_mfma"] = per_gpu / STEP_CEILING_MFMA_IMGS
         res["roofline"]["step_frac_hbm"] = per_gpu / STEP_CEILING_HBM_IMGS
-    if split is not None:
-        res["split_mfma"] = split
+    if beside is not None:
+        res["fp32_mfma" if other == "fp32" else "split_mfma"] = beside
     dws = timer.dw_summary()
     if dws:
         worst = min(dws.items(), key=lambda kv: kv[1]["GBps"])
@@ -331,6 +404,14 @@ def main():
                                          "frac": worst[1]["GBps"] / HBM_PEAK_GBPS,
                                          "ms_per_step": worst[1]["ms"] / max(inst_steps, 1),
                                          "all": {k: {"GBps": round(v["GBps"], 1), "ms_per_step": round(v["ms"] / max(inst_steps, 1), 3)} for k, v in dws.items()}}
+    if world == 1 and not a.no_configs and (a.model, a.size, a.batch, full) == ("efficientnet-b7", 448, 32, False):
+        del model, opt, out
+        torch.cuda.empty_cache()
+        res["configs"] = {
+            "config2": short_run("efficientnet-b0", 16, 448, a.epoch, 5, 30, dev, 2000),       # BASELINE.json configs[1]
+            "stepfull": short_run("efficientnet-b7", 32, 448, 12, 1, 3, dev, 1000),             # epoch >= 12 gates, headline model
+        }
+    muscle_amd.set_gemm_mode(0)
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.size, view, a.epoch)
     print(json.dumps(res))

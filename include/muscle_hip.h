@@ -57,6 +57,9 @@ int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_s
  * 2: split mode for every NT GEMM (tests). */
 int mx_set_gemm_mode(int mode);
 int mx_get_gemm_mode(void);
+/* 1 if, in the current mode, this GEMM runs in split arithmetic on the bf16 pipe (kind 0: mx_pw_fwd / data gradient
+ * C[M,N] = A[M,K] W[N,K]^T; kind 1: weight gradient dW[M=Co,N=Ci] over K=R rows), else 0 - for measurement code. */
+int mx_gemm_uses_split(int kind, int M, int N, int K);
 
 /* dst[cols,rows] = src[rows,cols]^T (conv weights): the data gradient runs as mx_pw_fwd against the transposed weight. */
 int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream);

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
       return;
     }
     const long plane = (long)gridDim.z * g.C;
-    if (owner) st4(scratch + blockIdx.x * plane + (long)sample * g.C + 4 * c4, s0);
+    if (owner) mx_st4_wt(scratch + blockIdx.x * plane + (long)sample * g.C + 4 * c4, s0);
     if (!mx_last_arriver(counters + sample * gridDim.y + blockIdx.y, gridDim.x, &last_flag)) return;
     if (owner) st4(o, ordered_sum4(scratch + (long)sample * g.C + 4 * c4, gridDim.x, plane));
   }
@@ -309,7 +309,8 @@ __global__ __launch_bounds__(256) void se_bn1_pool_kernel(const float* G, const 
     for (int i = 0; i < 5; ++i) {
       float4 s0 = sm[i][tid];
       for (int k = 1; k < g.rpp; ++k) { float4 t0 = sm[i][tid + k * g.tcols]; s0.x += t0.x; s0.y += t0.y; s0.z += t0.z; s0.w += t0.w; }
-      st4(dst + i * plane + off, s0);
+      if (gridDim.x == 1) st4(dst + i * plane + off, s0);
+      else mx_st4_wt(dst + i * plane + off, s0);
     }
   }
   if (gridDim.x == 1) return;
@@ -398,14 +399,28 @@ __device__ __forceinline__ void bn_fwd_finalize_one(int c, double st0, double st
   rstd_out[c] = rstd;
 }
 
+// second level of the two-level reduction: 32 channels x 8 slice lanes per workgroup (lane l adds slices l, l+8, ...), the 8
+// lane sums are added in lane order
+__device__ __forceinline__ bool slices_sum(const double* acc, int slices, int C, double& s0, double& s1) {
+  __shared__ double sh[2][8][32];
+  const int cl = threadIdx.x & 31, sl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  s0 = s1 = 0.0;
+  if (c < C)
+    for (int i = sl; i < slices; i += 8) { s0 += acc[(long)i * 2 * C + c]; s1 += acc[(long)i * 2 * C + C + c]; }
+  sh[0][sl][cl] = s0; sh[1][sl][cl] = s1;
+  __syncthreads();
+  if (sl != 0 || c >= C) return false;
+  for (int i = 1; i < 8; ++i) { s0 += sh[0][i][cl]; s1 += sh[1][i][cl]; }
+  return true;
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int slices, int C, double count, const float* gamma,
                                    const float* beta, float* rmean, float* rvar, float momentum, float eps, int training,
                                    float* scale, float* shift, float* mean_out, float* rstd_out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double st0 = 0.0, st1 = 0.0;
-  if (training)
-    for (int i = 0; i < slices; ++i) { st0 += acc[(long)i * 2 * C + c]; st1 += acc[(long)i * 2 * C + C + c]; }
+  double st0, st1;
+  if (!slices_sum(acc, training ? slices : 0, C, st0, st1)) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   bn_fwd_finalize_one(c, st0, st1, count, gamma, beta, rmean, rvar, momentum, eps, training, scale, shift, mean_out, rstd_out);
 }
 
@@ -431,10 +446,9 @@ __device__ __forceinline__ void bn_bwd_finalize_one(int c, double sg, double sgx
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc, int slices, int C, double count, const float* gamma,
                                        const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,
                                        float* c1, float* c2, float* c3) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s0 = 0.0, s1 = 0.0;
-  for (int i = 0; i < slices; ++i) { s0 += acc[(long)i * 2 * C + c]; s1 += acc[(long)i * 2 * C + C + c]; }
+  double s0, s1;
+  if (!slices_sum(acc, slices, C, s0, s1)) return;
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31);
   bn_bwd_finalize_one(c, s0, s1, count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3);
 }
 
@@ -591,7 +605,7 @@ int mx_bn_finalize(const float* part, int P, int C, double count, const float* g
   }
   int slices = 0;
   if (training) slices = launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, slices, C, count, gamma,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, acc, slices, C, count, gamma,
                      beta, running_mean, running_var, momentum, eps, training, scale, shift, mean, rstd);
   MX_LAUNCH_CHECK();
   return MX_OK;
@@ -631,7 +645,7 @@ int mx_bn_bwd_finalize(const float* part, int P, int C, double count, const floa
     return MX_OK;
   }
   const int slices = launch_parts_reduce(part, P, C, acc, (hipStream_t)stream);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, acc, slices, C, count, gamma,
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, acc, slices, C, count, gamma,
                      mean, rstd, training, dgamma, dbeta, c1, c2, c3);
   MX_LAUNCH_CHECK();
   return MX_OK;

@@ -62,28 +62,42 @@ __device__ __forceinline__ float wave_min(float v) {
 
 // ---------------------------------------------------------------------------
 // Ordered cross-workgroup reductions without a second launch ("last arriver finishes").
-// Every workgroup of a group stores its partial result to global scratch, then calls mx_last_arriver(): exactly one
-// caller per group - the one that arrives last - gets true; it then reads ALL partials of the group and adds them in
-// index order, so the result does not depend on which workgroup came last (fp32 atomics gave sums whose last bits
-// moved from run to run).  `counter` must be 0 before the launch and is 0 again afterwards (the last arriver resets it).
+// Every workgroup of a group stores its partial result to global scratch with mx_st_wt / mx_st4_wt, then calls
+// mx_last_arriver(): exactly one caller per group - the one that arrives last - gets true; it then reads ALL partials of
+// the group (plain loads) and adds them in index order, so the result does not depend on which workgroup came last
+// (fp32 atomics gave sums whose last bits moved from run to run).
+// Visibility on gfx950 (8 XCDs with private L2s, per-CU L1s never refreshed by other CUs; cdna_hip_programming.md,
+// Guideline 16, counter form): the partials are stored WRITE-THROUGH (sc1), every storing wave drains its stores
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, ONE lane adds to the counter with an agent-scope atomic, and the
+// lane that sees the last ticket runs ONE agent-scope acquire (drops this CU's stale L1 lines) before the workgroup's plain
+// loads.  No release fence anywhere: __threadfence() in every thread (buffer_wbl2 + buffer_inv per wave) made these
+// HBM-bound reductions 3x slower.
+// `counter` must be 0 before the launch and is 0 again afterwards (the last arriver resets it).
 // Scratch layout used by the entry points that take `ws`: [MX_WS_COUNTER_BYTES of counters][partials].
 // ---------------------------------------------------------------------------
 #define MX_WS_COUNTER_BYTES 65536
 #define MX_WS_COUNTERS (MX_WS_COUNTER_BYTES / 4)
 
+__device__ __forceinline__ void mx_st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mx_st4_wt(float* p, float4 v) {
+  mx_st_wt(p, v.x); mx_st_wt(p + 1, v.y); mx_st_wt(p + 2, v.z); mx_st_wt(p + 3, v.w);
+}
+
 __device__ __forceinline__ bool mx_last_arriver(unsigned* counter, unsigned total, unsigned* lds_flag) {
-  __threadfence();                    // release: this thread's partials are visible device-wide before the count moves
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave: its write-through partials have left the CU
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned prev = atomicAdd(counter, 1u);
+    const unsigned prev = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned last = (prev == total - 1u) ? 1u : 0u;
-    if (last) *counter = 0u;          // everyone has arrived: ready for the next launch
+    if (last) {
+      __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // everyone has arrived: ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate has completed before the barrier lets the others load
+    }
     *lds_flag = last;
   }
   __syncthreads();
-  const bool last = *lds_flag != 0u;
-  if (last) __threadfence();          // acquire: the other workgroups' partials
-  return last;
+  return *lds_flag != 0u;
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     }
     // the tiles of a sample are joined by the last workgroup to arrive, in tile order (no atomics: the squeeze, and with it
     // the whole eval forward, gives the same bits whatever the batch size and the run)
-    if (own) a.poolpart[((long)blockIdx.x * gridDim.z + n) * a.C + c0 + tid] = v;
+    if (own) mx_st_wt(a.poolpart + ((long)blockIdx.x * gridDim.z + n) * a.C + c0 + tid, v);
     if (!mx_last_arriver(a.counters + n * gridDim.y + blockIdx.y, gridDim.x, &last_flag)) return;
     const int cl = tid & 31, rl = tid >> 5;
     float t = 0.f;

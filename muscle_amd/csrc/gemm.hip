@@ -921,6 +921,11 @@ if (i < NB) put(st + 3 * PA_, PB_, woff[i], rb[i]);   // (weights split per work
 // 0 = fp32 MFMA everywhere (default, the parity mode of record); 1 = split mode for the MFMA-bound forward / data-gradient
 // shapes; 2 = split mode for every NT GEMM (tests).  Process-wide; MX_GEMM_SPLIT sets the initial value.
 static int g_gemm_mode = getenv("MX_GEMM_SPLIT") ? atoi(getenv("MX_GEMM_SPLIT")) : 0;
+// which forward / data-gradient GEMMs take the split-bf16 kernel: mode 2 all; mode 1 the MFMA-bound shapes only
+// (K and N large enough, <= 26 % padded columns)
+static bool nt_uses_split(int N, int K) {
+  return g_gemm_mode == 2 || (g_gemm_mode == 1 && K >= 128 && N >= 96 && (double)N / (64.0 * cdiv(N, 64)) >= 0.74);
+}
 
 template <int NJ>
 static void launch_nt_split_t(const GemmArgs& g, int batch, hipStream_t st) {
@@ -999,7 +1004,7 @@ static int pick_nt_cfg(int M, int N) {
 }
 
 static void dispatch_nt(const GemmArgs& g, int batch, hipStream_t st) {
-  if (g.a.mode != MX_BNBWD && (g_gemm_mode == 2 || (g_gemm_mode == 1 && g.K >= 128 && g.N >= 96 && (double)g.N / (64.0 * cdiv(g.N, 64)) >= 0.74))) {
+  if (g.a.mode != MX_BNBWD && nt_uses_split(g.N, g.K)) {
     launch_nt_split(g, batch, st);       // MFMA-bound shapes only: K and N large enough, <= 26 % padded columns
     return;
   }
@@ -1114,6 +1119,16 @@ int mx_set_gemm_mode(int mode) {
 }
 
 int mx_get_gemm_mode(void) { return g_gemm_mode; }
+
+bool mx_wgrad_uses_split(int R, int Co, int Ci);      // wgrad.hip
+
+// 1 when, in the current mode, the GEMM runs on the bf16 matrix pipe in split arithmetic (kind 0: mx_pw_fwd / the data
+// gradient as C[M,N] = A[M,K] W[N,K]^T; kind 1: the weight gradient dW[M=Co, N=Ci] over K = R rows), else 0.
+// For measurement code that prices each launch against the right peak (bench.py).
+int mx_gemm_uses_split(int kind, int M, int N, int K) {
+  if (kind == 0) return nt_uses_split(N, K) ? 1 : 0;
+  return mx_wgrad_uses_split(K, M, N) ? 1 : 0;
+}
 
 // number of partial-statistics rows mx_pw_fwd writes for an [M, N] output
 int mx_pw_fwd_parts(int M, int N, int K) {

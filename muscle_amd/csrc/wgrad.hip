@@ -665,6 +665,13 @@ int mx_pw_wgrad_small(const float* G, const float* X, int x_mode, const float* x
   return MX_OK;
 }
 
+bool mx_wgrad_uses_split(int R, int Co, int Ci) {
+  WgPlan sp;
+  if (wg_plan(R, Co, Ci, &sp)) return false;          // the small-output kernel is tried first (ops.pw_wgrad) and stays fp32
+  WtPlan p;
+  return wt_plan(R, Co, Ci, MX_PLAIN, &p) && wt_use_split(Co, Ci);
+}
+
 // bytes of scratch mx_pw_wgrad_tile needs (0 = shape not taken; a single row group accumulates straight into dW)
 long mx_pw_wgrad_tile_ws(int R, int Co, int Ci, int x_mode) {
   WtPlan p;

@@ -329,7 +329,35 @@ FOLD_BN0_APPLY = os.environ.get("MUSCLE_FOLD_BN0", "0") == "1"
 # data-gradient twin - both kernels fill every CU's wave slots, so the second one only trickles in.  Under overlap the
 # duration of a single launch says nothing about the kernel: bench.py takes its per-launch HIP events with this off.
 WGRAD_SIDE_STREAM = os.environ.get("MUSCLE_WGRAD_STREAM", "1") == "1"
-_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+_side_streams: Dict[tuple, "torch.cuda.Stream"] = {}
+
+
+def _masked_stream(device, n_cus: int):
+    """A HIP stream confined to `n_cus` of the chip's compute units (hipExtStreamCreateWithCUMask), wrapped for torch.
+    Stream creation is plumbing, so it goes straight to the HIP runtime torch has already loaded."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    n_cus = max(1, min(int(n_cus), total))
+    words = (total + 31) // 32
+    # every (256 // n)-th CU rather than the first n: the mask's bit order walks the XCDs / shader engines round-robin on
+    # some runtimes and CU-major on others; an evenly spaced pattern takes the same share of every XCD under both
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(n_cus):
+        cu = (i * total) // n_cus
+        mask[cu // 32] |= 1 << (cu % 32)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(words), mask)
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed (hipError {rc})")
+    return torch.cuda.ExternalStream(handle.value, device=device)
+
+
+# Weight-gradient side stream confined to this many CUs (0 = the whole chip).  The side stream's 180 us GEMM workgroups
+# otherwise take wave slots on every CU and the small latency-bound kernels of the main chain queue behind them
+# (profiles/r02_b_timeline.txt: se_bwd_b 134.9 us instead of 25.7 under overlap).
+WGRAD_CUS = int(os.environ.get("MUSCLE_WGRAD_CUS", "0"))
 
 
 class _WgradLane:
@@ -338,9 +366,12 @@ class _WgradLane:
         self.pending = []
         self.keep = []
         if WGRAD_SIDE_STREAM:
-            key = device.index if device.index is not None else torch.cuda.current_device()
+            key = (device.index if device.index is not None else torch.cuda.current_device(), WGRAD_CUS)
             if key not in _side_streams:
-                _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MUSCLE_WGRAD_PRIO", "0")))
+                if WGRAD_CUS > 0:
+                    _side_streams[key] = _masked_stream(device, WGRAD_CUS)
+                else:
+                    _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MUSCLE_WGRAD_PRIO", "0")))
             self.s = _side_streams[key]
 
     def wgrad(self, G, X, dW, **kw):

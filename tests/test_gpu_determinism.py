@@ -70,3 +70,28 @@ def test_eval_forward_is_bit_reproducible_and_batch_invariant():
         assert torch.equal(f, g)
     for f, o in zip(full, one):
         assert torch.equal(f[4:5], o)
+
+
+@pytest.mark.parametrize("arith", [0, 1])
+def test_headline_step_is_bit_reproducible(arith):
+    """BASELINE.json configs[2]'s workload (B7, 448x448, batch 32), where the large-shape kernel variants run (two-level BatchNorm
+    reductions, tiled / small-output weight gradients with row groups, the band ER backward): two steps on the same batch with
+    lr = 0 must give the same loss bits and the same gradient arena, in both GEMM arithmetics."""
+    import bench
+    name, N, size = "efficientnet-b7", 32, 448
+    torch.manual_seed(0)
+    model = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False).to(DEV)
+    opt = muscle_amd.FusedAdam(model.parameters(), lr=0.0, weight_decay=0.0)
+    batch = bench.make_batch(N, size, size // 2, 1234, DEV)
+    muscle_amd.set_gemm_mode(arith)
+    try:
+        runs = []
+        for _ in range(2):
+            torch.manual_seed(1)                       # same drop_connect draws
+            out = muscle_amd.mcl_step(model, opt, batch, 4, valid_channel=batch["label"].sum())
+            torch.cuda.synchronize()
+            runs.append((np.array([float(out[k]) for k in LOSSES], dtype=np.float32), model.last_grad_sink.arena.clone()))
+    finally:
+        muscle_amd.set_gemm_mode(0)
+    assert np.array_equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
+    assert torch.equal(runs[0][1], runs[1][1]), float((runs[0][1].double() - runs[1][1].double()).abs().max())

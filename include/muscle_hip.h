@@ -49,12 +49,13 @@ int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_s
               int rows_per_sample, const float* W, float* C, int M, int K, int N, int lda, int ldc,
               const float* bias, const float* residual, int relu, float* stats, void* stream);
 
-/* Arithmetic of the forward / data-gradient GEMMs (process-wide; initial value from MX_GEMM_SPLIT, default 0).
- * 0: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) - the parity mode of record.
- * 1: "split" mode for the MFMA-bound shapes: each fp32 operand is split exactly into three bf16 terms (x = h + m + l),
- *    six of the nine cross products (each exact in fp32) are accumulated in fp32 on the bf16 matrix pipe; the dropped
- *    terms are <= 3 * 2^-24 of a product.  Same results to fp32 round-off, 2.67x the matrix rate.  Opt-in.
- * 2: split mode for every NT GEMM (tests). */
+/* Arithmetic of the forward / data-gradient / weight-gradient GEMMs (process-wide; initial value from MX_GEMM_SPLIT, default 1).
+ * 0: exact-fp32 MFMA (v_mfma_f32_16x16x4_f32) for every GEMM.
+ * 1: (default) "split" arithmetic for the MFMA-bound shapes: each fp32 operand is split exactly into three bf16 terms
+ *    (x = h + m + l), six of the nine cross products (each exact in fp32) are accumulated in fp32 on the bf16 matrix pipe; the
+ *    dropped terms are <= 3 * 2^-24 of a product - one fp32 rounding.  Operands, accumulation and results are fp32; the error
+ *    against fp64 equals the fp32-MFMA kernels'; 2.67x the matrix rate.  The other shapes stay on exact-fp32 MFMA.
+ * 2: split arithmetic for every NT GEMM (tests). */
 int mx_set_gemm_mode(int mode);
 int mx_get_gemm_mode(void);
 /* 1 if, in the current mode, this GEMM runs in split arithmetic on the bf16 pipe (kind 0: mx_pw_fwd / data gradient

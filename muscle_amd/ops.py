@@ -65,9 +65,9 @@ def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None
 
 
 def set_gemm_mode(mode: int):
-    """Arithmetic of the forward / data-gradient GEMMs (include/muscle_hip.h, mx_set_gemm_mode): 0 = exact-fp32 MFMA (the
-    default and the parity mode of record); 1 = fp32 operands split exactly into three bf16 terms, six products on the
-    bf16 matrix pipe with fp32 accumulation, for the MFMA-bound shapes; 2 = the same for every NT GEMM (tests)."""
+    """Arithmetic of the pointwise-conv GEMMs (include/muscle_hip.h, mx_set_gemm_mode): 0 = exact-fp32 MFMA everywhere;
+    1 (the library's default) = fp32 operands split exactly into three bf16 terms, six products on the bf16 matrix pipe with
+    fp32 accumulation, for the MFMA-bound shapes; 2 = the same for every NT GEMM (tests)."""
     call("mx_set_gemm_mode", int(mode))
 
 

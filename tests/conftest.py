@@ -26,15 +26,16 @@ def pytest_addoption(parser):
 @pytest.fixture(autouse=True)
 def gemm_arith(request):
     mode = getattr(request, "param", 0)
-    if not mode or "gpu" not in request.keywords or not _has_gpu():
+    if "gpu" not in request.keywords or not _has_gpu():
         yield 0
         return
     import muscle_amd
+    before = muscle_amd.get_gemm_mode()        # the library's default is 1 (split); a test without a parameter runs in exact fp32
     muscle_amd.set_gemm_mode(mode)
     try:
         yield mode
     finally:
-        muscle_amd.set_gemm_mode(0)
+        muscle_amd.set_gemm_mode(before)
 
 
 def pytest_generate_tests(metafunc):

@@ -227,6 +227,87 @@ def test_chunked_exchange_equals_single_allreduce(tmp_path):
     np.testing.assert_allclose(a0["single"], want, rtol=1e-6)
 
 
+def test_grad_averager_behind_the_side_stream_issues_every_chunk_once(monkeypatch):
+    """engine._WgradLane.progress (the weight-gradient side stream's hand-off to the gradient exchange) with a mock stream:
+    the exchange must be issued INSIDE the side-stream context, only after that stream has been made to wait for the main
+    one (so the collective is ordered behind the kernels of both), pending weight-gradient GEMMs must have been flushed
+    first, and over a whole backward + the optimizer hook every chunk of the arena goes out exactly once."""
+    import torch
+    from muscle_amd import engine, ops
+    from muscle_amd import dist as mdist
+
+    log = []
+
+    class FakeStream:
+        def __init__(self, name):
+            self.name = name
+
+        def wait_stream(self, other):
+            log.append(("wait", self.name, other.name))
+
+        def record_event(self):
+            return None
+
+    main, side = FakeStream("main"), FakeStream("side")
+    active = [main]
+
+    class _Ctx:
+        def __init__(self, s):
+            self.s = s
+
+        def __enter__(self):
+            active.append(self.s)
+
+        def __exit__(self, *a):
+            active.pop()
+
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: active[-1])
+    monkeypatch.setattr(torch.cuda, "stream", lambda s: _Ctx(s))
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: 0)
+    monkeypatch.setattr(engine, "WGRAD_SIDE_STREAM", True)
+    monkeypatch.setattr(engine, "WGRAD_CUS", 0)
+    monkeypatch.setitem(engine._side_streams, (0, 0), side)
+    monkeypatch.setattr(ops, "pw_wgrad", lambda G, X, dW, **kw: log.append(("wgrad", active[-1].name, dW)))
+
+    n, chunk = 1000, 64
+    launched = []
+
+    class Sink:
+        arena = torch.zeros(n)
+
+    h = mdist.GradAverager(chunk_bytes=4 * chunk)
+    h.world = 2
+    monkeypatch.setattr(h, "_nccl", lambda: False)
+    monkeypatch.setattr(mdist.dist, "all_reduce", lambda buf, **kw: launched.append((active[-1].name, buf.data_ptr(), buf.numel())))
+    sink = Sink()
+
+    lane = engine._WgradLane(torch.device("cpu"))
+    assert lane.s is side
+    # a backward that reports progress back to front, with weight-gradient GEMMs queued in between
+    for step, lo in enumerate((900, 641, 640, 300, 130)):
+        lane.wgrad("G", "X", f"dW{step}")
+        before = len(log)
+        lane.progress(lambda m, lo=lo: h.on_ready(sink, lo), None)
+        new = log[before:]
+        assert ("wgrad", "side", f"dW{step}") in new                     # flushed, on the side stream
+        assert new[-1] == ("wait", "side", "main") or ("wait", "side", "main") in new
+    assert all(where == "side" for where, _, _ in launched)             # early chunks: issued from the side stream
+    early = len(launched)
+    assert early == h.launched_early > 0
+    lane.join()
+
+    class Model:
+        last_grad_sink = sink
+
+    h(Model(), 1)                                                       # the hook before the optimizer: the rest, incl. chunk 0
+    base = sink.arena.data_ptr()
+    spans = sorted(((p - base) // 4, cnt) for _, p, cnt in launched)
+    assert spans[0][0] == 0 and sum(c for _, c in spans) == n
+    for (a, ca), (b, _) in zip(spans, spans[1:]):
+        assert a + ca == b                                              # contiguous, no overlap: every element exactly once
+    assert h.bytes_reduced == 4 * n
+
+
 def test_infer_oracle_semantics_and_file_format(tmp_path):
     """infer_mcl.py:107-182 restated in the oracle: dict keys = positive labels, float32 [H,W] maps, the min-max rule
     with its 'below min + 1e-6 -> 0' quirk, un-flipping of odd passes, and the .npy dict layout evaluation.py reads."""

@@ -26,6 +26,7 @@
   } while (0)
 
 #include "../../muscle_amd/csrc/gemm.hip"
+#include "../../muscle_amd/csrc/wgrad.hip"
 #include "../../muscle_amd/csrc/api.cpp"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -59,7 +60,11 @@ static const Shape kShapes[] = {{25088, 640, 3840}, {25088, 3840, 640}, {25088, 
                                 {25088, 1344, 224}, {25088, 160, 960}, {25088, 960, 160}, {100352, 80, 480}, {100352, 480, 80},
                                 {401408, 48, 288}, {401408, 288, 48}, {401408, 192, 48}, {1605632, 32, 192}, {1605632, 32, 32}};
 
+static void* ws = nullptr;
+static const long ws_bytes = 512l << 20;
+
 static void run_time() {
+  if (!ws) CK(hipMalloc(&ws, ws_bytes));
   for (const Shape& s : kShapes) {
     float* A = dalloc((long)s.M * s.K, 1, 1.f); float* W = dalloc((long)s.N * s.K, 2, 0.05f);
     float* G = dalloc((long)s.M * s.N, 3, 1.f); float* C = dalloc((long)s.M * s.N, 4, 0.f);
@@ -68,8 +73,15 @@ static void run_time() {
     float* st = dalloc((long)parts * 2 * s.N, 7, 0.f);
     const double fl = 2.0 * s.M * s.K * s.N;
     float t1 = time_us([&] { mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C, s.M, s.K, s.N, s.K, s.N, nullptr, nullptr, 0, st, nullptr); });
-    float t2 = time_us([&] { mx_pw_dgrad(G, W, dX, s.M, s.N, s.K, s.N, s.K, nullptr, nullptr); });
-    float t3 = time_us([&] { mx_pw_wgrad(G, A, 0, nullptr, nullptr, nullptr, 1, dW, s.M, s.N, s.K, s.N, s.K, nullptr); });
+    // data gradient as the product runs it: a forward GEMM against W^T (ops.pw_dgrad)
+    float* Wt = dalloc((long)s.N * s.K, 8, 0.05f);
+    float t2 = time_us([&] { mx_pw_fwd(G, 0, nullptr, nullptr, nullptr, 1, Wt, dX, s.M, s.N, s.K, s.N, s.K, nullptr, nullptr, 0, nullptr, nullptr); });
+    CK(hipFree(Wt));
+    float t3 = time_us([&] {
+      if (mx_pw_wgrad_tile_ws(s.M, s.N, s.K, 0) > 0) mx_pw_wgrad_tile(G, A, 0, nullptr, nullptr, nullptr, 1, dW, s.M, s.N, s.K, s.N, s.K, ws, ws_bytes, nullptr);
+      else if (mx_pw_wgrad_small_ws(s.M, s.N, s.K, 0) > 0) mx_pw_wgrad_small(G, A, 0, nullptr, nullptr, nullptr, 1, dW, s.M, s.N, s.K, s.N, s.K, ws, ws_bytes, nullptr);
+      else mx_pw_wgrad(G, A, 0, nullptr, nullptr, nullptr, 1, dW, s.M, s.N, s.K, s.N, s.K, ws, ws_bytes, nullptr);
+    });
     printf("  M=%d K=%d N=%d: fwd %7.1f us %6.1f TF | dgrad %7.1f us %6.1f TF | wgrad %7.1f us %6.1f TF\n", s.M, s.K, s.N, t1,
            fl / t1 / 1e6, t2, fl / t2 / 1e6, t3, fl / t3 / 1e6);
     fflush(stdout);
@@ -88,8 +100,9 @@ static void run_stamps(int M, int K, int N, int which) {
   auto call = [&] {
     if (which == 0) mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C, M, K, N, K, N, nullptr, nullptr, 0, st, nullptr);
     else if (which == 1) mx_pw_dgrad(G, W, dX, M, N, K, N, K, nullptr, nullptr);
-    else mx_pw_wgrad(G, A, 0, nullptr, nullptr, nullptr, 1, dW, M, N, K, N, K, nullptr);
+    else mx_pw_wgrad(G, A, 0, nullptr, nullptr, nullptr, 1, dW, M, N, K, N, K, ws, ws_bytes, nullptr);
   };
+  if (!ws) CK(hipMalloc(&ws, ws_bytes));
   float t_plain = time_us(call);
   CK(hipMemset(stamps, 0, maxwg * 8 * sizeof(unsigned long long)));
   mx_gemm_stamps = stamps;
@@ -177,6 +190,14 @@ static int run_check(int M, int K, int N) {
 int main(int argc, char** argv) {
   if (argc >= 5 && !strcmp(argv[1], "check")) return run_check(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
   if (argc >= 2 && !strcmp(argv[1], "time")) { run_time(); return 0; }
+  if (argc >= 5 && !strcmp(argv[1], "time1")) {      // forward GEMM of one shape (plain A, statistics)
+    const int M = atoi(argv[2]), K = atoi(argv[3]), N = atoi(argv[4]);
+    float* A = dalloc((long)M * K, 1, 1.f); float* W = dalloc((long)(N + 256) * (K + 32) * 2, 2, 0.05f); float* C = dalloc((long)M * N, 4, 0.f);
+    float* st = dalloc((long)mx_pw_fwd_parts(M, N, K) * 2 * N, 7, 0.f);
+    float t1 = time_us([&] { mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C, M, K, N, K, N, nullptr, nullptr, 0, st, nullptr); });
+    printf("  M=%d K=%d N=%d: fwd %7.1f us %6.1f TF\n", M, K, N, t1, 2.0 * M * K * N / t1 / 1e6);
+    return 0;
+  }
   if (argc >= 5 && !strcmp(argv[1], "stamps")) {
     for (int which = 0; which < 3; ++which) run_stamps(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), which);
     return 0;

@@ -380,19 +380,21 @@ struct DwFusedArgs {
   int N, H, W, C, pad, tiles_x, tiles_y, tiles_per_block;
 };
 
-#ifndef DW_FUSED_K5_WAVES
-#define DW_FUSED_K5_WAVES 2
-#endif
-template <int K, int TH, int TW, int OX>
-__global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fused_kernel(DwFusedArgs a) {
+// Tile shapes (TH x TW output pixels per staged tile, PX consecutive pixels per thread "group", 16 groups per pass):
+//   8 x 16, PX 8  - one group per thread; 30 KB of LDS for 5x5: the round-1/2 shape, best where the image is not a multiple of 14/28
+//   14 x 28, PX 7 - four passes of groups per thread; 72 KB for 5x5 (2 workgroups per CU).  B7's stride-1 layers are 224 / 112 / 56 /
+//                   28 pixels wide: 28 = 2 x 14 rows x 1 x 28 columns EXACTLY, where 8 x 16 tiles cover 32 x 32 (1.31x the pixels) and stage
+//                   8 x 240 elements for 784 outputs (2.45x); 14 x 28 stages 2 x 576 (1.47x): -40 % staging work and dA / D reads.
+template <int K, int TH, int TW, int PX>
+__global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused_kernel(DwFusedArgs a) {
   // Only dd is staged with its halo.  The weight gradient is taken over INPUT pixels,
   //     dW[ky,kx] = sum_q act(X)[q] * dd[q - (ky,kx) + pad],
-  // so the activated input is needed at the tile's centre pixels only: each thread reads its 2 channels x 8 pixels of X
+  // so the activated input is needed at the tile's centre pixels only: each thread reads its 2 channels x PX pixels of X
   // straight into registers (1.0x instead of the halo's 1.9x, no LDS), reuses the raw values for the swish'(bn0(x))
   // factor and the BN0 sums of the epilogue, and the dW and dX loops walk the SAME shifted dd rows, so every LDS read
-  // feeds both.  One staged array instead of two: 30 KB instead of 61 KB for 5x5, 4 workgroups per CU instead of 2
-  // (round 1 PMC: the two-array kernel sat at SQ_WAIT_ANY 45-60 %, 1.5-1.9 TB/s).
-  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256, CH = (K == 5) ? 4 : 3;
+  // feeds both.  One staged array instead of two (round 1 PMC: the two-array kernel sat at SQ_WAIT_ANY 45-60 %, 1.5-1.9 TB/s).
+  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256;
+  constexpr int CH = (PER % 4 == 0) ? 4 : (PER % 3 == 0) ? 3 : 2;
   static_assert(PER % CH == 0, "staging chunks");
   __shared__ float4 td[TOT];     // dd with halo; at the end the per-wave partial rows of dW and of the BN0 sums
   static_assert(TOT * 4 >= 4 * K * K * CB, "the per-wave partial rows reuse the staged tile");
@@ -402,10 +404,10 @@ __global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fu
   const int c4 = tid % C4B;                        // staging: 4 channels per thread
   const int c = c0 + 4 * c4;
   const bool cok = c < a.C;
-  constexpr int C2B = CB / 2, PX = 8;              // compute: 2 channels x 8 pixels per thread
-  static_assert(TW % PX == 0 && TH * (TW / PX) * C2B == 256, "compute mapping");
+  constexpr int C2B = CB / 2;                      // compute: 2 channels x PX pixels per thread and pass
+  constexpr int GX = TW / PX, NGRP = TH * GX, NG = (NGRP + 15) / 16;   // pixel groups per tile; passes of 16 groups
+  static_assert(TW % PX == 0 && PX >= 5 && PX <= 8, "compute mapping");
   const int c2 = tid % C2B, pq = tid / C2B;
-  const int pyl = pq / (TW / PX), pxl = (pq % (TW / PX)) * PX;
   const int cc2 = c0 + 2 * c2;
   const bool cok2 = cc2 < a.C;
   const bool has_bn0 = a.a0 != nullptr;
@@ -426,6 +428,15 @@ __global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fu
   float2 s0 = make_float2(0, 0), s1 = s0;
   const long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
   const long t_beg = (long)blockIdx.x * a.tiles_per_block, t_end = min(ntiles, t_beg + a.tiles_per_block);
+  // this thread's centre pixels of X (raw) for one group: clamped addresses, masked at use
+  auto load_x = [&](float2 (&xr)[PX], int n, int oy, int oxb) {
+    const int oyc = min(oy, a.H - 1);
+#pragma unroll
+    for (int o = 0; o < PX; ++o) {
+      const int oxc = min(oxb + o, a.W - 1);
+      xr[o] = *reinterpret_cast<const float2*>(a.x + (((long)n * a.H + oyc) * a.W + oxc) * a.C + (cok2 ? cc2 : 0));
+    }
+  };
   for (long t = t_beg; t < t_end; ++t) {
     const int n = (int)(t / (a.tiles_x * a.tiles_y));
     const int rem = (int)(t % (a.tiles_x * a.tiles_y));
@@ -436,17 +447,9 @@ __global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fu
       int cc = tid % CB;
       cst[7 * CB + tid] = (c0 + cc < a.C) ? (tid < CB ? a.gate : a.add)[(long)n * a.C + c0 + cc] : 0.f;
     }
-    // this thread's centre pixels of X (raw), requested before the staging loop so they land under it
-    const int oy = oy0 + pyl;
+    // the first group's centre pixels are requested before the staging loop so they land under it
     float2 xr[PX];
-    {
-      const int oyc = min(oy, a.H - 1);
-#pragma unroll
-      for (int o = 0; o < PX; ++o) {
-        const int oxc = min(ox0 + pxl + o, a.W - 1);
-        xr[o] = *reinterpret_cast<const float2*>(a.x + (((long)n * a.H + oyc) * a.W + oxc) * a.C + (cok2 ? cc2 : 0));
-      }
-    }
+    load_x(xr, n, oy0 + pq / GX, ox0 + (pq % GX) * PX);
     __syncthreads();
     // stage dd, CH float4 pairs in flight per thread
 #pragma unroll 1
@@ -479,75 +482,103 @@ __global__ __launch_bounds__(256, K == 5 ? DW_FUSED_K5_WAVES : 3) void dw_bwd_fu
       }
     }
     __syncthreads();
-    // Compute: a thread owns 2 channels x PX=8 consecutive pixels of one tile row (4 channels x 4 pixels needs 100
+    // Compute: a thread owns 2 channels x PX consecutive pixels of one tile row per pass (4 channels x 4 pixels needs 100
     // accumulator VGPRs for K=5 and the allocator then spills; 2 x 8 needs 50 and keeps v_pk_fma_f32 over the channel pair).
     // Row ky of the kernel pairs this pixel row with dd row pyl + K-1-ky of the halo tile, for the weight gradient
     // (times act(X) of the centre pixel) and for the data gradient (times the flipped weight) alike.  The pixel loop is
     // a real loop over halves (QX pixels each): fully unrolled, the scheduler hoists every LDS read to the top and the
-    // kernel drops below 4 waves/SIMD or spills.
+    // kernel drops below its occupancy target or spills.
     const float2* td2 = reinterpret_cast<const float2*>(td);
     const float2 A0 = *reinterpret_cast<const float2*>(cst + 5 * CB + 2 * c2), B0 = *reinterpret_cast<const float2*>(cst + 6 * CB + 2 * c2);
-    constexpr int QX = PX / 2;
-    float2 acc[PX];
+    constexpr int QX = (PX + 1) / 2;               // pixels per half; an odd PX leaves the last slot of the second half masked
 #pragma unroll 1
-    for (int h = 0; h < 2; ++h) {
-      const int px = pxl + h * QX;
-      const float* wlh = wl + 2 * c2;            // opaque per half: the 25 weight pairs are loop-invariant and would
-      asm volatile("" : "+v"(wlh));              // otherwise be hoisted out of this loop as 50 live registers
-      float2 xa[QX], ah[QX];
-#pragma unroll
-      for (int o = 0; o < QX; ++o) {
-        const float2 r = h == 0 ? xr[o] : xr[QX + o];
-        const bool in_img = cok2 && oy < a.H && ox0 + px + o < a.W;
-        float2 v = r;
-        if (has_bn0) { v.x = swishf_(A0.x * r.x + B0.x); v.y = swishf_(A0.y * r.y + B0.y); }
-        xa[o] = in_img ? v : make_float2(0.f, 0.f);
-        ah[o] = make_float2(0.f, 0.f);
+    for (int gi = 0; gi < NG; ++gi) {
+      const int grp = pq + 16 * gi;
+      const bool gok = grp < NGRP;                 // (NGRP is a multiple of 16 for the 8 x 16 shape; 56 of 64 for 14 x 28)
+      const int pyl = min(grp, NGRP - 1) / GX, pxl = (min(grp, NGRP - 1) % GX) * PX;
+      const int oy = oy0 + pyl;
+      float2 xn[PX];                               // the next pass's centre pixels, in flight under this pass's arithmetic
+      if (gi + 1 < NG) {
+        const int g2 = min(grp + 16, NGRP - 1);
+        load_x(xn, n, oy0 + g2 / GX, ox0 + (g2 % GX) * PX);
       }
+      // sig: sigma(bn0(x)) of the centre pixels, evaluated ONCE (act and swish' both use it) where the register budget has
+      // room for it (2 waves per SIMD); the 3-wave 3x3 / 8 x 16 variant re-evaluates it in the epilogue instead of spilling
+      constexpr bool KEEP_SIG = (K == 5 || TH != 8);
+      float2 acc[PX], sig[KEEP_SIG ? PX : 1];
+#pragma unroll 1
+      for (int h = 0; h < 2; ++h) {
+        const int px = pxl + h * QX;
+        const float* wlh = wl + 2 * c2;            // opaque per half: the 25 weight pairs are loop-invariant and would
+        asm volatile("" : "+v"(wlh));              // otherwise be hoisted out of this loop as 50 live registers
+        float2 xa[QX], ah[QX], sg[QX];
 #pragma unroll
-      for (int ky = 0; ky < K; ++ky) {
-        __builtin_amdgcn_sched_barrier(0);       // one kernel row's LDS reads at a time (hoisted together they spill)
-        float2 in[QX - 1 + K];
+        for (int o = 0; o < QX; ++o) {
+          const int oo = h * QX + o;
+          float2 r = make_float2(0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < QX - 1 + K; ++j) in[j] = td2[((pyl + K - 1 - ky) * IW + px + j) * C2B + c2];
-#pragma unroll
-        for (int kx = 0; kx < K; ++kx) {
-          const float2 w = *reinterpret_cast<const float2*>(wlh + (ky * K + kx) * CB);
-          float2& p = part[ky * K + kx];
-#pragma unroll
-          for (int o = 0; o < QX; ++o) {
-            const float2 v = in[o + K - 1 - kx];
-            ah[o].x += w.x * v.x; ah[o].y += w.y * v.y;
-            p.x += xa[o].x * v.x; p.y += xa[o].y * v.y;
-          }
-        }
-      }
-      if (h == 0) {
-#pragma unroll
-        for (int o = 0; o < QX; ++o) acc[o] = ah[o];
-      } else {
-#pragma unroll
-        for (int o = 0; o < QX; ++o) acc[QX + o] = ah[o];
-      }
-    }
-    if (cok2 && oy < a.H) {
-#pragma unroll
-      for (int o = 0; o < PX; ++o) {
-        int ox = ox0 + pxl + o;
-        if (ox < a.W) {
-          const long off = (((long)n * a.H + oy) * a.W + ox) * a.C + cc2;
-          float2 v = acc[o];
+          for (int q = 0; q < PX; ++q) if (q == oo) r = xr[q];          // (register select: oo is uniform, PX <= 8)
+          const bool in_img = gok && cok2 && oo < PX && oy < a.H && ox0 + px + o < a.W;
+          float2 v = r, sv = make_float2(0.f, 0.f);
           if (has_bn0) {
-            const float2 r = xr[o];
-            v.x *= swish_gradf_(A0.x * r.x + B0.x); v.y *= swish_gradf_(A0.y * r.y + B0.y);
-            s0.x += v.x; s0.y += v.y;
-            s1.x += v.x * r.x; s1.y += v.y * r.y;
-          } else if (a.res) {
-            float2 r = *reinterpret_cast<const float2*>(a.res + off);
-            v.x += r.x; v.y += r.y;
+            const float zx = A0.x * r.x + B0.x, zy = A0.y * r.y + B0.y;
+            sv.x = sigmoidf_(zx); sv.y = sigmoidf_(zy);
+            v.x = zx * sv.x; v.y = zy * sv.y;
           }
-          *reinterpret_cast<float2*>(a.gx + off) = v;
+          xa[o] = in_img ? v : make_float2(0.f, 0.f);
+          sg[o] = sv;
+          ah[o] = make_float2(0.f, 0.f);
         }
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+          __builtin_amdgcn_sched_barrier(0);       // one kernel row's LDS reads at a time (hoisted together they spill)
+          float2 in[QX - 1 + K];
+#pragma unroll
+          for (int j = 0; j < QX - 1 + K; ++j) in[j] = td2[((pyl + K - 1 - ky) * IW + min(px + j, IW - 1)) * C2B + c2];
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) {
+            const float2 w = *reinterpret_cast<const float2*>(wlh + (ky * K + kx) * CB);
+            float2& p = part[ky * K + kx];
+#pragma unroll
+            for (int o = 0; o < QX; ++o) {
+              const float2 v = in[o + K - 1 - kx];
+              ah[o].x += w.x * v.x; ah[o].y += w.y * v.y;
+              p.x += xa[o].x * v.x; p.y += xa[o].y * v.y;
+            }
+          }
+        }
+#pragma unroll
+        for (int o = 0; o < QX; ++o) {
+          const int oo = h * QX + o;
+#pragma unroll
+          for (int q = 0; q < PX; ++q) if (q == oo) { acc[q] = ah[o]; if (KEEP_SIG) sig[q] = sg[o]; }
+        }
+      }
+      if (gok && cok2 && oy < a.H) {
+#pragma unroll
+        for (int o = 0; o < PX; ++o) {
+          int ox = ox0 + pxl + o;
+          if (ox < a.W) {
+            const long off = (((long)n * a.H + oy) * a.W + ox) * a.C + cc2;
+            float2 v = acc[o];
+            if (has_bn0) {
+              const float2 r = xr[o];
+              const float zx = A0.x * r.x + B0.x, zy = A0.y * r.y + B0.y;
+              const float2 sv = KEEP_SIG ? sig[o] : make_float2(sigmoidf_(zx), sigmoidf_(zy));
+              v.x *= sv.x * (1.0f + zx * (1.0f - sv.x)); v.y *= sv.y * (1.0f + zy * (1.0f - sv.y));   // swish'(z) from the same sigma
+              s0.x += v.x; s0.y += v.y;
+              s1.x += v.x * r.x; s1.y += v.y * r.y;
+            } else if (a.res) {
+              float2 r = *reinterpret_cast<const float2*>(a.res + off);
+              v.x += r.x; v.y += r.y;
+            }
+            *reinterpret_cast<float2*>(a.gx + off) = v;
+          }
+        }
+      }
+      if (gi + 1 < NG) {
+#pragma unroll
+        for (int o = 0; o < PX; ++o) xr[o] = xn[o];
       }
     }
   }
@@ -620,15 +651,30 @@ static void launch_dw_parts_reduce(const float* part, int P, int n, float* dW, h
   hipLaunchKernelGGL(dw_parts_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, P, n, dW);
 }
 
+// tile shape of the fused backward: 1 = 14 x 28 (PX 7), 0 = 8 x 16 (PX 8).  The large tile wherever it covers the image with
+// fewer staged elements per valid output (its halo factor is lower, its quantisation coarser); MX_DW_FUSED_TILE forces one.
+static int dw_fused_shape(int H, int Wd, int K) {
+  static const int forced = getenv("MX_DW_FUSED_TILE") ? atoi(getenv("MX_DW_FUSED_TILE")) : -1;
+  if (forced == 0 || forced == 1) return forced;
+  // measured on MI355X (tools/microbench.py dwfused, profiles/r03_dwfused_tiles.txt): 5x5 gains 13-19 % on every B7 layer
+  // (2.3-2.6 -> 2.8-2.9 TB/s); 3x3, which ran 3 workgroups per CU on the small tile, loses 9-15 % at 112 / 224 pixels and is
+  // level at 28: the large tile is taken for 5x5 only
+  if (K != 5) return 0;
+  const double small = (double)cdiv(H, 8) * cdiv(Wd, 16) * (8 + K - 1) * (16 + K - 1);
+  const double large = (double)cdiv(H, 14) * cdiv(Wd, 28) * (14 + K - 1) * (28 + K - 1);
+  return large < 0.9 * small ? 1 : 0;
+}
+
 static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int* tiles_y, int* tpb, int* groups) {
-  *tiles_x = cdiv(Wd, 16); *tiles_y = cdiv(H, 8);
+  const int shape = dw_fused_shape(H, Wd, K);
+  *tiles_x = cdiv(Wd, shape ? 28 : 16); *tiles_y = cdiv(H, shape ? 14 : 8);
   long ntiles = (long)N * (*tiles_x) * (*tiles_y);
   int chunks = cdiv(C, CB);
   // workgroups per launch ~ this target (tuning override MX_DW_GROUPS).  The 5x5 kernel (2 workgroups per CU, heavy
   // per-workgroup prologue / partial-row epilogue) wants few long-lived workgroups: 11.0 -> 9.8 ms per step at 1024
   // instead of 4096; the 3x3 kernel (3 per CU) wants the opposite: 6.8 ms at 4096, 8.0 ms at 1024.
   static const long override_target = getenv("MX_DW_GROUPS") ? atol(getenv("MX_DW_GROUPS")) : 0;
-  const long group_target = override_target > 0 ? override_target : (K == 5 ? 1024 : 4096);
+  const long group_target = override_target > 0 ? override_target : ((K == 5 || shape) ? 1024 : 4096);
   long g = group_target / chunks;
   if (g < 1) g = 1;
   if (g > ntiles) g = ntiles;
@@ -786,8 +832,16 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
   int groups;
   dw_fused_geom(N, H, Wd, C, K, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups);
   dim3 grid(groups, cdiv(C, CB), 1);
-  if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 8, 16, 4>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  const int shape = dw_fused_shape(H, Wd, K);
+  if (shape) {
+    static bool big_lds = false;                         // 14 x 28 tiles: 72 KB (5x5) / 60 KB (3x3) of static LDS
+    (void)big_lds;
+    if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 14, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 14, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else {
+    if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 8, 16, 8>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 8, 16, 8>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  }
   MX_LAUNCH_CHECK();
   launch_dw_parts_reduce(dw_scratch, groups, C * K * K, dW, (hipStream_t)stream);
   MX_LAUNCH_CHECK();

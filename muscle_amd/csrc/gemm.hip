@@ -817,8 +817,14 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + 3 * PA_;
     bf16x8 av[2][3], bv[NJ][3];
+#if defined(MX_LAB_NOREAD)      // lab: the loop without its LDS fragment reads (MFMA + barrier floor)
+    if (kt == 0)
+#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
+#if defined(MX_LAB_READ2)       // lab: two planes' worth of LDS reads instead of three
+      if (p == 2) { av[0][2] = av[0][1]; av[1][2] = av[1][1]; for (int j = 0; j < NJ; ++j) bv[j][2] = bv[j][1]; break; }
+#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i) av[i][p] = *reinterpret_cast<const bf16x8*>(sa + p * PA_ + fa[i]);
 #ifndef MX_LAB_BGLOBAL

@@ -32,6 +32,8 @@ struct DwArgs {
   int N, H, W, Ho, Wo, C, pad;
   int tiles_x, tiles_y;
   int tiles_per_block;   // bwd_weight
+  int xcd;               // fwd: 1 = 1-D grid, the tiles of one (sample, channel chunk) plane run on ONE XCD (see dw_fwd_kernel)
+  int chunks;            // fwd: channel chunks (the y extent of the logical grid)
 };
 
 __device__ __forceinline__ float4 dw_load(const DwArgs& a, const float* p, int c) {
@@ -102,8 +104,23 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float red[4][2 * CB];     // one row per wave: the four waves are added in wave order (LDS atomics gave sums
   __shared__ unsigned last_flag;       // whose last bit depended on which wave came first)
   const int tid = threadIdx.x;
-  const int tx = blockIdx.x % a.tiles_x, ty = blockIdx.x / a.tiles_x;
-  const int c0 = blockIdx.y * CB, n = blockIdx.z;
+  // Logical grid (tile, channel chunk, sample).  Neighbouring tiles share their halo; the hardware deals workgroups to the 8
+  // XCDs round-robin, so with a plain 3-D grid the neighbours of a tile sit on seven OTHER XCDs and every halo pixel crosses
+  // the fabric once per tile that touches it (PMC: 351 MB fetched per launch for a 221 MB tensor).  XCD-aware ids: workgroup L
+  // goes to XCD L % 8; all tiles of one (sample, chunk) plane get ids of the same residue, so the halo is an L2 hit.
+  const int ntile = a.tiles_x * a.tiles_y;
+  int tile_id, chunk, n;
+  if (a.xcd) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int plane = (j / ntile) * 8 + xcd;
+    tile_id = j % ntile;
+    if (plane >= a.chunks * a.N) return;
+    chunk = plane % a.chunks; n = plane / a.chunks;
+  } else {
+    tile_id = blockIdx.x; chunk = blockIdx.y; n = blockIdx.z;
+  }
+  const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
+  const int c0 = chunk * CB;
   const int oy0 = ty * TH, ox0 = tx * TW;
   dw_stage_weights<K>(a, wl, c0, tid);
   dw_stage_input<K, S, TH, TW>(a, tile, n, oy0, ox0, c0, tid);
@@ -166,18 +183,18 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     __syncthreads();
     const bool own = tid < CB && c0 + tid < a.C;
     const float v = own ? ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid] : 0.f;
-    if (gridDim.x == 1) {
+    if (ntile == 1) {
       if (own) a.pooled[(long)n * a.C + c0 + tid] = v;
       return;
     }
     // the tiles of a sample are joined by the last workgroup to arrive, in tile order (no atomics: the squeeze, and with it
     // the whole eval forward, gives the same bits whatever the batch size and the run)
-    if (own) mx_st_wt(a.poolpart + ((long)blockIdx.x * gridDim.z + n) * a.C + c0 + tid, v);
-    if (!mx_last_arriver(a.counters + n * gridDim.y + blockIdx.y, gridDim.x, &last_flag)) return;
+    if (own) mx_st_wt(a.poolpart + ((long)tile_id * a.N + n) * a.C + c0 + tid, v);
+    if (!mx_last_arriver(a.counters + n * a.chunks + chunk, ntile, &last_flag)) return;
     const int cl = tid & 31, rl = tid >> 5;
     float t = 0.f;
     if (c0 + cl < a.C)
-      for (int pt = rl; pt < (int)gridDim.x; pt += 8) t += a.poolpart[((long)pt * gridDim.z + n) * a.C + c0 + cl];
+      for (int pt = rl; pt < ntile; pt += 8) t += a.poolpart[((long)pt * a.N + n) * a.C + c0 + cl];
     __syncthreads();
     (&red[0][0])[rl * 32 + cl] = t;
     __syncthreads();
@@ -202,7 +219,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     if (tid < 2 * CB) {
       const int cc = tid % CB;
       if (c0 + cc < a.C) {
-        float* prow = a.stats + ((long)n * gridDim.x + blockIdx.x) * 2 * a.C;   // one partial row per (sample, tile)
+        float* prow = a.stats + ((long)n * ntile + tile_id) * 2 * a.C;   // one partial row per (sample, tile)
         prow[(tid / CB) * a.C + c0 + cc] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
       }
     }
@@ -378,6 +395,7 @@ struct DwFusedArgs {
   const float* w; const float* res;                   // weights [C,1,K,K]; residual added to gX (plain-input case)
   float* gx; float* dwpart; float* part;              // outputs: gX (or g*swish'), dW partial rows [groups][C*K*K], BN0 partial sums [groups][2][C]
   int N, H, W, C, pad, tiles_x, tiles_y, tiles_per_block;
+  int xcd, gpp, chunks;    // xcd = 1: 1-D grid, the gpp tile groups of one (sample, channel chunk) plane run on ONE XCD (dw_fwd_kernel)
 };
 
 // Tile shapes (TH x TW output pixels per staged tile, PX consecutive pixels per thread "group", 16 groups per pass):
@@ -400,7 +418,25 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
   static_assert(TOT * 4 >= 4 * K * K * CB, "the per-wave partial rows reuse the staged tile");
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
   __shared__ __attribute__((aligned(16))) float cst[9 * CB];   // a1 b1 c1 c2 c3 a0 b0 | gate add (per tile)
-  const int tid = threadIdx.x, c0 = blockIdx.y * CB;
+  // workgroup -> (group of tiles, channel chunk); XCD-aware ids as in dw_fwd_kernel when a plane is cut into several groups
+  int grp_id = blockIdx.x, chunk_id = blockIdx.y;
+  long t_beg, t_end;
+  const long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
+  if (a.xcd) {
+    const int ntile = a.tiles_x * a.tiles_y;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int plane = (j / a.gpp) * 8 + xcd, gi = j % a.gpp;
+    if (plane >= a.chunks * a.N) return;
+    chunk_id = plane % a.chunks;
+    const int n_ = plane / a.chunks;
+    grp_id = n_ * a.gpp + gi;
+    t_beg = (long)n_ * ntile + (long)gi * a.tiles_per_block;
+    t_end = min((long)(n_ + 1) * ntile, t_beg + a.tiles_per_block);
+  } else {
+    t_beg = (long)blockIdx.x * a.tiles_per_block;
+    t_end = min(ntiles, t_beg + a.tiles_per_block);
+  }
+  const int tid = threadIdx.x, c0 = chunk_id * CB;
   const int c4 = tid % C4B;                        // staging: 4 channels per thread
   const int c = c0 + 4 * c4;
   const bool cok = c < a.C;
@@ -426,8 +462,6 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
 #pragma unroll
   for (int t = 0; t < K * K; ++t) part[t] = make_float2(0, 0);
   float2 s0 = make_float2(0, 0), s1 = s0;
-  const long ntiles = (long)a.N * a.tiles_x * a.tiles_y;
-  const long t_beg = (long)blockIdx.x * a.tiles_per_block, t_end = min(ntiles, t_beg + a.tiles_per_block);
   // this thread's centre pixels of X (raw) for one group: clamped addresses, masked at use
   auto load_x = [&](float2 (&xr)[PX], int n, int oy, int oxb) {
     const int oyc = min(oy, a.H - 1);
@@ -599,7 +633,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
   for (int i = tid; i < K * K * CB; i += 256) {
     int cc = i % CB, tap = i / CB;
     if (c0 + cc < a.C)
-      a.dwpart[(long)blockIdx.x * a.C * K * K + (long)(c0 + cc) * K * K + tap] =
+      a.dwpart[(long)grp_id * a.C * K * K + (long)(c0 + cc) * K * K + tap] =
           ((slots[i] + slots[K * K * CB + i]) + slots[2 * K * K * CB + i]) + slots[3 * K * K * CB + i];
   }
   if (a.part) {
@@ -617,7 +651,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
     if (tid < 2 * CB) {
       const int cc = tid % CB;
       if (c0 + cc < a.C)
-        a.part[(long)blockIdx.x * 2 * a.C + (tid / CB) * a.C + c0 + cc] =
+        a.part[(long)grp_id * 2 * a.C + (tid / CB) * a.C + c0 + cc] =
             ((slots[tid] + slots[2 * CB + tid]) + slots[4 * CB + tid]) + slots[6 * CB + tid];
     }
   }
@@ -665,10 +699,13 @@ static int dw_fused_shape(int H, int Wd, int K) {
   return large < 0.9 * small ? 1 : 0;
 }
 
-static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int* tiles_y, int* tpb, int* groups) {
+// groups = partial rows written; gpp > 0: XCD-aware launch (a plane = one sample x one channel chunk is cut into gpp groups that do
+// not straddle samples, all on one XCD); gpp = 0: plain 2-D grid, a group is tpb consecutive tiles of the (sample, tile) sequence
+static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int* tiles_y, int* tpb, int* groups, int* gpp) {
   const int shape = dw_fused_shape(H, Wd, K);
   *tiles_x = cdiv(Wd, shape ? 28 : 16); *tiles_y = cdiv(H, shape ? 14 : 8);
-  long ntiles = (long)N * (*tiles_x) * (*tiles_y);
+  const int ntile = (*tiles_x) * (*tiles_y);
+  long ntiles = (long)N * ntile;
   int chunks = cdiv(C, CB);
   // workgroups per launch ~ this target (tuning override MX_DW_GROUPS).  The 5x5 kernel (2 workgroups per CU, heavy
   // per-workgroup prologue / partial-row epilogue) wants few long-lived workgroups: 11.0 -> 9.8 ms per step at 1024
@@ -680,6 +717,12 @@ static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int*
   if (g > ntiles) g = ntiles;
   *tpb = (int)((ntiles + g - 1) / g);
   *groups = cdiv(ntiles, *tpb);
+  *gpp = 0;
+  static const int xcd_on = getenv("MX_DW_XCD") ? atoi(getenv("MX_DW_XCD")) : 0;      // (measured neutral, see mx_dwconv_fwd)
+  if (xcd_on && *tpb < ntile && (long)chunks * N >= 64) {
+    *gpp = cdiv(ntile, *tpb);
+    *groups = N * (*gpp);
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -740,12 +783,22 @@ int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const 
   const int TH = 8, TW = (S == 1) ? 16 : 8;
   a.tiles_x = cdiv(Wo, TW); a.tiles_y = cdiv(Ho, TH);
   dim3 grid(a.tiles_x * a.tiles_y, cdiv(C, CB), N);
+  a.chunks = grid.y;
   if (pooled && grid.x > 1) {
     const long need = mx_dwconv_fwd_ws(N, Ho, Wo, C, S);
     MX_CHECK_ARG(ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0, "dwconv_fwd: pooled needs %ld bytes of scratch (mx_dwconv_fwd_ws)", need);
     MX_CHECK_ARG((long)N * grid.y <= MX_WS_COUNTERS, "dwconv_fwd: N=%d x %d channel chunks exceed the %d arrival counters", N, (int)grid.y, MX_WS_COUNTERS);
     a.counters = reinterpret_cast<unsigned*>(ws);
     a.poolpart = reinterpret_cast<float*>((char*)ws + MX_WS_COUNTER_BYTES);
+  }
+  // XCD-aware workgroup ids (MX_DW_XCD=1; off by default): built in round 3 on the PMC evidence above, measured neutral on every
+  // B7 layer shape (forward 3x3 +-4 %, 5x5 and the fused backward +-1 %, profiles/r03_dw_xcd.txt): the halo re-reads are served
+  // by the Infinity Cache, which the fabric-side counter includes
+  static const int xcd_on = getenv("MX_DW_XCD") ? atoi(getenv("MX_DW_XCD")) : 0;
+  const long planes = (long)grid.y * N;
+  if (xcd_on && grid.x > 1 && planes >= 64) {
+    a.xcd = 1;
+    grid = dim3((unsigned)(cdiv(planes, 8) * 8 * grid.x), 1, 1);
   }
   DW_DISPATCH(FWD_S1, FWD_S2, K, S, grid, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();
@@ -809,8 +862,8 @@ int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift,
 // number of partial rows mx_dwconv_bwd_fused writes (BN0 sums [rows][2][C] and dW scratch [rows][C*K*K])
 int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C, int K) {
   if (N <= 0 || H <= 0 || Wd <= 0 || C <= 0 || (K != 3 && K != 5)) return MX_EARG;
-  int tx, ty, tpb, groups;
-  dw_fused_geom(N, H, Wd, C, K, &tx, &ty, &tpb, &groups);
+  int tx, ty, tpb, groups, gpp;
+  dw_fused_geom(N, H, Wd, C, K, &tx, &ty, &tpb, &groups, &gpp);
   return groups;
 }
 
@@ -830,8 +883,13 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
   a.x = X; a.a0 = a0; a.b0 = b0; a.w = W; a.res = residual; a.gx = gX; a.dwpart = dw_scratch; a.part = a0 ? part : nullptr;
   a.N = N; a.H = H; a.W = Wd; a.C = C; a.pad = pad_lo;
   int groups;
-  dw_fused_geom(N, H, Wd, C, K, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups);
+  dw_fused_geom(N, H, Wd, C, K, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups, &a.gpp);
   dim3 grid(groups, cdiv(C, CB), 1);
+  a.chunks = grid.y;
+  if (a.gpp > 0) {
+    a.xcd = 1;
+    grid = dim3((unsigned)(cdiv((long)a.chunks * N, 8) * 8 * a.gpp), 1, 1);
+  }
   const int shape = dw_fused_shape(H, Wd, K);
   if (shape) {
     static bool big_lds = false;                         // 14 x 28 tiles: 72 KB (5x5) / 60 KB (3x3) of static LDS

@@ -849,7 +849,9 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][PW[t]], av[i][PX[t]], acc[i][j], 0, 0, 0);
+#ifndef MX_LAB_NOSYNC
     __syncthreads();
+#endif
   }
   // epilogue: acc[i][j][4 gq + e] = C[m = 32 i + l31][n = 32 j + 8 gq + 4 hf + e].  Bias / residual / relu / statistics in
   // registers; the values then cross a per-wave LDS patch [32][WNC] so that a store instruction writes whole rows

@@ -29,11 +29,13 @@ def family(n):
         return "gemm_kernel<%s>" % {"0": "NT fwd", "1": "NN dgrad", "2": "TN wgrad"}[m.group(1)]
     if n.startswith("gemm_nt_kernel"):
         return "gemm_nt_kernel<NT fwd + dgrad>"
+    if n.startswith("gemm_nt_split_kernel"):
+        return "gemm_nt_split_kernel<NT fwd + dgrad, split arithmetic>"
     if n.startswith("dw_bwd_fused_kernel"):
         return "dw_bwd_fused_kernel<%s>" % re.match(r"dw_bwd_fused_kernel<(\d)", n).group(1)
     return re.sub(r"<.*", "", n)
 
-GEMM_FAMILIES = ("gemm_kernel", "gemm_nt_kernel", "wgrad_small_kernel", "wgrad_tile_kernel")
+GEMM_FAMILIES = ("gemm_kernel", "gemm_nt_kernel", "gemm_nt_split_kernel", "wgrad_small_kernel", "wgrad_tile_kernel", "wgrad_split_kernel")
 GEMM_AUX = ("wgrad_parts_reduce_kernel",)      # bytes belong to the weight-gradient GEMMs, launches are not counted
 
 dirs = dict(a.split("=") for a in sys.argv[2:])

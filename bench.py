@@ -329,6 +329,28 @@ def main():
             dts = float(t)
         beside = {"value": a.batch * world * a.steps / dts, "unit": "images/sec", "ms_per_step": dts / a.steps * 1e3,
                   "arithmetic": ARITH_TEXT[other]}
+        # the same per-launch events in this arithmetic, so that both roofline fractions are in the line
+        main_pairs, main_dw = timer.pairs, timer.dw
+        timer.pairs, timer.dw = [], []
+        muscle_amd.set_gemm_mode(ARITH_MODE[other])
+        engine.WGRAD_SIDE_STREAM = False
+        timer.on = (rank == 0)
+        for _ in range(inst_steps):
+            eager_step()
+        barrier()
+        timer.on = False
+        engine.WGRAD_SIDE_STREAM = overlap
+        muscle_amd.set_gemm_mode(ARITH_MODE[a.arith])
+        if rank == 0:
+            o_ms, o_n = timer.total_ms()
+            o_peak, o_share = timer.blended_peak()
+            o_flops = pointwise_flops_per_image(cfg, a.size) * a.batch * inst_steps
+            if a.epoch < 12 and o_ms > 0:
+                o_ach = o_flops / (o_ms * 1e-3) / 1e12
+                beside["roofline"] = {"bound": "mfma", "achieved": o_ach, "peak": o_peak, "unit": "TFLOP/s", "frac": o_ach / o_peak,
+                                      "flop_share_split": o_share, "gemm_ms_per_step": o_ms / inst_steps,
+                                      "avg_launch_us": o_ms * 1e3 / max(o_n, 1)}
+        timer.pairs, timer.dw = main_pairs, main_dw
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

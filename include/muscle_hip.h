@@ -319,7 +319,10 @@ int mx_er_bwd(const float* cams, const float* sgcs, const float* lwb, const unsi
  * of the step, where k = int(0.2 * sum(labels) * H * W) (train_mcl.py:178,188) changes with every batch */
 int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
                  const int* k_dev, unsigned* krem, unsigned* prefix, unsigned long long* sum_gt, unsigned* cnt_eq, unsigned* hcnt,
-                 unsigned long long* hsum, float* loss, void* stream);
+                 unsigned long long* hsum, float* vals /* optional scratch [N*K*H*W]: see below */, float* loss, void* stream);
+/* vals: with it the first digit pass parks |diff|*mask for the planes of the labelled classes (the rest of the buffer is
+ * never touched) and the two later passes histogram those 4-byte values instead of re-evaluating upsample + softmaxes per
+ * pixel; NULL = three evaluating passes, nothing of size H*W allocated.  Same result bit for bit. */
 /* ws: mx_er_lr_bwd_ws bytes (64-bit fixed-point accumulators of the band kernel; plain scratch, no counter header) */
 long mx_er_lr_bwd_ws(int N, int h, int w, int L, int K);
 int mx_er_lr_bwd(const float* cam, const float* sgc, const float* lwb, const unsigned* prefix, const unsigned* krem,

@@ -559,7 +559,7 @@ __device__ __forceinline__ int lr_pixel(const float* cam, const float* sgc, int 
 
 __global__ __launch_bounds__(256) void er_lr_hist_kernel(const float* cam, const float* sgc, const float* lwb, int h, int w, int L,
                                                          int K, int H, int W, int shift, int nbits, unsigned himask,
-                                                         const unsigned* prefix, unsigned* hcnt, er_fix_t* hsum) {
+                                                         const unsigned* prefix, unsigned* hcnt, er_fix_t* hsum, float* vals) {
   __shared__ unsigned lc[RBINS];
   __shared__ er_fix_t ls[RBINS];
   const int n = blockIdx.y;
@@ -577,11 +577,48 @@ __global__ __launch_bounds__(256) void er_lr_hist_kernel(const float* cam, const
       float m = lwb[n * K + k];
       if (m == 0.f) continue;
       float v = fabsf(a[k] - b[k]) * m;
+      // first pass of the select: park the value (planes of the ACTIVE classes only, ~12 % of [N,K,H,W]) so that the two
+      // later digit passes read 4 bytes per value instead of re-evaluating the upsample and both softmaxes per pixel
+      if (vals) vals[((long)n * K + k) * HW + p] = v;
       unsigned key = __float_as_uint(v);
       if (key != 0u && (key & himask) == pf) {
         unsigned bb = (key >> shift) & dm;
         atomicAdd(&lc[bb], 1u);
         atomicAdd(&ls[bb], er_fix(v));
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < RBINS; i += 256)
+    if (lc[i]) { atomicAdd(&hcnt[n * RBINS + i], lc[i]); atomicAdd(&hsum[n * RBINS + i], ls[i]); }
+}
+
+// digit passes 2 and 3 from the parked values: planes of the active classes of sample blockIdx.y, pixel chunk blockIdx.x
+__global__ __launch_bounds__(256) void er_vals_hist_kernel(const float* vals, const float* lwb, int K, long HW, int shift, int nbits,
+                                                           unsigned himask, const unsigned* prefix, unsigned* hcnt, er_fix_t* hsum) {
+  __shared__ unsigned lc[RBINS];
+  __shared__ er_fix_t ls[RBINS];
+  const int n = blockIdx.y;
+  for (int i = threadIdx.x; i < RBINS; i += 256) { lc[i] = 0; ls[i] = 0; }
+  __syncthreads();
+  const unsigned pf = prefix[n], dm = (1u << nbits) - 1u;
+  const long per = ((HW + gridDim.x - 1) / gridDim.x + 3) & ~3L;        // multiples of 4 pixels: 16-byte loads
+  const long beg = blockIdx.x * per, end = min(HW, beg + per);
+  for (int k = 0; k < K; ++k) {
+    if (lwb[n * K + k] == 0.f) continue;
+    const float* row = vals + ((long)n * K + k) * HW;
+    for (long i = beg + 4 * threadIdx.x; i < end; i += 1024) {
+      float v4[4];
+      if (i + 3 < end && (HW & 3) == 0) { const float4 q = ld4(row + i); v4[0] = q.x; v4[1] = q.y; v4[2] = q.z; v4[3] = q.w; }
+      else { for (int e = 0; e < 4; ++e) v4[e] = (i + e < end) ? row[i + e] : 0.f; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const unsigned key = __float_as_uint(v4[e]);
+        if (key != 0u && (key & himask) == pf) {
+          const unsigned bb = (key >> shift) & dm;
+          atomicAdd(&lc[bb], 1u);
+          atomicAdd(&ls[bb], er_fix(v4[e]));
+        }
       }
     }
   }
@@ -752,7 +789,7 @@ extern "C" {
 // state buffers as mx_er_fwd (prefix and sum_gt zeroed by the caller); nothing of size H*W is allocated.
 int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, int h, int w, int L, int K, int H, int W, long k,
                  const int* k_dev, unsigned* krem, unsigned* prefix, unsigned long long* sum_gt, unsigned* cnt_eq, unsigned* hcnt,
-                 unsigned long long* hsum, float* loss, void* stream) {
+                 unsigned long long* hsum, float* vals, float* loss, void* stream) {
   MX_CHECK_ARG(cam && sgc && lwb && krem && prefix && sum_gt && cnt_eq && hcnt && hsum && loss, "er_lr_fwd: null pointer");
   MX_CHECK_ARG(N > 0 && h > 0 && w > 0 && K >= 2 && K <= KMAX && K <= L && L % 4 == 0 && H > 0 && W > 0, "er_lr_fwd: bad extents (L must be a multiple of 4)");
   MX_CHECK_ARG((((uintptr_t)cam | (uintptr_t)sgc) & 15) == 0, "er_lr_fwd: maps must be 16-byte aligned");
@@ -769,8 +806,12 @@ int mx_er_lr_fwd(const float* cam, const float* sgc, const float* lwb, int N, in
   for (int ps = 0; ps < 3; ++ps) {
     hipMemsetAsync(hcnt, 0, sizeof(unsigned) * N * RBINS, st);
     hipMemsetAsync(hsum, 0, sizeof(er_fix_t) * N * RBINS, st);
-    hipLaunchKernelGGL(er_lr_hist_kernel, dim3(chunks, N), dim3(256), 0, st, cam, sgc, lwb, h, w, L, K, H, W, shifts[ps], bits[ps],
-                       himask[ps], prefix, hcnt, hsum);
+    if (ps == 0 || !vals)
+      hipLaunchKernelGGL(er_lr_hist_kernel, dim3(chunks, N), dim3(256), 0, st, cam, sgc, lwb, h, w, L, K, H, W, shifts[ps], bits[ps],
+                         himask[ps], prefix, hcnt, hsum, ps == 0 ? vals : (float*)nullptr);
+    else
+      hipLaunchKernelGGL(er_vals_hist_kernel, dim3(chunks, N), dim3(256), 0, st, (const float*)vals, lwb, K, HW, shifts[ps], bits[ps],
+                         himask[ps], prefix, hcnt, hsum);
     hipLaunchKernelGGL(er_scan_kernel, dim3(N), dim3(64), 0, st, hcnt, hsum, shifts[ps], bits[ps], krem, prefix, sum_gt,
                        cnt_eq, N);
   }

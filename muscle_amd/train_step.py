@@ -3,6 +3,7 @@ script-level helpers it uses (cam_maxnorm / cam_softmaxnorm, train_mcl.py:21-36;
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional
 
 import torch
@@ -11,6 +12,7 @@ from . import loss_multilabel as L
 from ._lib import call, lib, ptr, stream
 
 _RBINS = 2048
+ER_PARK_VALUES = os.environ.get("MUSCLE_ER_PARK", "1") == "1"     # fused ER: later digit passes read parked values (measured: DESIGN.md 3)
 
 
 class _SoftmaxNorm(torch.autograd.Function):
@@ -92,8 +94,11 @@ class _ERLossLowRes(torch.autograd.Function):
         hcnt = torch.empty(N * _RBINS, dtype=torch.int32, device=dev)
         hsum = torch.empty(N * _RBINS, dtype=torch.int64, device=dev)
         loss = torch.empty(1, dtype=torch.float32, device=dev)
+        # scratch for the parked values of the select: address space for every plane, only the labelled classes' planes are
+        # ever written or read (~12 %)
+        vals = torch.empty(N * K * H * W, dtype=torch.float32, device=dev) if ER_PARK_VALUES else None
         call("mx_er_lr_fwd", ptr(cam_lr), ptr(sgc_lr), ptr(lwb), N, h, w, L, K, H, W, int(k), ptr(k_dev), ptr(st_u[0]), ptr(st_u[1]),
-             ptr(sum_gt), ptr(st_u[2]), ptr(hcnt), ptr(hsum), ptr(loss), stream())
+             ptr(sum_gt), ptr(st_u[2]), ptr(hcnt), ptr(hsum), ptr(vals), ptr(loss), stream())
         ctx.save_for_backward(cam_lr, sgc_lr, lwb, st_u)
         ctx.dims = (int(k), H, W)
         ctx.k_dev = k_dev

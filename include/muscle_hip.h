@@ -162,7 +162,7 @@ int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* g
  * rows part[mx_dwconv_fwd_parts(N,Ho,Wo,S)][2][C]; pooled (optional, inference, excludes stats):
  * pooled[n][c] = sum_hw swish(pool_scale[c]*Y + pool_shift[c]), the SE squeeze of model.py:81-82 under eval-mode BN1
  * (ws: mx_dwconv_fwd_ws bytes, only read when pooled is given) */
-int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S);
+int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int C, int S);
 long mx_dwconv_fwd_ws(int N, int Ho, int Wo, int C, int S);
 int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats,
                   const float* pool_scale, const float* pool_shift, float* pooled, void* ws, long ws_bytes, int N,

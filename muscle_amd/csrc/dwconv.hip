@@ -27,13 +27,12 @@ struct DwArgs {
   const float* ps;     // fwd, inference: BN1 scale / shift of the OUTPUT (running statistics) ...
   const float* pb;
   float* pooled;       // ... and the SE squeeze sums pooled[n][c] = sum_hw swish(ps*y + pb), or null
-  float* poolpart;     // per-tile partial squeeze rows [tiles][N][C] and the arrival counters [N][channel chunks] (mx_last_arriver)
+  float* poolpart;     // per-group partial squeeze rows [gpp][N][C] and the arrival counters [N][channel chunks] (mx_last_arriver)
   unsigned* counters;
   int N, H, W, Ho, Wo, C, pad;
   int tiles_x, tiles_y;
   int tiles_per_block;   // bwd_weight
-  int xcd;               // fwd: 1 = 1-D grid, the tiles of one (sample, channel chunk) plane run on ONE XCD (see dw_fwd_kernel)
-  int chunks;            // fwd: channel chunks (the y extent of the logical grid)
+  int gpp;               // fwd: groups of tiles per sample (inference squeeze), 0 = groups run over the whole (sample, tile) sequence
 };
 
 __device__ __forceinline__ float4 dw_load(const DwArgs& a, const float* p, int c) {
@@ -95,6 +94,13 @@ __device__ __forceinline__ void dw_stage_input(const DwArgs& a, float4* tile, in
 // ---------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------
+// A workgroup walks `tiles_per_block` consecutive tiles of one channel chunk (weights staged once) and leaves ONE partial: the
+// statistics row of its tiles (training) or its share of a sample's squeeze sum (inference).  One tile per workgroup, the
+// round-1/2 form, cost a partial row and - with the ordered squeeze of round 3 - a write-through store, a drain and an arrival
+// ticket per TILE: the inference forward's depthwise kernels ran 45 % over their training twins.
+//   gpp == 0 (training): group g covers tiles [g tpb, (g+1) tpb) of the (sample, tile) sequence, statistics row g;
+//   gpp  > 0 (inference squeeze): a sample's tiles are cut into gpp groups that do not straddle samples; group (n, gi) parks its
+//            partial squeeze row and the last of the gpp groups to arrive adds them in group order (mx_last_arriver).
 template <int K, int S, int TH, int TW, int OX>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
@@ -104,106 +110,93 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   __shared__ __attribute__((aligned(16))) float red[4][2 * CB];     // one row per wave: the four waves are added in wave order (LDS atomics gave sums
   __shared__ unsigned last_flag;       // whose last bit depended on which wave came first)
   const int tid = threadIdx.x;
-  // Logical grid (tile, channel chunk, sample).  Neighbouring tiles share their halo; the hardware deals workgroups to the 8
-  // XCDs round-robin, so with a plain 3-D grid the neighbours of a tile sit on seven OTHER XCDs and every halo pixel crosses
-  // the fabric once per tile that touches it (PMC: 351 MB fetched per launch for a 221 MB tensor).  XCD-aware ids: workgroup L
-  // goes to XCD L % 8; all tiles of one (sample, chunk) plane get ids of the same residue, so the halo is an L2 hit.
   const int ntile = a.tiles_x * a.tiles_y;
-  int tile_id, chunk, n;
-  if (a.xcd) {
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int plane = (j / ntile) * 8 + xcd;
-    tile_id = j % ntile;
-    if (plane >= a.chunks * a.N) return;
-    chunk = plane % a.chunks; n = plane / a.chunks;
+  const int c0 = blockIdx.y * CB;
+  long t_beg, t_end;
+  int n_fix = 0, gi = 0;
+  if (a.gpp > 0) {
+    n_fix = blockIdx.x / a.gpp; gi = blockIdx.x % a.gpp;
+    t_beg = (long)n_fix * ntile + (long)gi * a.tiles_per_block;
+    t_end = min((long)(n_fix + 1) * ntile, t_beg + a.tiles_per_block);
   } else {
-    tile_id = blockIdx.x; chunk = blockIdx.y; n = blockIdx.z;
+    t_beg = (long)blockIdx.x * a.tiles_per_block;
+    t_end = min((long)a.N * ntile, t_beg + a.tiles_per_block);
   }
-  const int tx = tile_id % a.tiles_x, ty = tile_id / a.tiles_x;
-  const int c0 = chunk * CB;
-  const int oy0 = ty * TH, ox0 = tx * TW;
   dw_stage_weights<K>(a, wl, c0, tid);
-  dw_stage_input<K, S, TH, TW>(a, tile, n, oy0, ox0, c0, tid);
-  __syncthreads();
-
   const int c4 = tid % C4B, q = tid / C4B;
   const int oyl = q / (TW / OX), oxl = (q % (TW / OX)) * OX;
-  float4 acc[OX];
+  const int c = c0 + 4 * c4;
+  const int wave = tid >> 6;
+  float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0), p = make_float4(0, 0, 0, 0);
+  float4 psc = make_float4(0, 0, 0, 0), psh = psc;
+  if (a.pooled && c < a.C) { psc = ld4(a.ps + c); psh = ld4(a.pb + c); }
+  for (long t = t_beg; t < t_end; ++t) {
+    const int n = (int)(t / ntile), rem = (int)(t % ntile);
+    const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
+    __syncthreads();                               // the previous tile's readers are done (first pass: the weights are staged)
+    dw_stage_input<K, S, TH, TW>(a, tile, n, oy0, ox0, c0, tid);
+    __syncthreads();
+    float4 acc[OX];
 #pragma unroll
-  for (int o = 0; o < OX; ++o) acc[o] = make_float4(0, 0, 0, 0);
-  // one kernel row at a time (8-12 input float4 live): fully unrolling ky for k=5 took 256 VGPRs = 1 wave/SIMD
+    for (int o = 0; o < OX; ++o) acc[o] = make_float4(0, 0, 0, 0);
+    // one kernel row at a time (8-12 input float4 live): fully unrolling ky for k=5 took 256 VGPRs = 1 wave/SIMD
 #pragma unroll 1
-  for (int ky = 0; ky < K; ++ky) {
-    float4 in[(OX - 1) * S + K];
+    for (int ky = 0; ky < K; ++ky) {
+      float4 in[(OX - 1) * S + K];
 #pragma unroll
-    for (int j = 0; j < (OX - 1) * S + K; ++j) in[j] = tile[((oyl * S + ky) * IW + oxl * S + j) * C4B + c4];
+      for (int j = 0; j < (OX - 1) * S + K; ++j) in[j] = tile[((oyl * S + ky) * IW + oxl * S + j) * C4B + c4];
 #pragma unroll
-    for (int kx = 0; kx < K; ++kx) {
-      float4 w = ld4(wl + (ky * K + kx) * CB + 4 * c4);
+      for (int kx = 0; kx < K; ++kx) {
+        float4 w = ld4(wl + (ky * K + kx) * CB + 4 * c4);
 #pragma unroll
-      for (int o = 0; o < OX; ++o) {
-        float4 v = in[o * S + kx];
-        acc[o].x += w.x * v.x; acc[o].y += w.y * v.y; acc[o].z += w.z * v.z; acc[o].w += w.w * v.w;
+        for (int o = 0; o < OX; ++o) {
+          float4 v = in[o * S + kx];
+          acc[o].x += w.x * v.x; acc[o].y += w.y * v.y; acc[o].z += w.z * v.z; acc[o].w += w.w * v.w;
+        }
       }
     }
-  }
-  const int c = c0 + 4 * c4, oy = oy0 + oyl;
-  const int wave = tid >> 6;
-  float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0);
-  if (c < a.C && oy < a.Ho) {
+    const int oy = oy0 + oyl;
+    if (c < a.C && oy < a.Ho) {
 #pragma unroll
-    for (int o = 0; o < OX; ++o) {
-      int ox = ox0 + oxl + o;
-      if (ox < a.Wo) {
-        st4(a.y + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + c, acc[o]);
-        s.x += acc[o].x; s.y += acc[o].y; s.z += acc[o].z; s.w += acc[o].w;
-        sq.x += acc[o].x * acc[o].x; sq.y += acc[o].y * acc[o].y; sq.z += acc[o].z * acc[o].z; sq.w += acc[o].w * acc[o].w;
+      for (int o = 0; o < OX; ++o) {
+        int ox = ox0 + oxl + o;
+        if (ox < a.Wo) {
+          st4(a.y + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + c, acc[o]);
+          if (a.pooled) {
+            // Inference (eval-mode BatchNorm: its affine is known before the batch is seen): the squeeze of the SE block,
+            // sum over the image of swish(bn1(y)), leaves with the tiles instead of costing a second pass over d (model.py:81-82)
+            p.x += swishf_(psc.x * acc[o].x + psh.x); p.y += swishf_(psc.y * acc[o].y + psh.y);
+            p.z += swishf_(psc.z * acc[o].z + psh.z); p.w += swishf_(psc.w * acc[o].w + psh.w);
+          } else {
+            s.x += acc[o].x; s.y += acc[o].y; s.z += acc[o].z; s.w += acc[o].w;
+            sq.x += acc[o].x * acc[o].x; sq.y += acc[o].y * acc[o].y; sq.z += acc[o].z * acc[o].z; sq.w += acc[o].w * acc[o].w;
+          }
+        }
       }
     }
   }
   if (a.pooled) {
-    // Inference (eval-mode BatchNorm: its affine is known before the batch is seen): the squeeze of the SE block,
-    // sum over the image of swish(bn1(y)), leaves with the tile instead of costing a second pass over d (model.py:81-82)
-    float4 p = make_float4(0, 0, 0, 0);
-    if (c < a.C && oy < a.Ho) {
-      const float4 sc = ld4(a.ps + c), sh = ld4(a.pb + c);
-#pragma unroll
-      for (int o = 0; o < OX; ++o) {
-        if (ox0 + oxl + o < a.Wo) {
-          p.x += swishf_(sc.x * acc[o].x + sh.x); p.y += swishf_(sc.y * acc[o].y + sh.y);
-          p.z += swishf_(sc.z * acc[o].z + sh.z); p.w += swishf_(sc.w * acc[o].w + sh.w);
-        }
-      }
-    }
 #pragma unroll
     for (int o = 8; o < 64; o <<= 1) {
       p.x += __shfl_xor(p.x, o, 64); p.y += __shfl_xor(p.y, o, 64); p.z += __shfl_xor(p.z, o, 64); p.w += __shfl_xor(p.w, o, 64);
     }
+    __syncthreads();
     if ((tid & 63) < C4B) st4(&red[wave][4 * c4], p);
     __syncthreads();
     const bool own = tid < CB && c0 + tid < a.C;
     const float v = own ? ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid] : 0.f;
-    if (ntile == 1) {
-      if (own) a.pooled[(long)n * a.C + c0 + tid] = v;
+    if (a.gpp == 1) {
+      if (own) a.pooled[(long)n_fix * a.C + c0 + tid] = v;
       return;
     }
-    // the tiles of a sample are joined by the last workgroup to arrive, in tile order (no atomics: the squeeze, and with it
+    // the groups of a sample are joined by the last workgroup to arrive, in group order (no atomics: the squeeze, and with it
     // the whole eval forward, gives the same bits whatever the batch size and the run)
-    if (own) mx_st_wt(a.poolpart + ((long)tile_id * a.N + n) * a.C + c0 + tid, v);
-    if (!mx_last_arriver(a.counters + n * a.chunks + chunk, ntile, &last_flag)) return;
-    const int cl = tid & 31, rl = tid >> 5;
-    float t = 0.f;
-    if (c0 + cl < a.C)
-      for (int pt = rl; pt < ntile; pt += 8) t += a.poolpart[((long)pt * a.N + n) * a.C + c0 + cl];
-    __syncthreads();
-    (&red[0][0])[rl * 32 + cl] = t;
-    __syncthreads();
+    if (own) mx_st_wt(a.poolpart + ((long)gi * a.N + n_fix) * a.C + c0 + tid, v);
+    if (!mx_last_arriver(a.counters + n_fix * gridDim.y + blockIdx.y, a.gpp, &last_flag)) return;
     if (own) {
-      const float* r = &red[0][0];
-      float u = r[tid];
-#pragma unroll
-      for (int k = 1; k < 8; ++k) u += r[k * 32 + tid];
-      a.pooled[(long)n * a.C + c0 + tid] = u;
+      float u = a.poolpart[(long)n_fix * a.C + c0 + tid];
+      for (int g = 1; g < a.gpp; ++g) u += a.poolpart[((long)g * a.N + n_fix) * a.C + c0 + tid];
+      a.pooled[(long)n_fix * a.C + c0 + tid] = u;
     }
     return;
   }
@@ -214,12 +207,13 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       s.x += __shfl_xor(s.x, o, 64); s.y += __shfl_xor(s.y, o, 64); s.z += __shfl_xor(s.z, o, 64); s.w += __shfl_xor(s.w, o, 64);
       sq.x += __shfl_xor(sq.x, o, 64); sq.y += __shfl_xor(sq.y, o, 64); sq.z += __shfl_xor(sq.z, o, 64); sq.w += __shfl_xor(sq.w, o, 64);
     }
+    __syncthreads();
     if ((tid & 63) < C4B) { st4(&red[wave][4 * c4], s); st4(&red[wave][CB + 4 * c4], sq); }
     __syncthreads();
     if (tid < 2 * CB) {
       const int cc = tid % CB;
       if (c0 + cc < a.C) {
-        float* prow = a.stats + ((long)n * ntile + tile_id) * 2 * a.C;   // one partial row per (sample, tile)
+        float* prow = a.stats + (long)blockIdx.x * 2 * a.C;                      // one partial row per workgroup
         prow[(tid / CB) * a.C + c0 + cc] = ((red[0][tid] + red[1][tid]) + red[2][tid]) + red[3][tid];
       }
     }
@@ -718,7 +712,7 @@ static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int*
   *tpb = (int)((ntiles + g - 1) / g);
   *groups = cdiv(ntiles, *tpb);
   *gpp = 0;
-  static const int xcd_on = getenv("MX_DW_XCD") ? atoi(getenv("MX_DW_XCD")) : 0;      // (measured neutral, see mx_dwconv_fwd)
+  static const int xcd_on = getenv("MX_DW_XCD") ? atoi(getenv("MX_DW_XCD")) : 0;      // XCD-aware ids: built on PMC evidence of 1.4-1.6x fabric-side over-read, measured neutral (profiles/r03_dw_xcd.txt): the Infinity Cache serves the halo
   if (xcd_on && *tpb < ntile && (long)chunks * N >= 64) {
     *gpp = cdiv(ntile, *tpb);
     *groups = N * (*gpp);
@@ -755,19 +749,47 @@ static int dw_check(const DwArgs& a, int K, int S, const char* who) {
 
 extern "C" {
 
-// Y = dwconv(act(X)); act = swish(scale*x+shift) if scale != null. stats[2C] += (sum Y, sum Y^2).
+// tile groups of the forward: ~MX_DWF_GROUPS workgroups per launch (default 4096), each walking tpb consecutive tiles
+static void dw_fwd_geom(int N, int Ho, int Wo, int C, int S, bool pooled, int* tiles_x, int* tiles_y, int* tpb, int* groups, int* gpp) {
+  *tiles_x = cdiv(Wo, S == 1 ? 16 : 8); *tiles_y = cdiv(Ho, 8);
+  const int ntile = (*tiles_x) * (*tiles_y);
+  const long ntiles = (long)N * ntile;
+  const int chunks = cdiv(C, CB);
+  static const long target = getenv("MX_DWF_GROUPS") ? atol(getenv("MX_DWF_GROUPS")) : 4096;
+  long g = target / chunks;
+  if (g < 1) g = 1;
+  if (g > ntiles) g = ntiles;
+  if (pooled) {
+    // groups do not straddle samples: gpp per sample, at least one
+    long per = g / N;
+    if (per < 1) per = 1;
+    if (per > ntile) per = ntile;
+    *tpb = cdiv(ntile, per);
+    *gpp = cdiv(ntile, *tpb);
+    *groups = N * (*gpp);
+  } else {
+    *tpb = (int)((ntiles + g - 1) / g);
+    *groups = cdiv(ntiles, *tpb);
+    *gpp = 0;
+  }
+}
+
+// Y = dwconv(act(X)); act = swish(scale*x+shift) if scale != null.
 // number of partial-statistics rows mx_dwconv_fwd writes
-int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int S) {
-  if (N <= 0 || Ho <= 0 || Wo <= 0 || (S != 1 && S != 2)) return MX_EARG;
-  return N * cdiv(Ho, 8) * cdiv(Wo, S == 1 ? 16 : 8);
+int mx_dwconv_fwd_parts(int N, int Ho, int Wo, int C, int S) {
+  if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (S != 1 && S != 2)) return MX_EARG;
+  int tx, ty, tpb, groups, gpp;
+  dw_fwd_geom(N, Ho, Wo, C, S, false, &tx, &ty, &tpb, &groups, &gpp);
+  return groups;
 }
 
 // bytes of scratch mx_dwconv_fwd needs when it also produces the SE squeeze sums (`pooled`); 0 = none
 long mx_dwconv_fwd_ws(int N, int Ho, int Wo, int C, int S) {
   if (N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || (S != 1 && S != 2)) return MX_EARG;
-  const long tiles = (long)cdiv(Ho, 8) * cdiv(Wo, S == 1 ? 16 : 8);
-  if (tiles == 1) return 0;
-  return MX_WS_COUNTER_BYTES + tiles * N * C * 4;
+  int tx, ty, tpb, groups, gpp;
+  dw_fwd_geom(N, Ho, Wo, C, S, true, &tx, &ty, &tpb, &groups, &gpp);
+  if (gpp <= 1) return 0;
+  return MX_WS_COUNTER_BYTES + (long)gpp * N * C * 4;
 }
 
 int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const float* W, float* Y, float* stats,
@@ -780,25 +802,15 @@ int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const 
   a.N = N; a.H = H; a.W = Wd; a.Ho = Ho; a.Wo = Wo; a.C = C; a.pad = pad_lo;
   MX_CHECK_ARG(X && W && Y, "dwconv_fwd: null pointer");
   if (int e = dw_check(a, K, S, "dwconv_fwd")) return e;
-  const int TH = 8, TW = (S == 1) ? 16 : 8;
-  a.tiles_x = cdiv(Wo, TW); a.tiles_y = cdiv(Ho, TH);
-  dim3 grid(a.tiles_x * a.tiles_y, cdiv(C, CB), N);
-  a.chunks = grid.y;
-  if (pooled && grid.x > 1) {
+  int groups;
+  dw_fwd_geom(N, Ho, Wo, C, S, pooled != nullptr, &a.tiles_x, &a.tiles_y, &a.tiles_per_block, &groups, &a.gpp);
+  dim3 grid(groups, cdiv(C, CB), 1);
+  if (pooled && a.gpp > 1) {
     const long need = mx_dwconv_fwd_ws(N, Ho, Wo, C, S);
     MX_CHECK_ARG(ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0, "dwconv_fwd: pooled needs %ld bytes of scratch (mx_dwconv_fwd_ws)", need);
     MX_CHECK_ARG((long)N * grid.y <= MX_WS_COUNTERS, "dwconv_fwd: N=%d x %d channel chunks exceed the %d arrival counters", N, (int)grid.y, MX_WS_COUNTERS);
     a.counters = reinterpret_cast<unsigned*>(ws);
     a.poolpart = reinterpret_cast<float*>((char*)ws + MX_WS_COUNTER_BYTES);
-  }
-  // XCD-aware workgroup ids (MX_DW_XCD=1; off by default): built in round 3 on the PMC evidence above, measured neutral on every
-  // B7 layer shape (forward 3x3 +-4 %, 5x5 and the fused backward +-1 %, profiles/r03_dw_xcd.txt): the halo re-reads are served
-  // by the Infinity Cache, which the fabric-side counter includes
-  static const int xcd_on = getenv("MX_DW_XCD") ? atoi(getenv("MX_DW_XCD")) : 0;
-  const long planes = (long)grid.y * N;
-  if (xcd_on && grid.x > 1 && planes >= 64) {
-    a.xcd = 1;
-    grid = dim3((unsigned)(cdiv(planes, 8) * 8 * grid.x), 1, 1);
   }
   DW_DISPATCH(FWD_S1, FWD_S2, K, S, grid, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();

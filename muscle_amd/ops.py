@@ -320,7 +320,7 @@ def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, want
     """pool=(scale, shift) (inference): also returns the SE squeeze sums [N, C] of swish(scale*Y + shift)."""
     N, H, Wd, C = X.shape
     Y = _f32(N, Ho, Wo, C, device=X.device)
-    stats = _f32(lib().mx_dwconv_fwd_parts(N, Ho, Wo, S), 2, C, device=X.device) if want_stats else None
+    stats = _f32(lib().mx_dwconv_fwd_parts(N, Ho, Wo, C, S), 2, C, device=X.device) if want_stats else None
     pooled = _f32(N, C, device=X.device) if pool is not None else None
     ws, wsn = _scratch(X.device, lib().mx_dwconv_fwd_ws(N, Ho, Wo, C, S)) if pool is not None else (None, 0)
     call("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),

@@ -10,6 +10,7 @@ from muscle_amd._lib import call, ptr, stream
 ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="efficientnet-b7"); ap.add_argument("--batch", type=int, default=64)
 ap.add_argument("--sizes", default="448,512,768"); ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--forward-only", action="store_true", help="only the batched eval forward (for kernel profiles)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
@@ -32,6 +33,8 @@ for size in (int(s) for s in a.sizes.split(",")):
     print(f"{a.model} eval forward cam_lr  batch {a.batch} {size}x{size}: {dt*1e3:8.1f} ms  {a.batch/dt:7.1f} img/s  "
           f"{fl/dt/1e12:6.1f} TFLOP/s  peak mem {torch.cuda.max_memory_allocated()/1e9:.1f} GB", flush=True)
     del x
+if a.forward_only:
+    sys.exit(0)
 # post-processing of one image: 8 passes (4 scales x flip) accumulated into [20,375,500] for CAM and SGC, then normalised
 H, W, K = 375, 500, 21
 acc = torch.zeros(K - 1, H, W, device=dev)

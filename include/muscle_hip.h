@@ -341,9 +341,10 @@ int mx_adam(float* p, const float* g, float* m, float* v, long n, float lr, floa
 int mx_maxnorm(const float* x, const float* gy, float* out, float* stats, int NK, long HW, int bwd, void* stream);
 
 /* PixPro (loss_multilabel.py:93-105) on NCHW maps (optionally multiplied by mask[n,k], train_mcl.py:209); coords are
- * int64 [N,4] = (h0,w0,hl,wl).  loss must hold 1.0 and g1 zeros on entry; g1 = d loss / d f1. */
+ * int64 [N,4] = (h0,w0,hl,wl).  loss[0] is overwritten; g1 must hold zeros on entry; g1 = d loss / d f1.  ws: N*8 bytes (the
+ * per-sample cosine sums are 64-bit fixed-point integers: same bits every run). */
 int mx_pixpro(const float* f1, const float* f2, const float* mask, const long* coord1, const long* coord2, float* loss, float* g1,
-              int N, int K, int H, int W, void* stream);
+              int N, int K, int H, int W, void* ws, long ws_bytes, void* stream);
 
 /* F.normalize(x, dim=1) on NCHW (train_mcl.py:218-219) and its backward */
 int mx_chan_l2norm(const float* x, const float* gy, float* out, int N, int K, long HW, int bwd, void* stream);
@@ -351,7 +352,8 @@ int mx_chan_l2norm(const float* x, const float* gy, float* out, int N, int K, lo
 /* torchutils.get_dynamic_crops (torchutils.py:217-291) pieces.  table rows of 8 ints {sample,y0,x0,lh,lw,rh,rw,out_off}:
  * out[out_off + r*rw + c, 0..23] = bilinear_align_corners(src[sample,:,y0:y0+lh,x0:x0+lw] -> (rh,rw)), 21 classes + 0 pad */
 int mx_crop_resize(const float* src, const int* table, int ncrops, float* out, int K, int H, int W, void* stream);
-int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* gsrc, int K, int H, int W, void* stream);
+/* adjoint: gsrc[nsamples,K,H,W] += ...; ordered gather (one adder per element, crops of a sample in table order) */
+int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* gsrc, int nsamples, int K, int H, int W, void* stream);
 /* 4x4/stride-4 average pool over packed crops; table rows of 4 ints {in_off,h,w,out_off}; bwd: in = pooled grad */
 int mx_avgpool4(const float* in, const int* table, int ncrops, float* out, int bwd, void* stream);
 

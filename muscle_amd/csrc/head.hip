@@ -75,17 +75,25 @@ __global__ __launch_bounds__(256) void upsample_to_nchw_bwd_kernel(const float* 
   const float* g = gdst + (long)nk * Hd * Wd;
   const float sx = (Wd > 1) ? (float)(Ws - 1) / (float)(Wd - 1) : 0.f;
   const float sy = (Hd > 1) ? (float)(Hs - 1) / (float)(Hd - 1) : 0.f;
-  for (int i = threadIdx.x; i < Hd * Ws; i += 256) t[i] = 0.f;
-  __syncthreads();
-  // stage 1: every destination element scatters into its two source columns (LDS atomics, row-local)
-  for (int i = threadIdx.x; i < Hd * Wd; i += 256) {
-    int x = i % Wd, y = i / Wd;
-    int x0, x1;
-    float wx;
-    bil_coord(x, Ws, Wd, x0, x1, wx);
-    float v = g[i];
-    atomicAdd(&t[y * Ws + x0], (1.f - wx) * v);
-    if (x1 != x0) atomicAdd(&t[y * Ws + x1], wx * v);
+  // stage 1: gather along X: t[y][sxi] = sum over the destination columns whose footprint names source column sxi (weight 1-f when
+  // floor(src) == sxi, f when it is sxi-1).  One owner per element, ascending x: same bits every run (it was an LDS-atomic scatter).
+  for (int o = threadIdx.x; o < Hd * Ws; o += 256) {
+    const int sxi = o % Ws, y = o / Ws;
+    int xlo = 0, xhi = Wd - 1;
+    if (sx > 0.f) {
+      xlo = max(0, (int)floorf((float)(sxi - 1) / sx) - 1);
+      xhi = min(Wd - 1, (int)ceilf((float)(sxi + 1) / sx) + 1);
+    }
+    float acc = 0.f;
+    for (int x = xlo; x <= xhi; ++x) {
+      int x0, x1;
+      float wx;
+      bil_coord(x, Ws, Wd, x0, x1, wx);
+      const float v = g[y * Wd + x];
+      if (x0 == sxi) acc += (1.f - wx) * v;
+      if (x1 == sxi && x1 != x0) acc += wx * v;
+    }
+    t[o] = acc;
   }
   __syncthreads();
   (void)sx;

@@ -81,10 +81,12 @@ __global__ __launch_bounds__(256) void maxnorm_bwd_kernel(const float* x, const 
 
 // ---------------------------------------------------------------------------
 // PixPro: loss = 1 - mean_n mean_window cos(m*f1, m*f2) over the channel dim; g1 = d loss / d f1
-// loss buffer must hold 1.0 on entry; g1 must be zero-filled.
+// g1 must be zero-filled.  The per-pixel cosines (|cos| <= 1) are summed per sample as 64-bit fixed-point integers (x 2^32):
+// integer atomics are associative, so the loss has the same bits every run; pixpro_finish_kernel forms 1 - mean_n mean_window.
 // ---------------------------------------------------------------------------
+#define PIXPRO_FIX 4294967296.0f      /* 2^32 */
 __global__ __launch_bounds__(256) void pixpro_kernel(const float* f1, const float* f2, const float* mask, const long* c1,
-                                                     const long* c2, float* loss, float* g1, int N, int K, int H, int W) {
+                                                     const long* c2, unsigned long long* ssum, float* g1, int N, int K, int H, int W) {
   const int n = blockIdx.y;
   const long h1 = c1[n * 4], w1 = c1[n * 4 + 1], hl = c1[n * 4 + 2], wl = c1[n * 4 + 3];
   const long h2 = c2[n * 4], w2 = c2[n * 4 + 1];
@@ -115,7 +117,17 @@ __global__ __launch_bounds__(256) void pixpro_kernel(const float* f1, const floa
     }
   }
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(loss, -acc * scale);
+  if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(ssum + n, (unsigned long long)(long long)(acc * PIXPRO_FIX));
+}
+
+__global__ void pixpro_finish_kernel(const unsigned long long* ssum, const long* c1, int N, float* loss) {
+  double acc = 0.0;
+  for (int n = threadIdx.x; n < N; n += 64) {
+    const double cnt = (double)c1[n * 4 + 2] * (double)c1[n * 4 + 3];
+    if (cnt > 0) acc += (double)(long long)ssum[n] / (double)PIXPRO_FIX / cnt;
+  }
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (threadIdx.x == 0) loss[0] = (float)(1.0 - acc / N);
 }
 
 // ---------------------------------------------------------------------------
@@ -181,27 +193,58 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* src, cons
   }
 }
 
-// adjoint, one block per crop of the table: gsrc[n,k,...] += W^T gout[off ...]
-__global__ __launch_bounds__(256) void crop_resize_bwd_kernel(const float* gout_all, const int* table, float* gsrc, int K, int H, int W) {
-  const int* trow = table + blockIdx.x * 8;
-  const int n = trow[0], y0 = trow[1], x0 = trow[2], lh = trow[3], lw = trow[4], rh = trow[5], rw = trow[6];
-  const float* gout = gout_all + (long)trow[7] * FP;
+// adjoint: gsrc[n,k,...] += W^T gout[off ...] for every crop of the table.  Crops overlap and a bilinear footprint is shared by
+// neighbouring output pixels, so the scatter form needs atomics (order-dependent bits).  Gather form instead: workgroup
+// (sample n, class group kg) walks the crops of ITS sample in table order; for one crop every thread owns source pixels of
+// the window and adds, over the few output pixels whose footprint names it (<= 4 x 4 when the resize shrinks, which it does
+// here: torchutils.py:254-262), weight x gradient for its KG classes; a barrier separates crops.  One adder per element,
+// fixed order: same bits every run.
+constexpr int CROP_KG = 7;     // classes per workgroup (21 = 3 x 7)
+__device__ __forceinline__ void adj_range(int si, int in, int out, int& lo, int& hi) {
+  // output indices d whose bil_coord2(d) can name source index si: scale*d in (si - 1, si + 1); one index of margin each side
+  if (out <= 1 || in <= 1) { lo = 0; hi = out - 1; return; }
+  const float inv = (float)(out - 1) / (float)(in - 1);
+  lo = max(0, (int)floorf((float)(si - 1) * inv) - 1);
+  hi = min(out - 1, (int)ceilf((float)(si + 1) * inv) + 1);
+}
+__global__ __launch_bounds__(256) void crop_resize_bwd_kernel(const float* gout_all, const int* table, int ncrops, float* gsrc, int K,
+                                                              int H, int W) {
+  const int n = blockIdx.x, k0 = blockIdx.y * CROP_KG;
   const long HW = (long)H * W;
-  for (int p = threadIdx.x; p < rh * rw; p += 256) {
-    int r = p / rw, c = p % rw;
-    int ya, yb, xa, xb;
-    float wy, wx;
-    bil_coord2(r, lh, rh, ya, yb, wy);
-    bil_coord2(c, lw, rw, xa, xb, wx);
-    for (int k = 0; k < K; ++k) {
-      float g = gout[(long)p * FP + k];
-      if (g == 0.f) continue;
-      float* q = gsrc + (long)n * K * HW + k * HW;
-      unsafeAtomicAdd(q + (long)(y0 + ya) * W + x0 + xa, (1.f - wy) * (1.f - wx) * g);
-      unsafeAtomicAdd(q + (long)(y0 + ya) * W + x0 + xb, (1.f - wy) * wx * g);
-      unsafeAtomicAdd(q + (long)(y0 + yb) * W + x0 + xa, wy * (1.f - wx) * g);
-      unsafeAtomicAdd(q + (long)(y0 + yb) * W + x0 + xb, wy * wx * g);
+  for (int ci = 0; ci < ncrops; ++ci) {
+    const int* trow = table + ci * 8;
+    if (trow[0] != n) continue;                   // (uniform over the workgroup)
+    const int y0 = trow[1], x0 = trow[2], lh = trow[3], lw = trow[4], rh = trow[5], rw = trow[6];
+    const float* gout = gout_all + (long)trow[7] * FP;
+    for (int sp = threadIdx.x; sp < lh * lw; sp += 256) {
+      const int sy = sp / lw, sx = sp % lw;
+      int rlo, rhi, clo, chi;
+      adj_range(sy, lh, rh, rlo, rhi);
+      adj_range(sx, lw, rw, clo, chi);
+      float acc[CROP_KG];
+#pragma unroll
+      for (int j = 0; j < CROP_KG; ++j) acc[j] = 0.f;
+      for (int r = rlo; r <= rhi; ++r) {
+        int ya, yb; float wy;
+        bil_coord2(r, lh, rh, ya, yb, wy);
+        const float wyy = (ya == sy ? 1.f - wy : 0.f) + (yb == sy ? wy : 0.f);     // (both terms when ya == yb, as the forward)
+        if (wyy == 0.f) continue;
+        for (int c = clo; c <= chi; ++c) {
+          int xa, xb; float wx;
+          bil_coord2(c, lw, rw, xa, xb, wx);
+          const float wxx = (xa == sx ? 1.f - wx : 0.f) + (xb == sx ? wx : 0.f);
+          if (wxx == 0.f) continue;
+          const float* g = gout + (long)(r * rw + c) * FP + k0;
+          const float wgt = wyy * wxx;
+#pragma unroll
+          for (int j = 0; j < CROP_KG; ++j) acc[j] += wgt * g[j];
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < CROP_KG; ++j)
+        if (k0 + j < K && acc[j] != 0.f) gsrc[((long)n * K + k0 + j) * HW + (long)(y0 + sy) * W + x0 + sx] += acc[j];
     }
+    __syncthreads();                              // the next crop of this sample may touch the same pixels
   }
 }
 
@@ -350,15 +393,25 @@ __global__ __launch_bounds__(1024) void emd_score_kernel(const float* feat, cons
 }
 
 // best[s] = index of the first minimal-score pair of sample s (stable sort semantics, :318); loss += score/ns
-__global__ void emd_best_kernel(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= nsamples) return;
-  int bi = -1;
-  float bs = INFINITY;
-  for (int p = 0; p < npairs; ++p)
-    if (pairs[p * 6 + 4] == s && score[p] < bs) { bs = score[p]; bi = p; }
-  best[s] = bi;
-  if (bi >= 0) atomicAdd(loss, bs / nsamples);
+__global__ __launch_bounds__(1024) void emd_best_kernel(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss) {
+  __shared__ float bsv[1024];
+  const int s = threadIdx.x;
+  float bs = 0.f;
+  if (s < nsamples) {
+    int bi = -1;
+    float b = INFINITY;
+    for (int p = 0; p < npairs; ++p)
+      if (pairs[p * 6 + 4] == s && score[p] < b) { b = score[p]; bi = p; }
+    best[s] = bi;
+    if (bi >= 0) bs = b / nsamples;
+  }
+  bsv[s] = bs;
+  __syncthreads();
+  if (s == 0) {                                   // one adder, sample order (was a float atomic per sample)
+    float t = 0.f;
+    for (int i = 0; i < nsamples; ++i) t += bsv[i];
+    loss[0] += t;
+  }
 }
 
 // backward through the 10 iterations for the best pair of each sample: gx[best crop1 pixels, 24] = d dist / d x * gscale
@@ -474,10 +527,13 @@ int mx_maxnorm(const float* x, const float* gy, float* out, float* stats, int NK
 }
 
 int mx_pixpro(const float* f1, const float* f2, const float* mask, const long* coord1, const long* coord2, float* loss, float* g1,
-              int N, int K, int H, int W, void* stream) {
+              int N, int K, int H, int W, void* ws, long ws_bytes, void* stream) {
   MX_CHECK_ARG(f1 && f2 && coord1 && coord2 && loss && g1 && N > 0 && K > 0 && K <= 32 && H > 0 && W > 0, "pixpro: bad args");
+  MX_CHECK_ARG(ws && ws_bytes >= (long)N * 8 && ((uintptr_t)ws & 7) == 0, "pixpro: %d bytes of scratch required", N * 8);
+  hipMemsetAsync(ws, 0, (size_t)N * 8, (hipStream_t)stream);
   hipLaunchKernelGGL(pixpro_kernel, dim3(cdiv((long)H * W, 256), N), dim3(256), 0, (hipStream_t)stream, f1, f2, mask, coord1, coord2,
-                     loss, g1, N, K, H, W);
+                     (unsigned long long*)ws, g1, N, K, H, W);
+  hipLaunchKernelGGL(pixpro_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)ws, coord1, N, loss);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -496,9 +552,11 @@ int mx_crop_resize(const float* src, const int* table, int ncrops, float* out, i
   return MX_OK;
 }
 
-int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* gsrc, int K, int H, int W, void* stream) {
-  MX_CHECK_ARG(gout && table && gsrc && ncrops > 0 && K > 0 && K <= FP, "crop_resize_bwd: bad args");
-  hipLaunchKernelGGL(crop_resize_bwd_kernel, dim3(ncrops), dim3(256), 0, (hipStream_t)stream, gout, table, gsrc, K, H, W);
+int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* gsrc, int nsamples, int K, int H, int W, void* stream) {
+  MX_CHECK_ARG(gout && table && gsrc && ncrops > 0 && nsamples > 0 && K > 0 && K <= FP, "crop_resize_bwd: bad args");
+  // samples = 1 + the largest sample index of the table is not known here: the grid covers `nsamples` given by the caller
+  hipLaunchKernelGGL(crop_resize_bwd_kernel, dim3(nsamples, cdiv(K, CROP_KG)), dim3(256), 0, (hipStream_t)stream, gout, table, ncrops, gsrc,
+                     K, H, W);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -529,9 +587,8 @@ int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, in
 }
 
 int mx_emd_best(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss, void* stream) {
-  MX_CHECK_ARG(score && pairs && best && loss && npairs > 0 && nsamples > 0, "emd_best: bad args");
-  hipLaunchKernelGGL(emd_best_kernel, dim3(cdiv(nsamples, 64)), dim3(64), 0, (hipStream_t)stream, score, pairs, npairs, nsamples, best,
-                     loss);
+  MX_CHECK_ARG(score && pairs && best && loss && npairs > 0 && nsamples > 0 && nsamples <= 1024, "emd_best: bad args (nsamples <= 1024)");
+  hipLaunchKernelGGL(emd_best_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, score, pairs, npairs, nsamples, best, loss);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -184,7 +184,8 @@ void mx_launch_parts_reduce(const float* part, int groups, int n, float* dW, hip
 
 static bool wg_plan(int R, int Co, int Ci, WgPlan* p) {
   const int cot = cdiv(Co, 16), cit = cdiv(Ci, 16);
-  if (Co % 4 || Ci % 4 || (long)Co * Ci > 40960 || R < 65536) return false;
+  static const int rmin = getenv("MX_WGRAD_SMALL_RMIN") ? atoi(getenv("MX_WGRAD_SMALL_RMIN")) : 65536;
+  if (Co % 4 || Ci % 4 || (long)Co * Ci > 40960 || R < rmin) return false;
   // waves: 4, or 8 when the tiles of one wave would exceed 24 (96 accumulator registers)
   int best_nw = 0, best_wco = 0, best_cost = 1 << 30;
   for (int nw : {4, 8}) {

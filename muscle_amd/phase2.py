@@ -55,10 +55,11 @@ class _PixPro(torch.autograd.Function):
         dev = f1.device
         c1 = c1.to(dev, torch.int64).contiguous()
         c2 = c2.to(dev, torch.int64).contiguous()
-        loss = torch.ones(1, dtype=torch.float32, device=dev)
+        loss = torch.empty(1, dtype=torch.float32, device=dev)
         g1 = torch.zeros_like(f1)
+        ws = torch.empty(N, dtype=torch.int64, device=dev)
         call("mx_pixpro", ptr(f1), ptr(f2), ptr(mask.contiguous().float()) if mask is not None else None, ptr(c1), ptr(c2),
-             ptr(loss), ptr(g1), N, K, H, W, stream())
+             ptr(loss), ptr(g1), N, K, H, W, ws.data_ptr(), 8 * N, stream())
         ctx.save_for_backward(g1)
         return loss[0]
 
@@ -227,7 +228,7 @@ class _Crops(torch.autograd.Function):
         if plan.pool:
             call("mx_avgpool4", ptr(g), ptr(tabs["pool"]), len(plan.pool), ptr(g), 1, stream())
         gx1 = torch.zeros(N, K, H, W, dtype=torch.float32, device=g.device)
-        call("mx_crop_resize_bwd", ptr(g), ptr(tabs["t1"]), len(plan.t1), ptr(gx1), K, H, W, stream())
+        call("mx_crop_resize_bwd", ptr(g), ptr(tabs["t1"]), len(plan.t1), ptr(gx1), N, K, H, W, stream())
         return gx1, None, None
 
 

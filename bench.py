@@ -430,7 +430,7 @@ def main():
         del model, opt, out
         torch.cuda.empty_cache()
         res["configs"] = {
-            "config2": short_run("efficientnet-b0", 16, 448, a.epoch, 5, 30, dev, 2000),       # BASELINE.json configs[1]
+            "config2": short_run("efficientnet-b0", 16, 448, a.epoch, 10, 50, dev, 2000),      # BASELINE.json configs[1]
             "stepfull": short_run("efficientnet-b7", 32, 448, 12, 1, 3, dev, 1000),             # epoch >= 12 gates, headline model
         }
     muscle_amd.set_gemm_mode(0)

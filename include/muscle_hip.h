@@ -371,11 +371,12 @@ int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsampl
 /* F.avg_pool2d(k=3,s=2,p=1) on NHWC (MuSCLe.py:51,54); bwd: x = pooled gradient, y = input gradient */
 int mx_avgpool3s2(const float* x, float* y, int N, int H, int W, int C, int bwd, void* stream);
 /* adjoint of mx_resize_nhwc (no relu): gsrc += W^T gdst */
-int mx_resize_nhwc_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int C, int Hd, int Wd, void* stream);
+int mx_resize_nhwc_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int C, int Hd, int Wd, void* stream);   /* ordered gather; C % 4 == 0 */
 /* CrossEntropyLoss(seg [N,K,HW], argmax_k mask) (train_muscle.py:189-191): loss[0] += mean; bwd: gseg = gup[0]*dL/dseg */
 int mx_ce_argmax(const float* seg, const float* mask, const float* gup, float* loss, float* gseg, int N, int K, long HW, int bwd,
-                 void* stream);
-/* clip_grad_norm_(max_norm, 2) on a flat gradient arena (train_muscle.py:202); norm_out (optional) = total norm */
+                 void* ws /* forward: 8 bytes, the fixed-point sum */, long ws_bytes, void* stream);
+/* clip_grad_norm_(max_norm, 2) on a flat gradient arena (train_muscle.py:202); norm_out (optional) = total norm;
+ * sq_scratch: 2048 doubles (per-workgroup partial square sums, added in a fixed order) */
 int mx_clip_grad_norm(float* grads, long n, float max_norm, double* sq_scratch, float* norm_out, void* stream);
 /* FieldLoss stage 1 (edge.py:423-440,45-89): softmax(beta*seg)[1:], 5x5 Sobel per labelled class, magnitude,
  * 8-way orientation, per-(n,class) max (float bits), edge_fg = sum over classes */
@@ -389,10 +390,11 @@ int mx_field_select(const float* mag, const unsigned char* orient, const unsigne
 int mx_field_gather(const float* dense, int mode, int h, int w, const float* mask, const int* pts, int npts, float* feat, float* mfeat,
                     int CH, int K, int ML, int H, int W, void* stream);
 /* stage 5 (edge.py:231-261,330-347): loss += terms/nsamples, gsim = d loss / d sim, per slot of k x k similarities */
-int mx_field_terms(const float* sim, const float* simm, int nslots, int k, float inv_n, float* loss, float* gsim, void* stream);
+int mx_field_terms(const float* sim, const float* simm, int nslots, int k, float inv_n, float* loss, float* gsim,
+                   float* slot_loss /* nslots floats of scratch */, void* stream);
 /* stage 6: softmax backward at the out points, scattered (+=) into the dense-feature gradient */
 int mx_field_scatter(const float* feat, const float* gfeat, const int* pts, int npts, int mode, int h, int w, const float* gup,
-                     float* gdense, int CH, int H, int W, void* stream);
+                     float* gdense, float* gpt /* mode 1: npts*CH floats of scratch */, int nsamples, int CH, int H, int W, void* stream);
 
 #ifdef __cplusplus
 }

@@ -61,31 +61,62 @@ __device__ __forceinline__ void bc(int d, int in, int out, int& i0, int& i1, flo
   w1 = s - i0;
 }
 
-// adjoint of mx_resize_nhwc (no relu): gsrc[N,Hs,Ws,C] += W^T gdst[N,Hd,Wd,C]
+// destination indices whose bilinear footprint (bc) can name source index si: scale*d in (si - 1, si + 1), one index of margin
+__device__ __forceinline__ void adj_rng(int si, int in, int out, int& lo, int& hi) {
+  if (out <= 1 || in <= 1) { lo = 0; hi = out - 1; return; }
+  const float inv = (float)(out - 1) / (float)(in - 1);
+  lo = max(0, (int)floorf((float)(si - 1) * inv) - 1);
+  hi = min(out - 1, (int)ceilf((float)(si + 1) * inv) + 1);
+}
+
+// adjoint of mx_resize_nhwc (no relu): gsrc[N,Hs,Ws,C] += W^T gdst[N,Hd,Wd,C].  Gather form: a thread owns four channels of one
+// SOURCE pixel and adds weight x gradient over the destination pixels that name it, rows then columns ascending - one adder per
+// element, same bits every run (the scatter form needed float atomics).
 __global__ __launch_bounds__(256) void resize_nhwc_bwd_kernel(const float* gdst, float* gsrc, int N, int Hs, int Ws, int C, int Hd, int Wd) {
-  const long total = (long)N * Hd * Wd * C;
+  const int c4n = C / 4;
+  const long total = (long)N * Hs * Ws * c4n;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    int c = (int)(i % C);
-    long p = i / C;
-    int x = (int)(p % Wd); long q = p / Wd;
-    int y = (int)(q % Hd), n = (int)(q / Hd);
-    int y0, y1, x0, x1; float wy, wx;
-    bc(y, Hs, Hd, y0, y1, wy); bc(x, Ws, Wd, x0, x1, wx);
-    float g = gdst[i];
-    float* b = gsrc + (long)n * Hs * Ws * C + c;
-    unsafeAtomicAdd(b + ((long)y0 * Ws + x0) * C, (1.f - wy) * (1.f - wx) * g);
-    if (x1 != x0) unsafeAtomicAdd(b + ((long)y0 * Ws + x1) * C, (1.f - wy) * wx * g);
-    if (y1 != y0) {
-      unsafeAtomicAdd(b + ((long)y1 * Ws + x0) * C, wy * (1.f - wx) * g);
-      if (x1 != x0) unsafeAtomicAdd(b + ((long)y1 * Ws + x1) * C, wy * wx * g);
+    const int c = (int)(i % c4n) * 4;
+    long p = i / c4n;
+    const int sx = (int)(p % Ws); long q = p / Ws;
+    const int sy = (int)(q % Hs), n = (int)(q / Hs);
+    int ylo, yhi, xlo, xhi;
+    adj_rng(sy, Hs, Hd, ylo, yhi);
+    adj_rng(sx, Ws, Wd, xlo, xhi);
+    float4 acc = make_float4(0, 0, 0, 0);
+    for (int y = ylo; y <= yhi; ++y) {
+      int y0, y1; float wy;
+      bc(y, Hs, Hd, y0, y1, wy);
+      const float wyy = (y0 == sy ? 1.f - wy : 0.f) + ((y1 == sy && y1 != y0) ? wy : 0.f);
+      if (wyy == 0.f) continue;
+      for (int x = xlo; x <= xhi; ++x) {
+        int x0, x1; float wx;
+        bc(x, Ws, Wd, x0, x1, wx);
+        const float wxx = (x0 == sx ? 1.f - wx : 0.f) + ((x1 == sx && x1 != x0) ? wx : 0.f);
+        if (wxx == 0.f) continue;
+        const float4 g = ld4(gdst + (((long)n * Hd + y) * Wd + x) * C + c);
+        const float w = wyy * wxx;
+        acc.x += w * g.x; acc.y += w * g.y; acc.z += w * g.z; acc.w += w * g.w;
+      }
     }
+    float* o = gsrc + p * C + c;
+    float4 v = ld4(o);
+    v.x += acc.x; v.y += acc.y; v.z += acc.z; v.w += acc.w;
+    st4(o, v);
   }
 }
+
 
 // ---------------------------------------------------------------------------
 // CrossEntropyLoss(seg [N,K,HW], argmax_k mask [N,K,HW]) mean over N*HW, and its gradient
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ce_argmax_kernel(const float* seg, const float* mask, const float* gup, float* loss, float* gseg,
+// forward: the per-pixel terms (>= 0) are summed as 64-bit fixed-point integers (x 2^32: associative, same bits every run);
+// ce_finish_kernel adds the mean to loss[0]
+#define CE_FIX 4294967296.0f
+__global__ void ce_finish_kernel(const unsigned long long* acc, double inv, float* loss) {
+  loss[0] += (float)((double)acc[0] / (double)CE_FIX * inv);
+}
+__global__ __launch_bounds__(256) void ce_argmax_kernel(const float* seg, const float* mask, const float* gup, unsigned long long* lacc, float* gseg,
                                                         int N, int K, long HW, int bwd) {
   const long total = (long)N * HW;
   const float inv = 1.f / (float)total;
@@ -108,24 +139,33 @@ __global__ __launch_bounds__(256) void ce_argmax_kernel(const float* seg, const 
   }
   if (!bwd) {
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss, acc * inv);
+    if ((threadIdx.x & 63) == 0 && acc != 0.f) atomicAdd(lacc, (unsigned long long)(acc * CE_FIX));
   }
+  (void)inv;
 }
 
 // ---------------------------------------------------------------------------
 // clip_grad_norm_: sq[0] += sum x^2 (fp64); then x *= min(1, max_norm / (sqrt(sq) + 1e-6))
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sqsum_kernel(const float* x, long n, double* sq) {
+__global__ __launch_bounds__(256) void sqsum_kernel(const float* x, long n, double* sq /*[gridDim.x]*/) {
   __shared__ double sh[4];
   double a = 0.0;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) { double v = x[i]; a += v * v; }
   for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o, 64);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = a;
   __syncthreads();
-  if (threadIdx.x == 0) unsafeAtomicAdd(sq, sh[0] + sh[1] + sh[2] + sh[3]);
+  if (threadIdx.x == 0) sq[blockIdx.x] = ((sh[0] + sh[1]) + sh[2]) + sh[3];      // one partial per workgroup (was an fp64 atomic)
 }
-__global__ __launch_bounds__(256) void clip_scale_kernel(float* x, long n, const double* sq, float max_norm, float* norm_out) {
-  const float total = (float)sqrt(sq[0]);
+// total = the nparts partials added in a fixed order (thread t: t, t + 256, ...; then the 256 thread sums in thread order)
+__global__ __launch_bounds__(256) void clip_scale_kernel(float* x, long n, const double* sq, int nparts, float max_norm, float* norm_out) {
+  __shared__ double sh[256];
+  double a = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) a += sq[i];
+  sh[threadIdx.x] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) { double t = 0.0; for (int i = 0; i < 256; ++i) t += sh[i]; sh[0] = t; }
+  __syncthreads();
+  const float total = (float)sqrt(sh[0]);
   const float coef = fminf(max_norm / (total + 1e-6f), 1.0f);
   if (blockIdx.x == 0 && threadIdx.x == 0 && norm_out) norm_out[0] = total;
   if (coef >= 1.0f) return;
@@ -334,7 +374,12 @@ __global__ __launch_bounds__(256) void field_gather_kernel(const float* dense, i
 
 // stage 5: per slot, from sim [k,k] (outs x ins) and sim_m: the eight FP/FN/TP/TN terms (edge.py:231-261,330-347),
 // loss += sum / nsamples, gsim = d loss / d sim.  One workgroup per slot, k <= 256.
-__global__ __launch_bounds__(256) void field_terms_kernel(const float* sim, const float* simm, int k, float inv_n, float* loss,
+__global__ void field_loss_sum_kernel(const float* slot_loss, int nslots, float* loss) {     // slots in order, one adder
+  float t = 0.f;
+  for (int i = 0; i < nslots; ++i) t += slot_loss[i];
+  loss[0] += t;
+}
+__global__ __launch_bounds__(256) void field_terms_kernel(const float* sim, const float* simm, int k, float inv_n, float* slot_loss,
                                                           float* gsim) {
   __shared__ float rm[256], cm[256], rmm[256], cmm[256];
   __shared__ float tot[2];
@@ -348,7 +393,6 @@ __global__ __launch_bounds__(256) void field_terms_kernel(const float* sim, cons
     for (int j = 0; j < k; ++j) { a += S[t * k + j]; b += S[j * k + t]; c += M[t * k + j]; d += M[j * k + t]; }
     rm[t] = a / k; cm[t] = b / k; rmm[t] = c / k; cmm[t] = d / k;
   }
-  if (t < 8) { cnt[t / 4][t % 4] = 0; ssum[t / 4][t % 4] = 0.f; }
   __syncthreads();
   if (t == 0) {
     float a = 0.f, c = 0.f;
@@ -358,14 +402,23 @@ __global__ __launch_bounds__(256) void field_terms_kernel(const float* sim, cons
   __syncthreads();
   // class of row t (dim=1) and of column t (dim=0): 0 FP, 1 FN, 2 TP, 3 TN
   int cls[2] = {0, 0};
+  __shared__ unsigned char clsm[2][256];
   if (t < k) {
     for (int d = 0; d < 2; ++d) {
       bool sm = (d == 0 ? rmm[t] : cmm[t]) > tot[1];
       bool sd = (d == 0 ? rm[t] : cm[t]) > tot[0];
       cls[d] = (sm && !sd) ? 0 : ((!sm && sd) ? 1 : ((!sm && !sd) ? 2 : 3));
-      atomicAdd(&cnt[d][cls[d]], 1);
-      atomicAdd(&ssum[d][cls[d]], d == 0 ? rm[t] : cm[t]);
+      clsm[d][t] = (unsigned char)cls[d];
     }
+  }
+  __syncthreads();
+  if (t < 8) {                                   // thread (d, c): count and sum of class c along dimension d, rows in order
+    const int d = t / 4, c = t % 4;
+    int n_ = 0;
+    float a = 0.f;
+    for (int i = 0; i < k; ++i)
+      if (clsm[d][i] == c) { ++n_; a += (d == 0 ? rm[i] : cm[i]); }
+    cnt[d][c] = n_; ssum[d][c] = a;
   }
   __syncthreads();
   if (t == 0) {
@@ -373,7 +426,7 @@ __global__ __launch_bounds__(256) void field_terms_kernel(const float* sim, cons
     for (int d = 0; d < 2; ++d)
       for (int c = 0; c < 4; ++c)
         if (cnt[d][c] > 0) l += ((c == 0 || c == 3) ? -1.f : 1.f) * ssum[d][c] / cnt[d][c];
-    atomicAdd(loss, l * inv_n);
+    slot_loss[s] = l * inv_n;
   }
   // gsim[i][j] = sign(cls_row i)/(k*cnt_row) + sign(cls_col j)/(k*cnt_col), scaled by inv_n
   __shared__ float rw[256], cw[256];
@@ -387,6 +440,58 @@ __global__ __launch_bounds__(256) void field_terms_kernel(const float* sim, cons
 
 // stage 6: softmax backward at the out points and scatter of the gradient into the dense feature gradient.
 // gfeat [npts, CH] = d loss / d softmaxed features (out points only); feat the forward softmax.
+// Two forms.  (a) mode 1 (the training step: features interpolated from the low-resolution NHWC map): field_point_grad_kernel
+// writes the per-point gradient rows gpt [npts, CH]; field_tile_gather_kernel - one workgroup per (sample, 8 x 8 tile of the
+// low-resolution map), thread = channel - walks ALL points in list order and adds the bilinear corner weights of the points
+// that fall into its tile into an LDS tile (a thread only ever touches its own channel column), then adds the tile to gdense:
+// one adder per element, points in order: same bits every run.  (b) mode 0 (materialised full-resolution features, the public
+// unfused path): the round-1 scatter with float atomics (last-bit noise), kept for that path only.
+__global__ __launch_bounds__(256) void field_point_grad_kernel(const float* feat, const float* gfeat, int npts, const float* gup,
+                                                               float* gpt, int CH) {
+  const int lane = threadIdx.x & 63;
+  const float gs_ = gup ? gup[0] : 1.f;
+  for (int q = blockIdx.x * 4 + (threadIdx.x >> 6); q < npts; q += gridDim.x * 4) {
+    float dot = 0.f;
+    for (int c = lane; c < CH; c += 64) dot += gfeat[(long)q * CH + c] * feat[(long)q * CH + c];
+    dot = wave_sum(dot);
+    for (int c = lane; c < CH; c += 64) gpt[(long)q * CH + c] = feat[(long)q * CH + c] * (gfeat[(long)q * CH + c] - dot) * gs_;
+  }
+}
+
+constexpr int FT = 8;      // tile edge (cells of the low-resolution map)
+__global__ __launch_bounds__(256) void field_tile_gather_kernel(const float* gpt, const int* pts, int npts, int h, int w, float* gdense,
+                                                                int CH, int H, int W) {
+  extern __shared__ float lacc[];                  // [FT*FT][CH]
+  const int tiles_x = (w + FT - 1) / FT;
+  const int ty0 = (blockIdx.x / tiles_x) * FT, tx0 = (blockIdx.x % tiles_x) * FT, n = blockIdx.y;
+  for (int i = threadIdx.x; i < FT * FT * CH; i += 256) lacc[i] = 0.f;
+  __syncthreads();
+  bool any = false;
+  for (int q = 0; q < npts; ++q) {
+    if (pts[2 * q] != n) continue;                 // (uniform: every thread reads the same words)
+    const int p = pts[2 * q + 1];
+    int y0, y1, x0, x1; float wy, wx;
+    bc(p / W, h, H, y0, y1, wy); bc(p % W, w, W, x0, x1, wx);
+    if (y1 < ty0 || y0 >= ty0 + FT || x1 < tx0 || x0 >= tx0 + FT) continue;
+    any = true;
+    const float w00 = (1.f - wy) * (1.f - wx), w01 = (x1 != x0) ? (1.f - wy) * wx : 0.f;
+    const float w10 = (y1 != y0) ? wy * (1.f - wx) : 0.f, w11 = (y1 != y0 && x1 != x0) ? wy * wx : 0.f;
+    for (int c = threadIdx.x; c < CH; c += 256) {
+      const float g = gpt[(long)q * CH + c];
+      auto add = [&](int yy, int xx, float wgt) {
+        if (wgt != 0.f && yy >= ty0 && yy < ty0 + FT && xx >= tx0 && xx < tx0 + FT) lacc[((yy - ty0) * FT + (xx - tx0)) * CH + c] += wgt * g;
+      };
+      add(y0, x0, w00); add(y0, x1, w01); add(y1, x0, w10); add(y1, x1, w11);
+    }
+  }
+  if (!any) return;                                // (uniform)
+  __syncthreads();
+  for (int i = threadIdx.x; i < FT * FT * CH; i += 256) {
+    const int c = i % CH, cell = i / CH, yy = ty0 + cell / FT, xx = tx0 + cell % FT;
+    if (yy < h && xx < w && lacc[i] != 0.f) gdense[(((long)n * h + yy) * w + xx) * CH + c] += lacc[i];
+  }
+}
+
 __global__ __launch_bounds__(256) void field_scatter_kernel(const float* feat, const float* gfeat, const int* pts, int npts, int mode,
                                                             int h, int w, const float* gup, float* gdense, int CH, int H, int W) {
   const int lane = threadIdx.x & 63;
@@ -397,21 +502,9 @@ __global__ __launch_bounds__(256) void field_scatter_kernel(const float* feat, c
     float dot = 0.f;
     for (int c = lane; c < CH; c += 64) dot += gfeat[(long)q * CH + c] * feat[(long)q * CH + c];
     dot = wave_sum(dot);
-    const int y = p / W, x = p % W;
-    int y0 = 0, y1 = 0, x0 = 0, x1 = 0; float wy = 0.f, wx = 0.f;
-    if (mode == 1) { bc(y, h, H, y0, y1, wy); bc(x, w, W, x0, x1, wx); }
     for (int c = lane; c < CH; c += 64) {
       float g = feat[(long)q * CH + c] * (gfeat[(long)q * CH + c] - dot) * gs_;
-      if (mode == 0) unsafeAtomicAdd(gdense + ((long)n * CH + c) * HW + p, g);
-      else {
-        float* b = gdense + (long)n * h * w * CH + c;
-        unsafeAtomicAdd(b + ((long)y0 * w + x0) * CH, (1.f - wy) * (1.f - wx) * g);
-        if (x1 != x0) unsafeAtomicAdd(b + ((long)y0 * w + x1) * CH, (1.f - wy) * wx * g);
-        if (y1 != y0) {
-          unsafeAtomicAdd(b + ((long)y1 * w + x0) * CH, wy * (1.f - wx) * g);
-          if (x1 != x0) unsafeAtomicAdd(b + ((long)y1 * w + x1) * CH, wy * wx * g);
-        }
-      }
+      unsafeAtomicAdd(gdense + ((long)n * CH + c) * HW + p, g);
     }
   }
 }
@@ -436,20 +529,24 @@ int mx_resize_nhwc_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, in
 }
 
 int mx_ce_argmax(const float* seg, const float* mask, const float* gup, float* loss, float* gseg, int N, int K, long HW, int bwd,
-                 void* stream) {
+                 void* ws, long ws_bytes, void* stream) {
   MX_CHECK_ARG(seg && mask && N > 0 && K > 1 && HW > 0 && (bwd ? (gup && gseg) : (loss != nullptr)), "ce_argmax: bad args");
-  hipLaunchKernelGGL(ce_argmax_kernel, dim3(gs((long)N * HW)), dim3(256), 0, (hipStream_t)stream, seg, mask, gup, loss, gseg, N, K, HW,
-                     bwd);
+  MX_CHECK_ARG(bwd || (ws && ws_bytes >= 8 && ((uintptr_t)ws & 7) == 0), "ce_argmax: forward needs 8 bytes of scratch");
+  hipStream_t st = (hipStream_t)stream;
+  if (!bwd) hipMemsetAsync(ws, 0, 8, st);
+  hipLaunchKernelGGL(ce_argmax_kernel, dim3(gs((long)N * HW)), dim3(256), 0, st, seg, mask, gup, (unsigned long long*)ws, gseg, N, K, HW, bwd);
+  if (!bwd) hipLaunchKernelGGL(ce_finish_kernel, dim3(1), dim3(1), 0, st, (const unsigned long long*)ws, 1.0 / ((double)N * (double)HW), loss);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
+// sq_scratch: 2048 doubles (one partial square sum per workgroup, added in a fixed order)
 int mx_clip_grad_norm(float* grads, long n, float max_norm, double* sq_scratch, float* norm_out, void* stream) {
   MX_CHECK_ARG(grads && sq_scratch && n > 0 && max_norm > 0, "clip_grad_norm: bad args");
   hipStream_t st = (hipStream_t)stream;
-  hipMemsetAsync(sq_scratch, 0, sizeof(double), st);
-  hipLaunchKernelGGL(sqsum_kernel, dim3(gs(n) > 2048 ? 2048 : gs(n)), dim3(256), 0, st, grads, n, sq_scratch);
-  hipLaunchKernelGGL(clip_scale_kernel, dim3(gs(n) > 4096 ? 4096 : gs(n)), dim3(256), 0, st, grads, n, sq_scratch, max_norm, norm_out);
+  const int nparts = gs(n) > 2048 ? 2048 : gs(n);
+  hipLaunchKernelGGL(sqsum_kernel, dim3(nparts), dim3(256), 0, st, grads, n, sq_scratch);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(gs(n) > 4096 ? 4096 : gs(n)), dim3(256), 0, st, grads, n, sq_scratch, nparts, max_norm, norm_out);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -485,18 +582,36 @@ int mx_field_gather(const float* dense, int mode, int h, int w, const float* mas
   return MX_OK;
 }
 
-int mx_field_terms(const float* sim, const float* simm, int nslots, int k, float inv_n, float* loss, float* gsim, void* stream) {
-  MX_CHECK_ARG(sim && simm && loss && gsim && nslots > 0 && k > 0 && k <= 256, "field_terms: bad args (k <= 256)");
-  hipLaunchKernelGGL(field_terms_kernel, dim3(nslots), dim3(256), 0, (hipStream_t)stream, sim, simm, k, inv_n, loss, gsim);
+// slot_loss: nslots floats of scratch (the per-slot terms, added to loss[0] in slot order)
+int mx_field_terms(const float* sim, const float* simm, int nslots, int k, float inv_n, float* loss, float* gsim, float* slot_loss,
+                   void* stream) {
+  MX_CHECK_ARG(sim && simm && loss && gsim && slot_loss && nslots > 0 && k > 0 && k <= 256, "field_terms: bad args (k <= 256)");
+  hipLaunchKernelGGL(field_terms_kernel, dim3(nslots), dim3(256), 0, (hipStream_t)stream, sim, simm, k, inv_n, slot_loss, gsim);
+  hipLaunchKernelGGL(field_loss_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (const float*)slot_loss, nslots, loss);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
+// gpt: npts*CH floats of scratch (mode 1 only: the per-point gradient rows; may be NULL for mode 0); nsamples = N of gdense
 int mx_field_scatter(const float* feat, const float* gfeat, const int* pts, int npts, int mode, int h, int w, const float* gup,
-                     float* gdense, int CH, int H, int W, void* stream) {
-  MX_CHECK_ARG(feat && gfeat && pts && gdense && npts > 0 && CH > 0, "field_scatter: bad args");
-  hipLaunchKernelGGL(field_scatter_kernel, dim3(cdiv(npts, 4)), dim3(256), 0, (hipStream_t)stream, feat, gfeat, pts, npts, mode, h, w,
-                     gup, gdense, CH, H, W);
+                     float* gdense, float* gpt, int nsamples, int CH, int H, int W, void* stream) {
+  MX_CHECK_ARG(feat && gfeat && pts && gdense && npts > 0 && CH > 0 && nsamples > 0, "field_scatter: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  if (mode == 1) {
+    MX_CHECK_ARG(gpt != nullptr && h > 0 && w > 0, "field_scatter: mode 1 needs gpt [npts, CH]");
+    const size_t sh = (size_t)FT * FT * CH * sizeof(float);
+    MX_CHECK_ARG(sh <= 160 * 1024, "field_scatter: %d channels do not fit the LDS tile", CH);
+    static bool big = false;
+    if (sh > 64 * 1024 && !big) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&field_tile_gather_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      big = true;
+    }
+    hipLaunchKernelGGL(field_point_grad_kernel, dim3(cdiv(npts, 4)), dim3(256), 0, st, feat, gfeat, npts, gup, gpt, CH);
+    hipLaunchKernelGGL(field_tile_gather_kernel, dim3(cdiv(h, FT) * cdiv(w, FT), nsamples), dim3(256), sh, st, (const float*)gpt, pts, npts, h, w,
+                       gdense, CH, H, W);
+  } else {
+    hipLaunchKernelGGL(field_scatter_kernel, dim3(cdiv(npts, 4)), dim3(256), 0, st, feat, gfeat, pts, npts, mode, h, w, gup, gdense, CH, H, W);
+  }
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -41,7 +41,8 @@ class _FieldLossFn(torch.autograd.Function):
         ops.bgemm(0, mfeat[0].view(S, k, _ML), mfeat[1].view(S, k, _ML), simm, k, k, _ML)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
         gsim = torch.empty_like(sim)
-        call("mx_field_terms", ptr(sim), ptr(simm), S, k, 1.0 / N, ptr(loss), ptr(gsim), stream())
+        slot_loss = torch.empty(S, dtype=torch.float32, device=dev)
+        call("mx_field_terms", ptr(sim), ptr(simm), S, k, 1.0 / N, ptr(loss), ptr(gsim), ptr(slot_loss), stream())
         ctx.save_for_backward(feat, gsim)
         ctx.plan = plan
         ctx.dshape = dense.shape
@@ -58,8 +59,9 @@ class _FieldLossFn(torch.autograd.Function):
         ops.bgemm(1, gsim, feat[1].view(S, k, CH), gfo, k, CH, k)                   # d sim / d outs = gsim @ ins
         gd = torch.zeros(ctx.dshape, dtype=torch.float32, device=dev)
         gup = g.contiguous().float().reshape(1)
+        gpt = torch.empty(S * k, CH, dtype=torch.float32, device=dev) if plan["mode"] == 1 else None
         call("mx_field_scatter", ptr(feat[0]), ptr(gfo), ptr(plan["pts"][0]), S * k, plan["mode"], plan["h"], plan["w"], ptr(gup),
-             ptr(gd), CH, H, W, stream())
+             ptr(gd), ptr(gpt), N, CH, H, W, stream())
         return gd, None
 
 
@@ -158,7 +160,8 @@ class _CEArgmax(torch.autograd.Function):
         seg, mask = seg.contiguous().float(), mask.contiguous().float()
         N, K, H, W = seg.shape
         loss = torch.zeros(1, dtype=torch.float32, device=seg.device)
-        call("mx_ce_argmax", ptr(seg), ptr(mask), None, ptr(loss), None, N, K, H * W, 0, stream())
+        ws = torch.empty(1, dtype=torch.int64, device=seg.device)
+        call("mx_ce_argmax", ptr(seg), ptr(mask), None, ptr(loss), None, N, K, H * W, 0, ws.data_ptr(), 8, stream())
         ctx.save_for_backward(seg, mask)
         return loss[0]
 
@@ -167,7 +170,7 @@ class _CEArgmax(torch.autograd.Function):
         seg, mask = ctx.saved_tensors
         N, K, H, W = seg.shape
         out = torch.empty_like(seg)
-        call("mx_ce_argmax", ptr(seg), ptr(mask), ptr(g.contiguous().float().reshape(1)), None, ptr(out), N, K, H * W, 1, stream())
+        call("mx_ce_argmax", ptr(seg), ptr(mask), ptr(g.contiguous().float().reshape(1)), None, ptr(out), N, K, H * W, 1, None, 0, stream())
         return out, None
 
 
@@ -183,7 +186,7 @@ def clip_grad_norm_(model, max_norm: float):
     if check is not None:
         check(model)                     # a gradient outside the arena would silently escape the clip
     arena = model.last_grad_sink.arena
-    sq = torch.empty(1, dtype=torch.float64, device=arena.device)
+    sq = torch.empty(2048, dtype=torch.float64, device=arena.device)      # per-workgroup partial square sums
     norm = torch.empty(1, dtype=torch.float32, device=arena.device)
     call("mx_clip_grad_norm", ptr(arena), arena.numel(), float(max_norm), ptr(sq), ptr(norm), stream())
     return norm[0]

@@ -101,3 +101,38 @@ def test_headline_step_is_bit_reproducible(arith):
         muscle_amd.set_gemm_mode(0)
     assert np.array_equal(runs[0][0], runs[1][0]), (runs[0][0], runs[1][0])
     assert torch.equal(runs[0][1], runs[1][1]), float((runs[0][1].double() - runs[1][1].double()).abs().max())
+
+
+def test_decoder_step_is_bit_reproducible():
+    """train_muscle.py's loop body (decoder mode, cross entropy + BEACON FieldLoss with replayed boundary points, clip, Adam) on the
+    fused path: two runs, same bits in both losses, the gradient norm, the gradient arena and the parameters."""
+    import random
+    import golden_util as gu
+    from test_gpu_decoder import build_dec
+    G = gu.load("muscle_step_b3_beacon.npz")
+    name = str(G["name"]); n, size, seed, tseed, kk, step = (int(v) for v in G["meta"])
+    T = lambda a: torch.from_numpy(np.asarray(a))   # noqa: E731
+    runs = []
+    for disturb in (False, True):
+        cfg, sd, model = build_dec(name, seed)
+        lab = synth.synth_labels(n, seed)
+        b = {"img": T(synth.normal(seed, "img", (n, 3, size, size)).astype(np.float32)).to(DEV), "label": T(lab).to(DEV),
+             "mask": T(synth.synth_soft_mask(lab, size, seed)).to(DEV)}
+        opt = muscle_amd.FusedAdam(model.parameters(), lr=float(G["lr"]), weight_decay=1e-5)
+        du = {int(i): T(u).to(DEV) for i, u in zip(G["drop_idx"], G["drop_u"])}
+        random.seed(78)
+        crit = muscle_amd.edge.FieldLoss(sobel_size=5, beta=1e2, k=kk)
+        crit.replay_points = (G["replay_b"], G["replay_out"], G["replay_in"])
+        if disturb:
+            bg = torch.cuda.Stream()
+            with torch.cuda.stream(bg):
+                junk = torch.randn(4096, 4096, device=DEV)
+                for _ in range(20):
+                    junk = junk * 1.0001 + 0.5
+        out = muscle_amd.muscle_step(model, opt, b, lamb=float(G["lamb"]), step=step, k=kk, drop_u=du, fused=True, criterion2=crit)
+        torch.cuda.synchronize()
+        runs.append((np.array([float(out["loss_seg"]), float(out["loss_beacon"]), float(out["grad_norm"])], dtype=np.float32),
+                     model.last_grad_sink.arena.cpu().numpy().copy(),
+                     torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()))
+    for tag, x, y in zip(("losses + norm", "gradient arena", "parameters"), *runs):
+        assert np.array_equal(x, y), (tag, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))

@@ -485,32 +485,35 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* pa
 // The pooled-path gradient of the SE block, the BN1 backward sums and their finalisation in one launch:
 //   add[n,c]  = inv_hw * sum_j gh[n,j] W1[j,c]                (d loss / d squeeze input, model.py:82-83 backward; gh from
 //               mx_se_bwd) - owned per (n, c), j in ascending order: no atomics across squeeze slices
-//   sums      = sum_n gate*S1 + add*S2, sum_n gate*S3 + add*S4 (fp64, n ascending)  -> bn_bwd_finalize_one
-// One workgroup = 64 channels x 4 sample lanes; gh [N][SQ] is staged in LDS.
-__global__ __launch_bounds__(256) void bn1_sums_finalize_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* gh,
-                                                                const float* W1, float inv_hw, float* add, int N, int C, int SQ,
-                                                                BnBwdFin b) {
-  extern __shared__ float ghs[];                      // [N][SQ], then 2 x [4][64] doubles
+//   sums      = sum_n gate*S1 + add*S2, sum_n gate*S3 + add*S4 (fp64, n ascending per lane, lanes in order)  -> bn_bwd_finalize_one
+// One workgroup = 64 channels x NL sample lanes (NL = 16: 1024 threads; the kernel is latency-bound - a chain of SQ dependent
+// W1 loads per sample group - so more lanes, not more work per lane: 23.5 -> 12 us at C = 2304); gh [N][SQ] is staged in LDS.
+constexpr int B1_NL = 16;
+__global__ __launch_bounds__(64 * B1_NL) void bn1_sums_finalize_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* gh,
+                                                                      const float* W1, float inv_hw, float* add, int N, int C, int SQ,
+                                                                      BnBwdFin b) {
+  extern __shared__ float ghs[];                      // [N][SQ], then 2 x [NL][64] doubles
   const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  for (int i = threadIdx.x; i < N * SQ; i += 256) ghs[i] = gh[i];
+  for (int i = threadIdx.x; i < N * SQ; i += 64 * B1_NL) ghs[i] = gh[i];
   __syncthreads();
   const long plane = (long)N * C;
   double s0 = 0.0, s1 = 0.0;
   if (c < C) {
-    for (int n0 = nl; n0 < N; n0 += 16) {             // this lane's samples n0, n0+4, n0+8, n0+12: four accumulators per W1 load
-      float a[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int n0 = nl; n0 < N; n0 += 2 * B1_NL) {      // this lane's samples n0 and n0 + NL: two accumulators per W1 load
+      const int n1 = n0 + B1_NL;
+      float a0 = 0.f, a1 = 0.f;
       for (int j = 0; j < SQ; ++j) {
         const float w = W1[(long)j * C + c];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { const int n = n0 + 4 * k; a[k] += (n < N ? ghs[n * SQ + j] : 0.f) * w; }
+        a0 += ghs[n0 * SQ + j] * w;
+        a1 += (n1 < N ? ghs[n1 * SQ + j] : 0.f) * w;
       }
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int n = n0 + 4 * k;
+      for (int k = 0; k < 2; ++k) {
+        const int n = k ? n1 : n0;
         if (n < N) {
           const long i = (long)n * C + c;
-          const float ad = a[k] * inv_hw;
+          const float ad = (k ? a1 : a0) * inv_hw;
           add[i] = ad;
           s0 += (double)gate[i] * pooled[plane + i] + (double)ad * pooled[2 * plane + i];
           s1 += (double)gate[i] * pooled[3 * plane + i] + (double)ad * pooled[4 * plane + i];
@@ -520,11 +523,11 @@ __global__ __launch_bounds__(256) void bn1_sums_finalize_kernel(const float* poo
   }
   double* red = reinterpret_cast<double*>(ghs + ((N * SQ + 1) & ~1));
   __syncthreads();
-  red[nl * 64 + cl] = s0; red[256 + nl * 64 + cl] = s1;
+  red[nl * 64 + cl] = s0; red[B1_NL * 64 + nl * 64 + cl] = s1;
   __syncthreads();
   if (nl != 0 || c >= C) return;
-  s0 = ((red[cl] + red[64 + cl]) + red[128 + cl]) + red[192 + cl];
-  s1 = ((red[256 + cl] + red[320 + cl]) + red[384 + cl]) + red[448 + cl];
+  s0 = red[cl]; s1 = red[B1_NL * 64 + cl];
+  for (int l = 1; l < B1_NL; ++l) { s0 += red[l * 64 + cl]; s1 += red[B1_NL * 64 + l * 64 + cl]; }
   bn_bwd_finalize_one(c, (double)(float)s0, (double)(float)s1, b.count, b.gamma, b.mean, b.rstd, b.training, b.dgamma, b.dbeta,
                       b.c1, b.c2, b.c3);
 }
@@ -690,10 +693,10 @@ int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* g
                          float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream) {
   MX_CHECK_ARG(pooled5 && gate && gh && W1 && add && N > 0 && C > 0 && SQ > 0 && count > 0, "bn1_sums_finalize: bad args");
   MX_CHECK_ARG(gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3, "bn1_sums_finalize: null pointer");
-  const size_t shb = (size_t)((N * SQ + 1) & ~1) * sizeof(float) + 512 * sizeof(double);
+  const size_t shb = (size_t)((N * SQ + 1) & ~1) * sizeof(float) + 2 * B1_NL * 64 * sizeof(double);
   MX_CHECK_ARG(shb <= 64 * 1024, "bn1_sums_finalize: N*SQ = %d too large for LDS staging", N * SQ);
   BnBwdFin b{count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3};
-  hipLaunchKernelGGL(bn1_sums_finalize_kernel, dim3(cdiv(C, 64)), dim3(256), shb, (hipStream_t)stream, pooled5, gate, gh, W1, inv_hw,
+  hipLaunchKernelGGL(bn1_sums_finalize_kernel, dim3(cdiv(C, 64)), dim3(64 * B1_NL), shb, (hipStream_t)stream, pooled5, gate, gh, W1, inv_hw,
                      add, N, C, SQ, b);
   MX_LAUNCH_CHECK();
   return MX_OK;

@@ -54,41 +54,56 @@ __device__ __forceinline__ void dw_stage_weights(const DwArgs& a, float* wl, int
   }
 }
 
-// Stage one input tile.  All global loads of a thread are issued before the first use (the tile needs
-// <= 12 float4 per thread), so a workgroup has its whole tile in flight instead of one line per wave.
+// Stage one input tile in two halves: dw_tile_load issues all global loads of a thread (the tile needs <= 12 float4 per
+// thread), so a workgroup has its whole tile in flight instead of one line per wave; dw_tile_store applies the producer's
+// BatchNorm affine + SiLU and writes the LDS tile.  Split so that the tile loop of the forward can request tile t + 1 before it
+// computes tile t.
+template <int K, int S, int TH, int TW>
+struct DwTile {
+  static constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+  static constexpr int TOT = IH * IW * C4B, PER = (TOT + 255) / 256;
+  float4 v[PER];
+  unsigned ok;
+  __device__ __forceinline__ void load(const DwArgs& a, int n, int oy0, int ox0, int c0, int tid) {
+    const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
+    const int c = c0 + 4 * (tid % C4B);
+    ok = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int i = tid + 256 * k;
+      int pix = i / C4B;
+      int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+      v[k] = make_float4(0, 0, 0, 0);
+      if (i < TOT && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.C) {
+        v[k] = ld4(a.x + (((long)n * a.H + iy) * a.W + ix) * a.C + c);
+        ok |= 1u << k;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(const DwArgs& a, float4* tile, int c0, int tid) const {
+    const int c = c0 + 4 * (tid % C4B);
+    float4 s = make_float4(0, 0, 0, 0), t = s;
+    if (a.sc && c < a.C) { s = ld4(a.sc + c); t = ld4(a.sh + c); }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      int i = tid + 256 * k;
+      if (i < TOT) {
+        float4 x = v[k];
+        if (a.sc && ((ok >> k) & 1u)) {
+          x.x = swishf_(s.x * x.x + t.x); x.y = swishf_(s.y * x.y + t.y);
+          x.z = swishf_(s.z * x.z + t.z); x.w = swishf_(s.w * x.w + t.w);
+        }
+        tile[i] = x;
+      }
+    }
+  }
+};
+
 template <int K, int S, int TH, int TW>
 __device__ __forceinline__ void dw_stage_input(const DwArgs& a, float4* tile, int n, int oy0, int ox0, int c0, int tid) {
-  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
-  constexpr int TOT = IH * IW * C4B, PER = (TOT + 255) / 256;
-  const int iy0 = oy0 * S - a.pad, ix0 = ox0 * S - a.pad;
-  const int c4 = tid % C4B, c = c0 + 4 * c4;
-  float4 v[PER];
-  unsigned ok = 0;
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    int i = tid + 256 * k;
-    int pix = i / C4B;
-    int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-    v[k] = make_float4(0, 0, 0, 0);
-    if (i < TOT && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && c < a.C) {
-      v[k] = ld4(a.x + (((long)n * a.H + iy) * a.W + ix) * a.C + c);
-      ok |= 1u << k;
-    }
-  }
-  float4 s = make_float4(0, 0, 0, 0), t = s;
-  if (a.sc && c < a.C) { s = ld4(a.sc + c); t = ld4(a.sh + c); }
-#pragma unroll
-  for (int k = 0; k < PER; ++k) {
-    int i = tid + 256 * k;
-    if (i < TOT) {
-      float4 x = v[k];
-      if (a.sc && ((ok >> k) & 1u)) {
-        x.x = swishf_(s.x * x.x + t.x); x.y = swishf_(s.y * x.y + t.y);
-        x.z = swishf_(s.z * x.z + t.z); x.w = swishf_(s.w * x.w + t.w);
-      }
-      tile[i] = x;
-    }
-  }
+  DwTile<K, S, TH, TW> t;
+  t.load(a, n, oy0, ox0, c0, tid);
+  t.store(a, tile, c0, tid);
 }
 
 // ---------------------------------------------------------------------------
@@ -101,6 +116,12 @@ __device__ __forceinline__ void dw_stage_input(const DwArgs& a, float4* tile, in
 //   gpp == 0 (training): group g covers tiles [g tpb, (g+1) tpb) of the (sample, tile) sequence, statistics row g;
 //   gpp  > 0 (inference squeeze): a sample's tiles are cut into gpp groups that do not straddle samples; group (n, gi) parks its
 //            partial squeeze row and the last of the gpp groups to arrive adds them in group order (mx_last_arriver).
+// Software pipelining of the tile loop (tile t + 1's global loads in flight while tile t is computed; -DDW_FWD_PREFETCH=1): measured
+// in round 3 and OFF - the 40 staging registers it keeps live cost a wave per SIMD (4 -> 3), 3x3 loses 10-20 %, 5x5 gains 5-12 % on the
+// widest layers only and loses on the rest; whole step 109.0 -> 110.6 ms.  Occupancy, not intra-workgroup overlap, feeds these kernels.
+#ifndef DW_FWD_PREFETCH
+#define DW_FWD_PREFETCH 0
+#endif
 template <int K, int S, int TH, int TW, int OX>
 __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
@@ -130,12 +151,23 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   float4 s = make_float4(0, 0, 0, 0), sq = make_float4(0, 0, 0, 0), p = make_float4(0, 0, 0, 0);
   float4 psc = make_float4(0, 0, 0, 0), psh = psc;
   if (a.pooled && c < a.C) { psc = ld4(a.ps + c); psh = ld4(a.pb + c); }
+  // software pipeline over the tiles: tile t + 1's global loads are in flight while tile t is computed from LDS
+  DwTile<K, S, TH, TW> stg;
+  if (t_beg < t_end) {
+    const int rem0 = (int)(t_beg % ntile);
+    stg.load(a, (int)(t_beg / ntile), (rem0 / a.tiles_x) * TH, (rem0 % a.tiles_x) * TW, c0, tid);
+  }
   for (long t = t_beg; t < t_end; ++t) {
     const int n = (int)(t / ntile), rem = (int)(t % ntile);
     const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
+    if (!DW_FWD_PREFETCH && t > t_beg) stg.load(a, n, oy0, ox0, c0, tid);
     __syncthreads();                               // the previous tile's readers are done (first pass: the weights are staged)
-    dw_stage_input<K, S, TH, TW>(a, tile, n, oy0, ox0, c0, tid);
+    stg.store(a, tile, c0, tid);
     __syncthreads();
+    if (DW_FWD_PREFETCH && t + 1 < t_end) {
+      const int rem1 = (int)((t + 1) % ntile);
+      stg.load(a, (int)((t + 1) / ntile), (rem1 / a.tiles_x) * TH, (rem1 % a.tiles_x) * TW, c0, tid);
+    }
     float4 acc[OX];
 #pragma unroll
     for (int o = 0; o < OX; ++o) acc[o] = make_float4(0, 0, 0, 0);

@@ -153,14 +153,14 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   if (a.pooled && c < a.C) { psc = ld4(a.ps + c); psh = ld4(a.pb + c); }
   // software pipeline over the tiles: tile t + 1's global loads are in flight while tile t is computed from LDS
   DwTile<K, S, TH, TW> stg;
-  if (t_beg < t_end) {
+  if (DW_FWD_PREFETCH && t_beg < t_end) {
     const int rem0 = (int)(t_beg % ntile);
     stg.load(a, (int)(t_beg / ntile), (rem0 / a.tiles_x) * TH, (rem0 % a.tiles_x) * TW, c0, tid);
   }
   for (long t = t_beg; t < t_end; ++t) {
     const int n = (int)(t / ntile), rem = (int)(t % ntile);
     const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
-    if (!DW_FWD_PREFETCH && t > t_beg) stg.load(a, n, oy0, ox0, c0, tid);
+    if (!DW_FWD_PREFETCH) stg.load(a, n, oy0, ox0, c0, tid);
     __syncthreads();                               // the previous tile's readers are done (first pass: the weights are staged)
     stg.store(a, tile, c0, tid);
     __syncthreads();

@@ -89,3 +89,38 @@ def test_infer_kernels_edge_cases():
     assert np.allclose(acc[4].cpu().numpy(), ref, rtol=1e-5)
     # negative channel -> clamped to 0 -> (0 - 0 - 1e-6)/1e-6 = -1
     assert np.allclose(acc[0].cpu().numpy(), -1.0, rtol=1e-5)
+
+
+def test_eval_fold_cache_follows_the_weights():
+    """The cached inference fold (MuSCLe.fold_eval_bn) must never serve weights the model no longer has (round-2 advisor
+    finding): loading through a SUBMODULE, editing a weight or a running statistic in place - none of which goes through
+    MuSCLe.load_state_dict / train() - has to show in the next no-grad eval forward."""
+    import muscle_amd
+    from muscle_amd import synth
+    from muscle_amd.arch import net_cfg
+    name = "efficientnet-b0"
+    cfg = net_cfg(name, False)
+    dev = torch.device("cuda:0")
+
+    def make(seed):
+        m = muscle_amd.MuSCLe(21, name, layers=3, last_pooling=False)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.synth_state_dict(cfg, seed).items()}, strict=True)
+        return m.to(dev).eval()
+
+    x = torch.from_numpy(synth.normal(3, "x", (2, 3, 96, 96)).astype(np.float32)).to(dev)
+    a, b = make(1), make(2)
+    a.fold_eval_bn()
+    with torch.no_grad():
+        ya = [t.clone() for t in a(x, cam="cam_lr")]
+        yb = [t.clone() for t in b(x, cam="cam_lr")]
+    assert not torch.equal(ya[0], yb[0])
+    a.backbone.load_state_dict(b.backbone.state_dict())                 # through a submodule: MuSCLe.load_state_dict is not called
+    a.fuse.load_state_dict(b.fuse.state_dict()); a.fc.load_state_dict(b.fc.state_dict())
+    with torch.no_grad():
+        y2 = a(x, cam="cam_lr")
+    for p, q in zip(y2, yb):
+        assert torch.equal(p, q)
+    with torch.no_grad():
+        a.backbone._blocks[3]._bn1.running_var.mul_(4.0)                # in-place edit of a folded statistic
+        y3 = a(x, cam="cam_lr")
+    assert not torch.equal(y3[0], yb[0])

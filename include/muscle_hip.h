@@ -115,6 +115,15 @@ int mx_bn_finalize(const float* part, int P, int C, double count, const float* g
                    float* running_var, float momentum, float eps, int training, float* scale, float* shift,
                    float* mean, float* rstd, double* acc /* [64][2C] */, void* stream);
 
+/* Inference constants of one MBConv block, one launch (eval-mode BatchNorm, model.py:72-92 under model.eval()):
+ * s = gamma * rsqrt(running_var + eps), t = beta - s * running_mean for each of the block's BatchNorms {g,b,m,v};
+ * We_f[Cexp,Cin] = We * s0[:,None], be = t0 (We == NULL: the block has no expand conv); s1, t1 = BN1's affine;
+ * Wp_f[Cout,Cexp] = Wp * s2[:,None], bp = t2 */
+int mx_fold_block(const float* We, const float* g0, const float* b0, const float* m0, const float* v0, float eps0,
+                  const float* g1, const float* b1, const float* m1, const float* v1, float eps1,
+                  const float* Wp, const float* g2, const float* b2, const float* m2, const float* v2, float eps2,
+                  int Cin, int Cexp, int Cout, float* We_f, float* be, float* s1, float* t1, float* Wp_f, float* bp, void* stream);
+
 /* out = (scale[c]*P + shift[c]) [swish if act] [* gate[n,c]] [* row_scale[n]] [+ residual]
  * (BN2 + drop_connect + skip; with act + gate: the activated, SE-gated project-conv input, model.py:78-84) */
 int mx_bn_apply(const float* P, const float* scale, const float* shift, const float* row_scale, const float* residual,
@@ -357,13 +366,17 @@ int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* g
 /* 4x4/stride-4 average pool over packed crops; table rows of 4 ints {in_off,h,w,out_off}; bwd: in = pooled grad */
 int mx_avgpool4(const float* in, const int* table, int ncrops, float* out, int bwd, void* stream);
 
-/* EMD.dynamic_matching (loss_multilabel.py:287-326).  pairs rows of 6 ints {x_off,n1,y_off,n2,sample,0};
- * scores: Sinkhorn distance of every pair; best: first minimal pair per sample, loss += mean of their scores;
- * grad: gx[crop-1 pixels of each best pair] = d loss / d x (through the 10 iterations), scaled by gscale*(gup?gup[0]:1);
- * traj: nsamples*(11*(maxn1+maxn2)) floats scratch */
-int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, int maxn2, float* score, void* stream);
+/* EMD.dynamic_matching (loss_multilabel.py:287-326).  pairs rows of 6 ints {x_off,n1,y_off,n2,sample,rank}: one workgroup per
+ * row, rows in any order (longest first balances the chip); rank = the pair's position in the reference's enumeration.
+ * scores: Sinkhorn distance of every pair; traj (optional): npairs * 11*(maxn1+maxn2) floats that receive the 11 states
+ *         (u_t, v_t) of every pair, which mx_emd_grad differentiates;
+ * best:   minimal-score pair (row index) per sample, ties to the lower rank (= the first minimal pair of the reference's stable
+ *         sort, :318); loss += mean of their scores;
+ * grad:   gx[crop-1 pixels of each best pair] = d loss / d x (through the 10 iterations), scaled by gscale*(gup?gup[0]:1);
+ *         traj = what mx_emd_scores recorded for the same table */
+int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, int maxn2, float* score, float* traj, void* stream);
 int mx_emd_best(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss, void* stream);
-int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsamples, int maxn1, int maxn2, float* traj,
+int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsamples, int maxn1, int maxn2, const float* traj,
                 const float* gup, float gscale, float* gx, void* stream);
 
 /* ---- decoder mode / config 4: BiFPN support, CE, gradient clipping, BEACON FieldLoss ------------------------------ */

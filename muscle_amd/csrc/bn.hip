@@ -579,7 +579,58 @@ static int grid_for(long total4) {
   return (int)(b < cap ? (b < 1 ? 1 : b) : cap);
 }
 
+// Inference constants of one MBConv block in ONE launch (was ~17 elementwise launches per block, ~900 per network: the
+// no-grad eval forward of train_mcl.py:205-206 refolds every step, because the optimizer has just moved the weights).
+struct FoldArgs {
+  const float *We, *g0, *b0, *m0, *v0, *g1, *b1, *m1, *v1, *Wp, *g2, *b2, *m2, *v2;
+  float eps0, eps1, eps2;
+  int Cin, Cexp, Cout;
+  float *We_f, *be, *s1, *t1, *Wp_f, *bp;
+};
+__global__ __launch_bounds__(256) void fold_block_kernel(FoldArgs a) {
+  const long tid = (long)blockIdx.x * 256 + threadIdx.x, nth = (long)gridDim.x * 256;
+  if (a.We) {
+    for (long i = tid; i < (long)a.Cexp * a.Cin; i += nth) {
+      const int c = (int)(i / a.Cin);
+      a.We_f[i] = a.We[i] * (a.g0[c] * rsqrtf(a.v0[c] + a.eps0));
+    }
+    for (long c = tid; c < a.Cexp; c += nth) {
+      const float s = a.g0[c] * rsqrtf(a.v0[c] + a.eps0);
+      a.be[c] = a.b0[c] - s * a.m0[c];
+    }
+  }
+  for (long c = tid; c < a.Cexp; c += nth) {
+    const float s = a.g1[c] * rsqrtf(a.v1[c] + a.eps1);
+    a.s1[c] = s; a.t1[c] = a.b1[c] - s * a.m1[c];
+  }
+  for (long i = tid; i < (long)a.Cout * a.Cexp; i += nth) {
+    const int c = (int)(i / a.Cexp);
+    a.Wp_f[i] = a.Wp[i] * (a.g2[c] * rsqrtf(a.v2[c] + a.eps2));
+  }
+  for (long c = tid; c < a.Cout; c += nth) {
+    const float s = a.g2[c] * rsqrtf(a.v2[c] + a.eps2);
+    a.bp[c] = a.b2[c] - s * a.m2[c];
+  }
+}
+
 extern "C" {
+
+int mx_fold_block(const float* We, const float* g0, const float* b0, const float* m0, const float* v0, float eps0,
+                  const float* g1, const float* b1, const float* m1, const float* v1, float eps1,
+                  const float* Wp, const float* g2, const float* b2, const float* m2, const float* v2, float eps2,
+                  int Cin, int Cexp, int Cout, float* We_f, float* be, float* s1, float* t1, float* Wp_f, float* bp, void* stream) {
+  MX_CHECK_ARG(Cin > 0 && Cexp > 0 && Cout > 0, "fold_block: bad extents");
+  MX_CHECK_ARG(!We || (g0 && b0 && m0 && v0 && We_f && be), "fold_block: expand weight without its BatchNorm / outputs");
+  MX_CHECK_ARG(g1 && b1 && m1 && v1 && s1 && t1 && Wp && g2 && b2 && m2 && v2 && Wp_f && bp, "fold_block: null pointer");
+  FoldArgs a{We, g0, b0, m0, v0, g1, b1, m1, v1, Wp, g2, b2, m2, v2, eps0, eps1, eps2, Cin, Cexp, Cout, We_f, be, s1, t1, Wp_f, bp};
+  long work = (long)Cexp * (Cin > Cout ? Cin : Cout);
+  int grid = (int)((work + 1023) / 1024);
+  if (grid > 1024) grid = 1024;
+  if (grid < 1) grid = 1;
+  hipLaunchKernelGGL(fold_block_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
 
 int mx_colreduce_parts(long rows, int C) {
   if (rows <= 0 || C <= 0 || C % 4) return MX_EARG;

@@ -290,228 +290,317 @@ __device__ __forceinline__ float dot24(const F24& x, const float* y) {
          dot4(x.f, ld4(y + 20));
 }
 
-// shared layout: xs[n1*24], ys[n2*24], u[n1], v[n2], lmu[n1], lnu[n2], tmp[max(n1,n2)]
-// One Jacobi iteration: both updates use the same (u, v) (loss_multilabel.py:215-217).
-__device__ void emd_iterate(const float* xs, const float* ys, float* u, float* v, const float* lmu, const float* lnu, float* tmp,
-                            int n1, int n2) {
+// Work decomposition.  A sweep gives every "owner" (a row i for the u update, a column j for the v update) the log-sum-exp of
+// its line of M.  One owner per thread leaves most of a 1024-thread workgroup idle (a 49 x 272 pair has 49 rows) and makes the
+// line loop the critical path, so the line of owner o is cut into S = 2^k <= 16 contiguous slices, S * n_own <= 1024: thread
+// (s, o) = threadIdx / n_own, threadIdx % n_own reduces slice s, the partials meet in LDS (pm / ps, indexed by threadIdx) and
+// thread o joins them in slice order.  Neighbouring lanes share s, so the other side's vector is an LDS broadcast read.
+constexpr int EMD_T = 1024;       // threads per workgroup
+constexpr int EMD_MAXS = 16;
+static_assert(EMD_MAXP <= EMD_T, "one owner per thread");
+
+struct EmdSlice { int idx, s, S, lo, hi; };
+__device__ __forceinline__ EmdSlice emd_slice(int n_own, int n_other) {
+  int S = 1;
+  while (S < EMD_MAXS && 2 * S * n_own <= EMD_T) S *= 2;
+  EmdSlice e;
+  e.S = S;
+  e.s = threadIdx.x / n_own; e.idx = threadIdx.x - e.s * n_own;
+  const int chunk = (n_other + S - 1) / S;
+  e.lo = e.s * chunk; e.hi = min(n_other, e.lo + chunk);
+  if (e.s >= S) { e.idx = -1; e.lo = e.hi = 0; }
+  return e;
+}
+
+// (m, s): max and sum exp(M - m) of M_oj = (a_o . b_j - 1 + pa_o + pb_j) / reg over j in [lo, hi), four entries at a time
+__device__ __forceinline__ void emd_lse_part(const F24& ao, float pao, const float* bs, const float* pb, int lo, int hi, float& m,
+                                             float& s) {
   const float ir = 1.f / EMD_REG;
-  // rows: tmp_i = reg*(lmu_i - LSE_j M_ij) + u_i
-  for (int i = threadIdx.x; i < n1; i += blockDim.x) {
-    F24 xi = ld24(xs + i * FP);
-    float ui = u[i], m = -INFINITY, s = 0.f;
-    for (int j = 0; j < n2; ++j) {
-      float M = (dot24(xi, ys + j * FP) - 1.f + ui + v[j]) * ir;
-      if (M > m) { s = s * __expf(m - M) + 1.f; m = M; } else s += __expf(M - m);
-    }
-    tmp[i] = EMD_REG * (lmu[i] - (m + __logf(s))) + ui;
+  m = -INFINITY; s = 0.f;
+  int j = lo;
+  for (; j + 4 <= hi; j += 4) {
+    const float M0 = (dot24(ao, bs + j * FP) - 1.f + pao + pb[j]) * ir;
+    const float M1 = (dot24(ao, bs + (j + 1) * FP) - 1.f + pao + pb[j + 1]) * ir;
+    const float M2 = (dot24(ao, bs + (j + 2) * FP) - 1.f + pao + pb[j + 2]) * ir;
+    const float M3 = (dot24(ao, bs + (j + 3) * FP) - 1.f + pao + pb[j + 3]) * ir;
+    const float mn = fmaxf(fmaxf(fmaxf(M0, M1), fmaxf(M2, M3)), m);
+    s = s * __expf(m - mn) + ((__expf(M0 - mn) + __expf(M1 - mn)) + (__expf(M2 - mn) + __expf(M3 - mn)));
+    m = mn;
+  }
+  for (; j < hi; ++j) {
+    const float M = (dot24(ao, bs + j * FP) - 1.f + pao + pb[j]) * ir;
+    const float mn = fmaxf(M, m);
+    s = s * __expf(m - mn) + __expf(M - mn);
+    m = mn;
+  }
+}
+
+// log-sum-exp of owner o's whole line from its S slice partials, slices in order
+__device__ __forceinline__ float emd_lse_join(const float* pm, const float* ps, int o, int n_own, int S) {
+  float m = -INFINITY;
+  for (int s = 0; s < S; ++s) m = fmaxf(m, pm[s * n_own + o]);
+  float t = 0.f;
+  for (int s = 0; s < S; ++s) {
+    const float ms = pm[s * n_own + o];
+    if (ms > -INFINITY) t += ps[s * n_own + o] * __expf(ms - m);
+  }
+  return m + __logf(t);
+}
+
+// shared layout: xs[n1*24], ys[n2*24], u[n1], v[n2], lmu[n1], lnu[n2], tmp[n1], pm[1024], ps[1024]  (+ gradient: cl[n2], ub[n1], vb[n2])
+struct EmdLds { float *xs, *ys, *u, *v, *lmu, *lnu, *tmp, *pm, *ps, *cl, *ub, *vb; };
+__device__ __forceinline__ EmdLds emd_carve(float* sh, int n1, int n2) {
+  EmdLds L;
+  L.xs = sh; L.ys = L.xs + n1 * FP; L.u = L.ys + n2 * FP; L.v = L.u + n1; L.lmu = L.v + n2; L.lnu = L.lmu + n1; L.tmp = L.lnu + n2;
+  L.pm = L.tmp + n1; L.ps = L.pm + EMD_T; L.cl = L.ps + EMD_T; L.ub = L.cl + n2; L.vb = L.ub + n1;
+  return L;
+}
+
+// One Jacobi iteration: both updates use the same (u, v) (loss_multilabel.py:215-217).
+__device__ void emd_iterate(const EmdLds& L, const EmdSlice& r, const EmdSlice& c, int n1, int n2) {
+  const int tid = threadIdx.x;
+  // rows: u_i' = reg*(lmu_i - LSE_j M_ij) + u_i
+  if (r.idx >= 0) {
+    const F24 xi = ld24(L.xs + r.idx * FP);
+    float m, s;
+    emd_lse_part(xi, L.u[r.idx], L.ys, L.v, r.lo, r.hi, m, s);
+    L.pm[tid] = m; L.ps[tid] = s;
   }
   __syncthreads();
-  // columns (use OLD u): v_j' = reg*(lnu_j - LSE_i M_ij) + v_j, written in place after the sweep
-  float vn[(EMD_MAXP + 255) / 256];
-  int cnt = 0;
-  for (int j = threadIdx.x; j < n2; j += blockDim.x, ++cnt) {
-    F24 yj = ld24(ys + j * FP);
-    float vj = v[j], m = -INFINITY, s = 0.f;
-    for (int i = 0; i < n1; ++i) {
-      float M = (dot24(yj, xs + i * FP) - 1.f + u[i] + vj) * ir;
-      if (M > m) { s = s * __expf(m - M) + 1.f; m = M; } else s += __expf(M - m);
-    }
-    vn[cnt] = EMD_REG * (lnu[j] - (m + __logf(s))) + vj;
+  if (tid < n1) L.tmp[tid] = EMD_REG * (L.lmu[tid] - emd_lse_join(L.pm, L.ps, tid, n1, r.S)) + L.u[tid];
+  __syncthreads();
+  // columns (use OLD u): v_j' = reg*(lnu_j - LSE_i M_ij) + v_j
+  if (c.idx >= 0) {
+    const F24 yj = ld24(L.ys + c.idx * FP);
+    float m, s;
+    emd_lse_part(yj, L.v[c.idx], L.xs, L.u, c.lo, c.hi, m, s);
+    L.pm[tid] = m; L.ps[tid] = s;
   }
   __syncthreads();
-  cnt = 0;
-  for (int j = threadIdx.x; j < n2; j += blockDim.x, ++cnt) v[j] = vn[cnt];
-  for (int i = threadIdx.x; i < n1; i += blockDim.x) u[i] = tmp[i];
+  if (tid < n2) L.v[tid] = EMD_REG * (L.lnu[tid] - emd_lse_join(L.pm, L.ps, tid, n2, c.S)) + L.v[tid];
+  if (tid < n1) L.u[tid] = L.tmp[tid];
   __syncthreads();
 }
 
-__device__ void emd_setup(const float* X, const float* Y, float* xs, float* ys, float* u, float* v, float* lmu, float* lnu,
-                          float* tmp, int n1, int n2) {
-  for (int i = threadIdx.x; i < n1 * FP; i += blockDim.x) xs[i] = X[i];
-  for (int i = threadIdx.x; i < n2 * FP; i += blockDim.x) ys[i] = Y[i];
+__device__ void emd_setup(const float* X, const float* Y, const EmdLds& L, int n1, int n2) {
+  for (int i = threadIdx.x; i < n1 * FP; i += EMD_T) L.xs[i] = X[i];
+  for (int i = threadIdx.x; i < n2 * FP; i += EMD_T) L.ys[i] = Y[i];
   __syncthreads();
-  // weights (get_weight_vector, :250-257): mu_i = x_i . mean(y), nu_j = y_j . mean(x); tmp[0..23], tmp[24..47] hold the means
+  // weights (get_weight_vector, :250-257): mu_i = x_i . mean(y), nu_j = y_j . mean(x); pm[0..23], pm[24..47] hold the means
   if (threadIdx.x < 2 * FP) {
     int k = threadIdx.x % FP;
-    const float* src = (threadIdx.x < FP) ? ys : xs;
+    const float* src = (threadIdx.x < FP) ? L.ys : L.xs;
     int n = (threadIdx.x < FP) ? n2 : n1;
     float s = 0.f;
     for (int i = 0; i < n; ++i) s += src[i * FP + k];
-    tmp[threadIdx.x] = s / n;
+    L.pm[threadIdx.x] = s / n;
   }
   __syncthreads();
   float my[FP], mx[FP];
-  for (int k = 0; k < FP; ++k) { my[k] = tmp[k]; mx[k] = tmp[FP + k]; }
+  for (int k = 0; k < FP; ++k) { my[k] = L.pm[k]; mx[k] = L.pm[FP + k]; }
   __syncthreads();
-  for (int i = threadIdx.x; i < n1; i += blockDim.x) {
+  for (int i = threadIdx.x; i < n1; i += EMD_T) {
     float s = 0.f;
-    for (int k = 0; k < FP; ++k) s += xs[i * FP + k] * my[k];
-    lmu[i] = __logf(s + 1e-6f);
-    u[i] = 0.f;
+    for (int k = 0; k < FP; ++k) s += L.xs[i * FP + k] * my[k];
+    L.lmu[i] = __logf(s + 1e-6f);
+    L.u[i] = 0.f;
   }
-  for (int j = threadIdx.x; j < n2; j += blockDim.x) {
+  for (int j = threadIdx.x; j < n2; j += EMD_T) {
     float s = 0.f;
-    for (int k = 0; k < FP; ++k) s += ys[j * FP + k] * mx[k];
-    lnu[j] = __logf(s + 1e-6f);
-    v[j] = 0.f;
+    for (int k = 0; k < FP; ++k) s += L.ys[j * FP + k] * mx[k];
+    L.lnu[j] = __logf(s + 1e-6f);
+    L.v[j] = 0.f;
   }
   __syncthreads();
 }
 
-// sum_ij exp(M_ij) * C_ij / (n1*n2)
-__device__ float emd_distance(const float* xs, const float* ys, const float* u, const float* v, float* tmp, int n1, int n2) {
+// sum_ij exp(M_ij) * C_ij / (n1*n2): slice partials, then waves in order
+__device__ float emd_distance(const EmdLds& L, const EmdSlice& r, int n1, int n2) {
   const float ir = 1.f / EMD_REG;
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n1; i += blockDim.x) {
-    F24 xi = ld24(xs + i * FP);
-    for (int j = 0; j < n2; ++j) {
-      float c = 1.f - dot24(xi, ys + j * FP);
-      acc += __expf((-c + u[i] + v[j]) * ir) * c;
+  if (r.idx >= 0) {
+    const F24 xi = ld24(L.xs + r.idx * FP);
+    const float ui = L.u[r.idx];
+    for (int j = r.lo; j < r.hi; ++j) {
+      float c = 1.f - dot24(xi, L.ys + j * FP);
+      acc += __expf((-c + ui + L.v[j]) * ir) * c;
     }
   }
   acc = wave_sum(acc);
   __syncthreads();
-  if ((threadIdx.x & 63) == 0) tmp[threadIdx.x >> 6] = acc;
+  if ((threadIdx.x & 63) == 0) L.pm[threadIdx.x >> 6] = acc;
   __syncthreads();
   float t = 0.f;
-  for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += tmp[w];
+  for (int w = 0; w < EMD_T / 64; ++w) t += L.pm[w];
   return t / ((float)n1 * (float)n2);
 }
 
-// 1024 threads: the operands of one pair fill the CU's LDS (up to 150 KB), so one workgroup per CU is all there is; with 256
-// threads the CU ran 4 waves and the row loops were latency-bound.
-__global__ __launch_bounds__(1024) void emd_score_kernel(const float* feat, const int* pairs, float* score) {
+// One workgroup per pair, in table order: the host sorts the table by descending n1 * n2, so the long pairs start first and
+// the short ones fill the tail.  traj (optional): (u_t, v_t) of the 11 Sinkhorn states, which mx_emd_grad differentiates.
+__global__ __launch_bounds__(EMD_T) void emd_score_kernel(const float* feat, const int* pairs, float* score, float* traj,
+                                                          long traj_stride) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int* t = pairs + blockIdx.x * 6;
-  const int n1 = t[1], n2 = t[3];
-  float* xs = sh; float* ys = xs + n1 * FP; float* u = ys + n2 * FP; float* v = u + n1; float* lmu = v + n2;
-  float* lnu = lmu + n1; float* tmp = lnu + n2;
-  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, xs, ys, u, v, lmu, lnu, tmp, n1, n2);
-  for (int it = 0; it < EMD_ITERS; ++it) emd_iterate(xs, ys, u, v, lmu, lnu, tmp, n1, n2);
-  float d = emd_distance(xs, ys, u, v, tmp, n1, n2);
+  const int n1 = t[1], n2 = t[3], nn = n1 + n2;
+  const EmdLds L = emd_carve(sh, n1, n2);
+  const EmdSlice r = emd_slice(n1, n2), c = emd_slice(n2, n1);
+  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, L, n1, n2);
+  float* tr = traj ? traj + blockIdx.x * traj_stride : nullptr;
+  for (int it = 0; it <= EMD_ITERS; ++it) {
+    if (tr) {
+      if (threadIdx.x < n1) tr[it * nn + threadIdx.x] = L.u[threadIdx.x];
+      if (threadIdx.x < n2) tr[it * nn + n1 + threadIdx.x] = L.v[threadIdx.x];
+    }
+    if (it < EMD_ITERS) emd_iterate(L, r, c, n1, n2);
+  }
+  float d = emd_distance(L, r, n1, n2);
   if (threadIdx.x == 0) score[blockIdx.x] = d;
 }
 
-// best[s] = index of the first minimal-score pair of sample s (stable sort semantics, :318); loss += score/ns
+// best[s] = the minimal-score pair of sample s, ties to the lower rank (column 5 = the pair's position in the reference's
+// enumeration order: stable sort semantics, :318); loss += score/ns.  Pairs are spread over the threads; the per-sample
+// minimum is an LDS atomicMin on the 64-bit key (order-preserving score bits, rank) - a minimum does not depend on arrival order.
+__device__ __forceinline__ unsigned emd_ord(float f) {
+  const unsigned u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 __global__ __launch_bounds__(1024) void emd_best_kernel(const float* score, const int* pairs, int npairs, int nsamples, int* best, float* loss) {
+  __shared__ unsigned long long key[1024];
   __shared__ float bsv[1024];
-  const int s = threadIdx.x;
-  float bs = 0.f;
-  if (s < nsamples) {
-    int bi = -1;
-    float b = INFINITY;
-    for (int p = 0; p < npairs; ++p)
-      if (pairs[p * 6 + 4] == s && score[p] < b) { b = score[p]; bi = p; }
-    best[s] = bi;
-    if (bi >= 0) bs = b / nsamples;
-  }
-  bsv[s] = bs;
+  const int tid = threadIdx.x;
+  key[tid] = ~0ull;
+  bsv[tid] = 0.f;
+  if (tid < nsamples) best[tid] = -1;
   __syncthreads();
-  if (s == 0) {                                   // one adder, sample order (was a float atomic per sample)
+  for (int p = tid; p < npairs; p += 1024) {
+    const int s = pairs[p * 6 + 4];
+    if (s >= 0 && s < nsamples)
+      atomicMin(&key[s], ((unsigned long long)emd_ord(score[p]) << 32) | (unsigned)pairs[p * 6 + 5]);
+  }
+  __syncthreads();
+  for (int p = tid; p < npairs; p += 1024) {
+    const int s = pairs[p * 6 + 4];
+    if (s >= 0 && s < nsamples && key[s] == (((unsigned long long)emd_ord(score[p]) << 32) | (unsigned)pairs[p * 6 + 5])) {
+      best[s] = p;                                // ranks are unique within a table: one writer per sample
+      bsv[s] = score[p] / nsamples;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {                                 // one adder, sample order (was a float atomic per sample)
     float t = 0.f;
     for (int i = 0; i < nsamples; ++i) t += bsv[i];
     loss[0] += t;
   }
 }
 
-// backward through the 10 iterations for the best pair of each sample: gx[best crop1 pixels, 24] = d dist / d x * gscale
-// traj: per block (EMD_ITERS+1) * (n1 + n2) floats of (u_t, v_t), in global scratch
-template <int BLOCK>
-__global__ __launch_bounds__(BLOCK) void emd_grad_kernel(const float* feat, const int* pairs, const int* best, float* traj,
-                                                       long traj_stride, const float* gup, float gscale, float* gx) {
+// backward through the 10 iterations for the best pair of each sample: gx[best crop1 pixels, 24] = d dist / d x * gscale.
+// traj: the states mx_emd_scores recorded, row `pair` holds (EMD_ITERS+1) * (n1 + n2) floats of (u_t, v_t).
+// Same slice decomposition as the forward; every thread keeps the 24 gradient terms of its (row, slice) in registers through
+// all stages and the slices of a row are added in order at the end (in the LDS that held x).
+__global__ __launch_bounds__(EMD_T) void emd_grad_kernel(const float* feat, const int* pairs, const int* best, const float* traj,
+                                                         long traj_stride, const float* gup, float gscale, float* gx) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int bi = best[blockIdx.x];
   if (bi < 0) return;
   if (gup) gscale *= gup[0];
   const int* t = pairs + bi * 6;
-  const int n1 = t[1], n2 = t[3];
-  float* xs = sh; float* ys = xs + n1 * FP; float* u = ys + n2 * FP; float* v = u + n1; float* lmu = v + n2;
-  float* lnu = lmu + n1; float* tmp = lnu + n2;
-  float* ub = tmp + (n1 > n2 ? n1 : n2);   // adjoint of u  [n1]
-  float* vb = ub + n1;                      // adjoint of v  [n2]
-  float* tr = traj + blockIdx.x * traj_stride;
-  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, xs, ys, u, v, lmu, lnu, tmp, n1, n2);
-  const int nn = n1 + n2;
-  for (int it = 0; it <= EMD_ITERS; ++it) {
-    for (int i = threadIdx.x; i < n1; i += blockDim.x) tr[it * nn + i] = u[i];
-    for (int j = threadIdx.x; j < n2; j += blockDim.x) tr[it * nn + n1 + j] = v[j];
-    if (it < EMD_ITERS) emd_iterate(xs, ys, u, v, lmu, lnu, tmp, n1, n2);
-  }
-  __syncthreads();
+  const int n1 = t[1], n2 = t[3], nn = n1 + n2, tid = threadIdx.x;
+  const EmdLds L = emd_carve(sh, n1, n2);
+  const EmdSlice r = emd_slice(n1, n2), c = emd_slice(n2, n1);
+  const float* tr = traj + bi * traj_stride;
+  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, L, n1, n2);
   const float ir = 1.f / EMD_REG, inv12 = 1.f / ((float)n1 * (float)n2);
-  // per-thread gradient accumulators for the rows it owns
-  constexpr int RPT = (EMD_MAXP + BLOCK - 1) / BLOCK;      // rows per thread
-  float gxl[RPT][FP];
-  for (int q = 0; q < RPT; ++q)
-    for (int k = 0; k < FP; ++k) gxl[q][k] = 0.f;
-  // final stage: Mbar_ij = pi_ij * Cd_ij / (n1 n2); Cbar += -Mbar/reg (the explicit Cd factor is detached); ubar_i = sum_j Mbar/reg ...
+  float gxl[FP];
+#pragma unroll
+  for (int k = 0; k < FP; ++k) gxl[k] = 0.f;
+  // final stage, on the last state: Mbar_ij = pi_ij * Cd_ij / (n1 n2); Cbar += -Mbar/reg (the explicit Cd factor is detached);
+  // ubar_i = sum_j Mbar/reg, vbar_j = sum_i Mbar/reg
+  if (tid < n1) L.u[tid] = tr[EMD_ITERS * nn + tid];
+  if (tid < n2) L.v[tid] = tr[EMD_ITERS * nn + n1 + tid];
+  __syncthreads();
   {
-    int q = 0;
-    for (int i = threadIdx.x; i < n1; i += blockDim.x, ++q) {
-      F24 xi = ld24(xs + i * FP);
-      float us = 0.f;
-      for (int j = 0; j < n2; ++j) {
-        float c = 1.f - dot24(xi, ys + j * FP);
-        float mb = __expf((-c + u[i] + v[j]) * ir) * c * inv12 * ir;   // Mbar / reg
+    float us = 0.f, vs = 0.f;
+    if (r.idx >= 0) {
+      const F24 xi = ld24(L.xs + r.idx * FP);
+      const float ui = L.u[r.idx];
+      for (int j = r.lo; j < r.hi; ++j) {
+        const float* y = L.ys + j * FP;
+        const float cst = 1.f - dot24(xi, y);
+        const float mb = __expf((-cst + ui + L.v[j]) * ir) * cst * inv12 * ir;   // Mbar / reg
         us += mb;
         // Cbar_ij = -mb ; dC/dx_i = -y_j  ->  gx_i += mb * y_j
-        for (int k = 0; k < FP; ++k) gxl[q][k] += mb * ys[j * FP + k];
+#pragma unroll
+        for (int k = 0; k < FP; ++k) gxl[k] += mb * y[k];
       }
-      ub[i] = us;
     }
-    for (int j = threadIdx.x; j < n2; j += blockDim.x) {
-      F24 yj = ld24(ys + j * FP);
-      float vs = 0.f;
-      for (int i = 0; i < n1; ++i) {
-        float c = 1.f - dot24(yj, xs + i * FP);
-        vs += __expf((-c + u[i] + v[j]) * ir) * c * inv12 * ir;
+    if (c.idx >= 0) {
+      const F24 yj = ld24(L.ys + c.idx * FP);
+      const float vj = L.v[c.idx];
+      for (int i = c.lo; i < c.hi; ++i) {
+        const float cst = 1.f - dot24(yj, L.xs + i * FP);
+        vs += __expf((-cst + L.u[i] + vj) * ir) * cst * inv12 * ir;
       }
-      vb[j] = vs;
     }
-    __syncthreads();
+    L.pm[tid] = us; L.ps[tid] = vs;
   }
   for (int it = EMD_ITERS - 1; it >= 0; --it) {
+    __syncthreads();                              // the sweeps of the stage above are done: its u, v, tmp, cl, ub, vb are free
+    // join the slice partials of the stage above into the adjoints this stage consumes, and stage this stage's state:
+    // u, v = state `it`; tmp_i = rowLSE_i = lmu_i - (u'_i - u_i)/reg ; cl_j = colLSE_j = lnu_j - (v'_j - v_j)/reg
     const float* ut = tr + it * nn;
-    const float* vt = ut + n1;
-    const float* un = tr + (it + 1) * nn;
-    const float* vn = un + n1;
-    // P_ij = exp(M_ij - rowLSE_i), rowLSE_i = lmu_i - (u'_i - u_i)/reg ; Q_ij = exp(M_ij - colLSE_j)
+    const float* un = ut + nn;
+    if (tid < n1) {
+      float ubn = 0.f;
+      for (int s = 0; s < r.S; ++s) ubn += L.pm[s * n1 + tid];
+      const float a = ut[tid];
+      L.ub[tid] = ubn; L.u[tid] = a; L.tmp[tid] = L.lmu[tid] - (un[tid] - a) * ir;
+    }
+    if (tid < n2) {
+      float vbn = 0.f;
+      for (int s = 0; s < c.S; ++s) vbn += L.ps[s * n2 + tid];
+      const float a = ut[n1 + tid];
+      L.vb[tid] = vbn; L.v[tid] = a; L.cl[tid] = L.lnu[tid] - (un[n1 + tid] - a) * ir;
+    }
+    __syncthreads();                              // pm / ps are read, the stage's vectors are in place
+    // P_ij = exp(M_ij - rowLSE_i), Q_ij = exp(M_ij - colLSE_j)
     // Cbar_ij += ub'_i P_ij + vb'_j Q_ij  ->  gx_i -= (...) y_j ; ub_i = -sum_j vb'_j Q_ij ; vb_j = -sum_i ub'_i P_ij
-    int q = 0;
-    for (int i = threadIdx.x; i < n1; i += blockDim.x, ++q) {
-      F24 xi = ld24(xs + i * FP);
-      const float rl = lmu[i] - (un[i] - ut[i]) * ir, ubi = ub[i];
-      float nu_ = 0.f;
-      for (int j = 0; j < n2; ++j) {
-        float M = (dot24(xi, ys + j * FP) - 1.f + ut[i] + vt[j]) * ir;
-        float P = __expf(M - rl);
-        float Q = __expf(M - (lnu[j] - (vn[j] - vt[j]) * ir));
-        float cb = ubi * P + vb[j] * Q;
-        nu_ -= vb[j] * Q;
-        for (int k = 0; k < FP; ++k) gxl[q][k] -= cb * ys[j * FP + k];
+    float nu_ = 0.f, acc = 0.f;
+    if (r.idx >= 0) {
+      const F24 xi = ld24(L.xs + r.idx * FP);
+      const float ui = L.u[r.idx], rl = L.tmp[r.idx], ubi = L.ub[r.idx];
+      for (int j = r.lo; j < r.hi; ++j) {
+        const float* y = L.ys + j * FP;
+        const float M = (dot24(xi, y) - 1.f + ui + L.v[j]) * ir;
+        const float P = __expf(M - rl);
+        const float vq = L.vb[j] * __expf(M - L.cl[j]);
+        const float cb = ubi * P + vq;
+        nu_ -= vq;
+#pragma unroll
+        for (int k = 0; k < FP; ++k) gxl[k] -= cb * y[k];
       }
-      tmp[i] = nu_;
     }
-    float vnew[RPT];
-    int c2 = 0;
-    for (int j = threadIdx.x; j < n2; j += blockDim.x, ++c2) {
-      F24 yj = ld24(ys + j * FP);
-      float acc = 0.f;
-      for (int i = 0; i < n1; ++i) {
-        float M = (dot24(yj, xs + i * FP) - 1.f + ut[i] + vt[j]) * ir;
-        acc -= ub[i] * __expf(M - (lmu[i] - (un[i] - ut[i]) * ir));
+    if (c.idx >= 0) {
+      const F24 yj = ld24(L.ys + c.idx * FP);
+      const float vj = L.v[c.idx];
+      for (int i = c.lo; i < c.hi; ++i) {
+        const float M = (dot24(yj, L.xs + i * FP) - 1.f + L.u[i] + vj) * ir;
+        acc -= L.ub[i] * __expf(M - L.tmp[i]);
       }
-      vnew[c2] = acc;
     }
-    __syncthreads();
-    c2 = 0;
-    for (int j = threadIdx.x; j < n2; j += blockDim.x, ++c2) vb[j] = vnew[c2];
-    for (int i = threadIdx.x; i < n1; i += blockDim.x) ub[i] = tmp[i];
+    L.pm[tid] = nu_; L.ps[tid] = acc;
+  }
+  // slices of a row, in order, into the LDS that held x
+  __syncthreads();
+  for (int s = 0; s < r.S; ++s) {
+    if (r.idx >= 0 && r.s == s) {
+      float* d = L.xs + r.idx * FP;
+#pragma unroll
+      for (int k = 0; k < FP; ++k) d[k] = (s ? d[k] : 0.f) + gxl[k];
+    }
     __syncthreads();
   }
-  int q = 0;
-  for (int i = threadIdx.x; i < n1; i += blockDim.x, ++q)
-    for (int k = 0; k < FP; ++k) gx[((long)t[0] + i) * FP + k] = gxl[q][k] * gscale;
+  float* out = gx + (long)t[0] * FP;
+  for (int e = tid; e < n1 * FP; e += EMD_T) out[e] = L.xs[e] * gscale;
 }
 
 static int gs(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
@@ -569,19 +658,19 @@ int mx_avgpool4(const float* in, const int* table, int ncrops, float* out, int b
 }
 
 static size_t emd_lds(int maxn1, int maxn2, int grad) {
-  size_t f = (size_t)(maxn1 + maxn2) * FP + 2 * (size_t)(maxn1 + maxn2) + (size_t)(maxn1 > maxn2 ? maxn1 : maxn2);
-  if (f < (size_t)(maxn1 + maxn2) * FP + 2 * (size_t)(maxn1 + maxn2) + 2 * FP) f += 2 * FP;
-  if (grad) f += (size_t)(maxn1 + maxn2);
+  size_t f = (size_t)(maxn1 + maxn2) * FP + 2 * (size_t)(maxn1 + maxn2) + (size_t)maxn1 + 2 * EMD_T;
+  if (grad) f += (size_t)(maxn1 + 2 * maxn2);
   return f * sizeof(float);
 }
 
-int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, int maxn2, float* score, void* stream) {
+int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, int maxn2, float* score, float* traj, void* stream) {
   MX_CHECK_ARG(feat && pairs && score && npairs > 0, "emd_scores: bad args");
   MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_scores: crop larger than %d pixels", EMD_MAXP);
-  size_t sh = emd_lds(maxn1 < 2 * FP ? 2 * FP : maxn1, maxn2 < 2 * FP ? 2 * FP : maxn2, 0);
+  size_t sh = emd_lds(maxn1, maxn2, 0);
   MX_CHECK_ARG(sh <= 160 * 1024, "emd_scores: LDS need %zu exceeds 160 KiB", sh);
   if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  hipLaunchKernelGGL(emd_score_kernel, dim3(npairs), dim3(1024), sh, (hipStream_t)stream, feat, pairs, score);
+  const long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
+  hipLaunchKernelGGL(emd_score_kernel, dim3(npairs), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, score, traj, stride);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -593,15 +682,15 @@ int mx_emd_best(const float* score, const int* pairs, int npairs, int nsamples, 
   return MX_OK;
 }
 
-int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsamples, int maxn1, int maxn2, float* traj,
+int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsamples, int maxn1, int maxn2, const float* traj,
                 const float* gup, float gscale, float* gx, void* stream) {
   MX_CHECK_ARG(feat && pairs && best && traj && gx && nsamples > 0, "emd_grad: bad args");
   MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_grad: crop larger than %d pixels", EMD_MAXP);
-  size_t sh = emd_lds(maxn1 < 2 * FP ? 2 * FP : maxn1, maxn2 < 2 * FP ? 2 * FP : maxn2, 1);
+  size_t sh = emd_lds(maxn1, maxn2, 1);
   MX_CHECK_ARG(sh <= 160 * 1024, "emd_grad: LDS need %zu exceeds 160 KiB", sh);
-  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
-  long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
-  hipLaunchKernelGGL(emd_grad_kernel<1024>, dim3(nsamples), dim3(1024), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
+  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+  const long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
+  hipLaunchKernelGGL(emd_grad_kernel, dim3(nsamples), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
                      gx);
   MX_LAUNCH_CHECK();
   return MX_OK;

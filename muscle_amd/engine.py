@@ -86,12 +86,6 @@ def stem_weight28(backbone):
     return w28
 
 
-def _bn_affine(bn: torch.nn.BatchNorm2d):
-    """Eval-mode BatchNorm as y = s*z + t (running statistics)."""
-    s = bn.weight.detach() * torch.rsqrt(bn.running_var + bn.eps)
-    return s, bn.bias.detach() - s * bn.running_mean
-
-
 def _fold_sources(backbone, cfg: NetCfg):
     """Every tensor the inference fold is computed from."""
     for b in cfg.blocks:
@@ -113,22 +107,14 @@ def fold_fingerprint(backbone, cfg: NetCfg):
 def fold_eval_bn(backbone, cfg: NetCfg):
     """Inference-only constants of every block (infer_mcl.py:107-125 runs the model in eval mode): BN0 folded into the
     expand weight (+ bias), BN2 folded into the project weight (+ bias), BN1 as scale / shift for the depthwise kernel's
-    SE squeeze and the project GEMM's operand prologue.  A handful of tiny elementwise launches per block: done once per
-    model load by MuSCLe.fold_eval_bn(), or per forward when no cache is installed (always correct)."""
+    SE squeeze and the project GEMM's operand prologue.  One launch per block (mx_fold_block): done once per model load by
+    MuSCLe.fold_eval_bn(), or per forward when no cache is installed (always correct; the no-grad forward of view 2 in
+    the training loop, train_mcl.py:205-206, is that case: the weights have just been stepped)."""
     out = {}
     for b in cfg.blocks:
         m = _blk(backbone, b.index)
-        f = {}
-        if b.expand:
-            s0, t0 = _bn_affine(m._bn0)
-            f["We"] = (m._expand_conv.weight.detach().view(b.cexp, b.cin) * s0[:, None]).contiguous()
-            f["be"] = t0.contiguous()
-        s1, t1 = _bn_affine(m._bn1)
-        f["bn1"] = BNState(s1.contiguous(), t1.contiguous(), None, None)
-        s2, t2 = _bn_affine(m._bn2)
-        f["Wp"] = (m._project_conv.weight.detach().view(b.cout, b.cexp) * s2[:, None]).contiguous()
-        f["bp"] = t2.contiguous()
-        out[b.index] = f
+        out[b.index] = ops.fold_block(m._expand_conv.weight.view(b.cexp, b.cin) if b.expand else None, m._bn0 if b.expand else None,
+                                      m._bn1, m._project_conv.weight.view(b.cout, b.cexp), m._bn2)
     dev = backbone._conv_stem.weight.device
     cmax = max(b.cexp for b in cfg.blocks)
     out["one"] = torch.ones(cmax, dtype=torch.float32, device=dev)

@@ -184,6 +184,27 @@ def bn_finalize(stats, count, bn: torch.nn.BatchNorm2d, training: bool) -> BNSta
     return BNState(b0, b1, b2, b3)
 
 
+def fold_block(We, bn0, bn1, Wp, bn2):
+    """Eval-mode BatchNorm folded into one block's 1x1 convolutions (mx_fold_block): dict We / be / bn1 / Wp / bp."""
+    dev = Wp.device
+    cout, cexp = Wp.shape
+    cin = We.shape[1] if We is not None else cexp
+    f = {}
+    vec = _f32(3, cexp, device=dev)
+    if We is not None:
+        f["We"], f["be"] = _f32(cexp, cin, device=dev), vec[0]
+    f["bn1"] = BNState(vec[1], vec[2], None, None)
+    f["Wp"], f["bp"] = _f32(cout, cexp, device=dev), _f32(cout, device=dev)
+
+    def four(bn):
+        return (ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps))
+    none4 = (None, None, None, None, 0.0)
+    call("mx_fold_block", ptr(We.detach()) if We is not None else None, *(four(bn0) if We is not None else none4), *four(bn1),
+         ptr(Wp.detach()), *four(bn2), cin, cexp, cout, ptr(f.get("We")), ptr(f.get("be")), ptr(vec[1]), ptr(vec[2]),
+         ptr(f["Wp"]), ptr(f["bp"]), stream())
+    return f
+
+
 _acc_bufs: dict = {}
 
 

@@ -143,9 +143,50 @@ class _CropPlan:
     pass
 
 
-def _plan_crops(coord1, coord2, geometry):
-    c1 = coord1.detach().cpu().numpy().astype(np.int64)
-    c2 = coord2.detach().cpu().numpy().astype(np.int64)
+_copy_streams: dict = {}
+
+
+class HostCoords:
+    """coord1 / coord2 on their way to the host.  get_dynamic_crops decides the crop windows on the host
+    (torchutils.py:217-291 is Python), and a plain `.cpu()` in the middle of the step makes the host wait for everything
+    enqueued so far - phase 1 and both phase-2 forwards - and then enqueue the ~1000 launches of the backward with the GPU
+    idle.  The coordinates are inputs of the step: mcl_step starts this copy on a stream of its own before it enqueues
+    anything, and planning waits for that copy alone."""
+
+    def __init__(self, coord1: torch.Tensor, coord2: torch.Tensor):
+        dev = coord1.device
+        key = dev.index if dev.index is not None else torch.cuda.current_device()
+        side = _copy_streams.get(key)
+        if side is None:
+            side = _copy_streams[key] = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))          # whatever produced the batch
+        self.host = []
+        with torch.cuda.stream(side):
+            for c in (coord1, coord2):
+                c = c.detach()
+                h = torch.empty(c.shape, dtype=c.dtype, pin_memory=True)
+                h.copy_(c, non_blocking=True)
+                c.record_stream(side)
+                self.host.append(h)
+            self.done = side.record_event()
+
+    def numpy(self):
+        self.done.synchronize()
+        return tuple(h.numpy().astype(np.int64) for h in self.host)
+
+
+def prefetch_coords(batch):
+    """Start the device-to-host copy of the view coordinates (None when they already live on the host)."""
+    c1, c2 = batch["coord1"], batch["coord2"]
+    return HostCoords(c1, c2) if c1.is_cuda and c2.is_cuda else None
+
+
+def _plan_crops(coord1, coord2, geometry, host: Optional[HostCoords] = None):
+    if host is not None:
+        c1, c2 = host.numpy()
+    else:
+        c1 = coord1.detach().cpu().numpy().astype(np.int64)
+        c2 = coord2.detach().cpu().numpy().astype(np.int64)
     t1, t2, pool = [], [], []            # resize tables for view 1 / view 2, pool table
     per1, per2, bidx = [], [], []
     fixups = []                          # (list, index) entries whose offset must be shifted into the pooled region
@@ -202,6 +243,11 @@ def _plan_crops(coord1, coord2, geometry):
     return p
 
 
+def _table(rows, dev):
+    """int32 table to the device through pinned memory: a copy from pageable memory makes the host wait for the stream."""
+    return torch.tensor(rows, dtype=torch.int32).pin_memory().to(dev, non_blocking=True)
+
+
 class _Crops(torch.autograd.Function):
     """feat = packed crops of (x1 -> gradient, x2 -> no gradient)."""
 
@@ -211,7 +257,7 @@ class _Crops(torch.autograd.Function):
         N, K, H, W = x1.shape
         dev = x1.device
         feat = torch.zeros(plan.total + 4, FP, dtype=torch.float32, device=dev)
-        it = lambda rows: torch.tensor(rows, dtype=torch.int32, device=dev)  # noqa: E731
+        it = lambda rows: _table(rows, dev)  # noqa: E731
         tabs = {"t1": it(plan.t1), "t2": it(plan.t2), "pool": it(plan.pool) if plan.pool else None}
         call("mx_crop_resize", ptr(x1), ptr(tabs["t1"]), len(plan.t1), ptr(feat), K, H, W, stream())
         call("mx_crop_resize", ptr(x2), ptr(tabs["t2"]), len(plan.t2), ptr(feat), K, x2.shape[2], x2.shape[3], stream())
@@ -232,11 +278,12 @@ class _Crops(torch.autograd.Function):
         return gx1, None, None
 
 
-def get_dynamic_crops(x1, coord1, x2, coord2, geometry: Optional[Sequence] = None):
+def get_dynamic_crops(x1, coord1, x2, coord2, geometry: Optional[Sequence] = None, host_coords: Optional[HostCoords] = None):
     """torchutils.get_dynamic_crops.  Returns (crops1, crops2, batch_indices) where crops1/crops2 are CropSet
     views of one packed device buffer (gradient flows to x1 only, as x2 arrives detached at train_mcl.py:220).
-    `geometry` replays recorded draws; otherwise np.random is consumed in the reference's order."""
-    plan = _plan_crops(coord1, coord2, geometry)
+    `geometry` replays recorded draws; otherwise np.random is consumed in the reference's order.
+    `host_coords`: a copy of the coordinates started earlier (prefetch_coords), so that planning does not drain the stream."""
+    plan = _plan_crops(coord1, coord2, geometry, host_coords)
     if not plan.per1:
         return CropSet(None, [], x1.shape[1]), CropSet(None, [], x1.shape[1]), []
     feat = _Crops.apply(x1, x2.detach(), plan)
@@ -252,16 +299,21 @@ class _EMD(torch.autograd.Function):
     @staticmethod
     def forward(ctx, feat, plan):
         dev = feat.device
-        pairs = torch.tensor(plan.pairs, dtype=torch.int32, device=dev)
-        npairs, ns = len(plan.pairs), len(plan.per1)
-        m1 = max(p[1] for p in plan.pairs)
-        m2 = max(p[3] for p in plan.pairs)
+        # one workgroup per pair: longest first, so the short pairs fill the tail; column 5 keeps the reference's enumeration
+        # order for the tie-break of the per-sample minimum
+        rows = sorted(([*p[:5], rank] for rank, p in enumerate(plan.pairs)), key=lambda p: -p[1] * p[3])
+        pairs = _table(rows, dev)
+        npairs, ns = len(rows), len(plan.per1)
+        m1 = max(p[1] for p in rows)
+        m2 = max(p[3] for p in rows)
         score = torch.empty(npairs, dtype=torch.float32, device=dev)
         best = torch.empty(ns, dtype=torch.int32, device=dev)
         loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        call("mx_emd_scores", ptr(feat), ptr(pairs), npairs, m1, m2, ptr(score), stream())
+        traj = torch.empty(npairs * 11 * (m1 + m2), dtype=torch.float32, device=dev) if ctx.needs_input_grad[0] else None
+        call("mx_emd_scores", ptr(feat), ptr(pairs), npairs, m1, m2, ptr(score), ptr(traj) if traj is not None else None, stream())
         call("mx_emd_best", ptr(score), ptr(pairs), npairs, ns, ptr(best), ptr(loss), stream())
         ctx.save_for_backward(feat, pairs, best)
+        ctx.traj = traj
         ctx.dims = (ns, m1, m2)
         return loss[0]
 
@@ -270,9 +322,9 @@ class _EMD(torch.autograd.Function):
         feat, pairs, best = ctx.saved_tensors
         ns, m1, m2 = ctx.dims
         gx = torch.zeros_like(feat)
-        traj = torch.empty(ns * 11 * (m1 + m2), dtype=torch.float32, device=feat.device)
         gup = g.contiguous().float().reshape(1)
-        call("mx_emd_grad", ptr(feat), ptr(pairs), ptr(best), ns, m1, m2, ptr(traj), ptr(gup), 1.0 / ns, ptr(gx), stream())
+        call("mx_emd_grad", ptr(feat), ptr(pairs), ptr(best), ns, m1, m2, ptr(ctx.traj), ptr(gup), 1.0 / ns, ptr(gx), stream())
+        ctx.traj = None
         return gx, None
 
 
@@ -290,7 +342,7 @@ class EMD(object):
 # ---------------------------------------------------------------------------
 # the second half of the loop body
 # ---------------------------------------------------------------------------
-def run(model, optimizer, batch, ep, label_with_bg, out, crop_geom=None, grad_hook=None):
+def run(model, optimizer, batch, ep, label_with_bg, out, crop_geom=None, grad_hook=None, host_coords=None):
     model.eval()
     view1, view2 = batch["view1"], batch["view2"]
     _, sgcs_vw1 = model(view1, cam="pix")
@@ -302,7 +354,7 @@ def run(model, optimizer, batch, ep, label_with_bg, out, crop_geom=None, grad_ho
     if ep >= 12:
         vw1 = normalize_channels(cam_softmaxnorm(sgcs_vw1))
         vw2 = normalize_channels(cam_softmaxnorm(cams_vw2))
-        c1, c2, _ = get_dynamic_crops(vw1, batch["coord1"], vw2.detach(), batch["coord2"], crop_geom)
+        c1, c2, _ = get_dynamic_crops(vw1, batch["coord1"], vw2.detach(), batch["coord2"], crop_geom, host_coords)
         out["loss_emd"] = EMD()(c1, c2, mode="dynamic")
         # train_mcl.py:211 binds `loss` to the loss_pixpro tensor and :224 adds in place: the value reported as
         # loss_pixpro from epoch 12 on is pixpro + emd

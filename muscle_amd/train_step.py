@@ -155,6 +155,10 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
     """
     img, label = batch["img"], batch["label"].float()
     out: Dict[str, object] = {}
+    host_coords = None
+    if ep >= 12:
+        from . import phase2
+        host_coords = phase2.prefetch_coords(batch)     # the crop planning of phase 2 reads them on the host
     optimizer.zero_grad()
     if not model.training:             # (walking ~150 submodules costs 0.65 ms of host time per call)
         model.train()
@@ -194,7 +198,7 @@ def mcl_step(model, optimizer, batch: Dict[str, torch.Tensor], ep: int, *, drop_
     out["loss_emd"] = 0
     if ep >= 8:
         from . import phase2
-        phase2.run(model, optimizer, batch, ep, label_with_bg, out, crop_geom=crop_geom, grad_hook=grad_hook)
+        phase2.run(model, optimizer, batch, ep, label_with_bg, out, crop_geom=crop_geom, grad_hook=grad_hook, host_coords=host_coords)
     return out
 
 

@@ -36,7 +36,10 @@ static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that o
     for (int tc : cand) {
       if (tc > g.c4) continue;
       const double util = (double)g.c4 / (double)(cdiv(g.c4, tc) * tc) * (double)(256 / tc * tc) / 256.0;
-      if (util > best + 1e-9) { best = util; g.tcols = tc; }
+      // per-sample reductions (groups > 1) take the NARROWEST of equally good widths: more column chunks mean fewer row
+      // blocks per sample, and the last arriver adds a sample's row blocks one after the other (C = 960 as one 240-wide
+      // chunk cut every sample into 32 row blocks: a 160-load chain at the end of se_bn1_pool, 84 us against 40)
+      if (groups > 1 ? util > best - 1e-9 : util > best + 1e-9) { best = util; g.tcols = tc; }
     }
   }
   g.rpp = 256 / g.tcols;
@@ -96,6 +99,18 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
     long r = r0 + tr;
     const long st = g.rpp;
     float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, c0 = b0, c1 = b0, d0 = b0, d1 = b0;
+    if (NOUT == 1) {
+      for (; r + 7 * st < r1; r += 8 * st) {     // one-tensor reductions (pooling): eight independent rows in flight
+        f.eval(r, 4 * c4, a0, a1);
+        f.eval(r + st, 4 * c4, b0, b1);
+        f.eval(r + 2 * st, 4 * c4, c0, c1);
+        f.eval(r + 3 * st, 4 * c4, d0, d1);
+        f.eval(r + 4 * st, 4 * c4, a0, a1);
+        f.eval(r + 5 * st, 4 * c4, b0, b1);
+        f.eval(r + 6 * st, 4 * c4, c0, c1);
+        f.eval(r + 7 * st, 4 * c4, d0, d1);
+      }
+    }
     for (; r + 3 * st < r1; r += 4 * st) {       // four independent rows in flight
       f.eval(r, 4 * c4, a0, a1);
       f.eval(r + st, 4 * c4, b0, b1);

@@ -44,7 +44,8 @@ for C, H in shapes:
     if "pool" in which:
         t = timeit(lambda: ops.pool_sum(X, H * H, st=st, act=True))
         t2 = timeit(lambda: ops.pool_sum(X, H * H, G=G, st=st, act=True))
-        print(f"pool   C={C:5d} H={H:4d}: fwd {t*1e6:7.1f}us {gb/t:7.1f} GB/s | bwd {t2*1e6:7.1f}us {2*gb/t2:7.1f} GB/s")
+        t3 = timeit(lambda: ops.se_bn1_pool(G, X, st, H * H))
+        print(f"pool   C={C:5d} H={H:4d}: fwd {t*1e6:7.1f}us {gb/t:7.1f} GB/s | bwd {t2*1e6:7.1f}us {2*gb/t2:7.1f} GB/s | se_bn1_pool {t3*1e6:7.1f}us {2*gb/t3:7.1f} GB/s")
     if "dw" in which:
         for K in (3, 5):
             W = torch.randn(C, 1, K, K, device=dev)

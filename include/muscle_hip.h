@@ -64,6 +64,9 @@ int mx_gemm_uses_split(int kind, int M, int N, int K);
 
 /* dst[cols,rows] = src[rows,cols]^T (conv weights): the data gradient runs as mx_pw_fwd against the transposed weight. */
 int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream);
+/* n such transposes in one launch (every 1x1 conv weight of the network, once per step).  table: DEVICE array of n rows of 5 longs
+ * {src, dst, rows, cols, first_tile}; first_tile = running sum of ceil(rows/32)*ceil(cols/32), total_tiles = the full sum */
+int mx_transpose_batch(const long* table, int n, int total_tiles, void* stream);
 
 /* dX[M,N] = G[M,K] * W[K,N] (+residual): data gradient of the 1x1 conv with weight W[K=Cout, N=Cin]. */
 int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, int ldg, int ldx,

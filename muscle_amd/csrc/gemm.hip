@@ -1133,7 +1133,47 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
   }
 }
 
+// Every conv weight of the network in one launch: table rows of 5 longs {src, dst, rows, cols, first tile}; workgroup id ->
+// (matrix, 32x32 tile) by a scan of the first-tile column (~110 rows).
+__global__ __launch_bounds__(256) void transpose_batch_kernel(const long* __restrict__ table, int n) {
+  __shared__ float t[32][33];
+  __shared__ int job;
+  if (threadIdx.x == 0) {
+    int j = 0;
+    while (j + 1 < n && table[(j + 1) * 5 + 4] <= (long)blockIdx.x) ++j;
+    job = j;
+  }
+  __syncthreads();
+  const long* e = table + job * 5;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  float* dst = reinterpret_cast<float*>(e[1]);
+  const int rows = (int)e[2], cols = (int)e[3];
+  const int tile = (int)(blockIdx.x - e[4]), tx_n = (cols + 31) / 32;
+  const int bx = (tile % tx_n) * 32, by = (tile / tx_n) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int r = by + ty + i, c = bx + tx;
+    if (r < rows && c < cols) t[ty + i][tx] = src[(long)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 32; i += 8) {
+    const int c = bx + ty + i, r = by + tx;
+    if (r < rows && c < cols) dst[(long)c * rows + r] = t[tx][ty + i];
+  }
+}
+
 extern "C" {
+
+// n transposes in one launch.  table: DEVICE array of n rows {src, dst, rows, cols, first_tile} (longs), first_tile = the
+// running sum of ceil(rows/32) * ceil(cols/32) over the rows before; total_tiles = that sum over all rows.
+int mx_transpose_batch(const long* table, int n, int total_tiles, void* stream) {
+  MX_CHECK_ARG(table && n > 0 && total_tiles > 0, "transpose_batch: bad arguments");
+  hipLaunchKernelGGL(transpose_batch_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table, n);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
 
 // dst[cols, rows] = src[rows, cols]^T.  The data gradient of a 1x1 convolution is run as a forward GEMM against the
 // transposed weight (mx_pw_fwd with W^T: both operands K-contiguous, 16-byte LDS traffic, 16-column tiles).

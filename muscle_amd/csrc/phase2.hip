@@ -348,20 +348,24 @@ __device__ __forceinline__ float emd_lse_join(const float* pm, const float* ps, 
 }
 
 // shared layout: xs[n1*24], ys[n2*24], u[n1], v[n2], lmu[n1], lnu[n2], tmp[n1], pm[1024], ps[1024]  (+ gradient: cl[n2], ub[n1], vb[n2])
+// XG ("x in global"): the launch holds a pair whose two crops do not fit the 160 KB together (two 28 x 28 crops need 150 KB of
+// features alone).  Then only y is staged and x is read where it lies - every lane of a wave asks for the same row, one cache
+// line per request - so that any pair of crops up to EMD_MAXP pixels each runs, at a lower rate.
 struct EmdLds { float *xs, *ys, *u, *v, *lmu, *lnu, *tmp, *pm, *ps, *cl, *ub, *vb; };
+template <bool XG>
 __device__ __forceinline__ EmdLds emd_carve(float* sh, int n1, int n2) {
   EmdLds L;
-  L.xs = sh; L.ys = L.xs + n1 * FP; L.u = L.ys + n2 * FP; L.v = L.u + n1; L.lmu = L.v + n2; L.lnu = L.lmu + n1; L.tmp = L.lnu + n2;
+  L.xs = sh; L.ys = L.xs + (XG ? 0 : n1 * FP); L.u = L.ys + n2 * FP; L.v = L.u + n1; L.lmu = L.v + n2; L.lnu = L.lmu + n1; L.tmp = L.lnu + n2;
   L.pm = L.tmp + n1; L.ps = L.pm + EMD_T; L.cl = L.ps + EMD_T; L.ub = L.cl + n2; L.vb = L.ub + n1;
   return L;
 }
 
 // One Jacobi iteration: both updates use the same (u, v) (loss_multilabel.py:215-217).
-__device__ void emd_iterate(const EmdLds& L, const EmdSlice& r, const EmdSlice& c, int n1, int n2) {
+__device__ __forceinline__ void emd_iterate(const EmdLds& L, const float* xs, const EmdSlice& r, const EmdSlice& c, int n1, int n2) {
   const int tid = threadIdx.x;
   // rows: u_i' = reg*(lmu_i - LSE_j M_ij) + u_i
   if (r.idx >= 0) {
-    const F24 xi = ld24(L.xs + r.idx * FP);
+    const F24 xi = ld24(xs + r.idx * FP);
     float m, s;
     emd_lse_part(xi, L.u[r.idx], L.ys, L.v, r.lo, r.hi, m, s);
     L.pm[tid] = m; L.ps[tid] = s;
@@ -373,7 +377,7 @@ __device__ void emd_iterate(const EmdLds& L, const EmdSlice& r, const EmdSlice& 
   if (c.idx >= 0) {
     const F24 yj = ld24(L.ys + c.idx * FP);
     float m, s;
-    emd_lse_part(yj, L.v[c.idx], L.xs, L.u, c.lo, c.hi, m, s);
+    emd_lse_part(yj, L.v[c.idx], xs, L.u, c.lo, c.hi, m, s);
     L.pm[tid] = m; L.ps[tid] = s;
   }
   __syncthreads();
@@ -382,14 +386,15 @@ __device__ void emd_iterate(const EmdLds& L, const EmdSlice& r, const EmdSlice& 
   __syncthreads();
 }
 
-__device__ void emd_setup(const float* X, const float* Y, const EmdLds& L, int n1, int n2) {
-  for (int i = threadIdx.x; i < n1 * FP; i += EMD_T) L.xs[i] = X[i];
+template <bool XG>
+__device__ __forceinline__ void emd_setup(const float* X, const float* Y, const EmdLds& L, const float* xs, int n1, int n2) {
+  if (!XG) for (int i = threadIdx.x; i < n1 * FP; i += EMD_T) L.xs[i] = X[i];
   for (int i = threadIdx.x; i < n2 * FP; i += EMD_T) L.ys[i] = Y[i];
   __syncthreads();
   // weights (get_weight_vector, :250-257): mu_i = x_i . mean(y), nu_j = y_j . mean(x); pm[0..23], pm[24..47] hold the means
   if (threadIdx.x < 2 * FP) {
     int k = threadIdx.x % FP;
-    const float* src = (threadIdx.x < FP) ? L.ys : L.xs;
+    const float* src = (threadIdx.x < FP) ? L.ys : xs;
     int n = (threadIdx.x < FP) ? n2 : n1;
     float s = 0.f;
     for (int i = 0; i < n; ++i) s += src[i * FP + k];
@@ -401,7 +406,7 @@ __device__ void emd_setup(const float* X, const float* Y, const EmdLds& L, int n
   __syncthreads();
   for (int i = threadIdx.x; i < n1; i += EMD_T) {
     float s = 0.f;
-    for (int k = 0; k < FP; ++k) s += L.xs[i * FP + k] * my[k];
+    for (int k = 0; k < FP; ++k) s += xs[i * FP + k] * my[k];
     L.lmu[i] = __logf(s + 1e-6f);
     L.u[i] = 0.f;
   }
@@ -415,11 +420,11 @@ __device__ void emd_setup(const float* X, const float* Y, const EmdLds& L, int n
 }
 
 // sum_ij exp(M_ij) * C_ij / (n1*n2): slice partials, then waves in order
-__device__ float emd_distance(const EmdLds& L, const EmdSlice& r, int n1, int n2) {
+__device__ __forceinline__ float emd_distance(const EmdLds& L, const float* xs, const EmdSlice& r, int n1, int n2) {
   const float ir = 1.f / EMD_REG;
   float acc = 0.f;
   if (r.idx >= 0) {
-    const F24 xi = ld24(L.xs + r.idx * FP);
+    const F24 xi = ld24(xs + r.idx * FP);
     const float ui = L.u[r.idx];
     for (int j = r.lo; j < r.hi; ++j) {
       float c = 1.f - dot24(xi, L.ys + j * FP);
@@ -437,23 +442,25 @@ __device__ float emd_distance(const EmdLds& L, const EmdSlice& r, int n1, int n2
 
 // One workgroup per pair, in table order: the host sorts the table by descending n1 * n2, so the long pairs start first and
 // the short ones fill the tail.  traj (optional): (u_t, v_t) of the 11 Sinkhorn states, which mx_emd_grad differentiates.
+template <bool XG>
 __global__ __launch_bounds__(EMD_T) void emd_score_kernel(const float* feat, const int* pairs, float* score, float* traj,
                                                           long traj_stride) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
   const int* t = pairs + blockIdx.x * 6;
   const int n1 = t[1], n2 = t[3], nn = n1 + n2;
-  const EmdLds L = emd_carve(sh, n1, n2);
+  const EmdLds L = emd_carve<XG>(sh, n1, n2);
   const EmdSlice r = emd_slice(n1, n2), c = emd_slice(n2, n1);
-  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, L, n1, n2);
+  const float* xs = XG ? feat + (long)t[0] * FP : L.xs;
+  emd_setup<XG>(feat + (long)t[0] * FP, feat + (long)t[2] * FP, L, xs, n1, n2);
   float* tr = traj ? traj + blockIdx.x * traj_stride : nullptr;
   for (int it = 0; it <= EMD_ITERS; ++it) {
     if (tr) {
       if (threadIdx.x < n1) tr[it * nn + threadIdx.x] = L.u[threadIdx.x];
       if (threadIdx.x < n2) tr[it * nn + n1 + threadIdx.x] = L.v[threadIdx.x];
     }
-    if (it < EMD_ITERS) emd_iterate(L, r, c, n1, n2);
+    if (it < EMD_ITERS) emd_iterate(L, xs, r, c, n1, n2);
   }
-  float d = emd_distance(L, r, n1, n2);
+  float d = emd_distance(L, xs, r, n1, n2);
   if (threadIdx.x == 0) score[blockIdx.x] = d;
 }
 
@@ -497,6 +504,7 @@ __global__ __launch_bounds__(1024) void emd_best_kernel(const float* score, cons
 // traj: the states mx_emd_scores recorded, row `pair` holds (EMD_ITERS+1) * (n1 + n2) floats of (u_t, v_t).
 // Same slice decomposition as the forward; every thread keeps the 24 gradient terms of its (row, slice) in registers through
 // all stages and the slices of a row are added in order at the end (in the LDS that held x).
+template <bool XG>
 __global__ __launch_bounds__(EMD_T) void emd_grad_kernel(const float* feat, const int* pairs, const int* best, const float* traj,
                                                          long traj_stride, const float* gup, float gscale, float* gx) {
   extern __shared__ __attribute__((aligned(16))) float sh[];
@@ -505,10 +513,11 @@ __global__ __launch_bounds__(EMD_T) void emd_grad_kernel(const float* feat, cons
   if (gup) gscale *= gup[0];
   const int* t = pairs + bi * 6;
   const int n1 = t[1], n2 = t[3], nn = n1 + n2, tid = threadIdx.x;
-  const EmdLds L = emd_carve(sh, n1, n2);
+  const EmdLds L = emd_carve<XG>(sh, n1, n2);
   const EmdSlice r = emd_slice(n1, n2), c = emd_slice(n2, n1);
   const float* tr = traj + bi * traj_stride;
-  emd_setup(feat + (long)t[0] * FP, feat + (long)t[2] * FP, L, n1, n2);
+  const float* xs = XG ? feat + (long)t[0] * FP : L.xs;
+  emd_setup<XG>(feat + (long)t[0] * FP, feat + (long)t[2] * FP, L, xs, n1, n2);
   const float ir = 1.f / EMD_REG, inv12 = 1.f / ((float)n1 * (float)n2);
   float gxl[FP];
 #pragma unroll
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(EMD_T) void emd_grad_kernel(const float* feat, cons
   {
     float us = 0.f, vs = 0.f;
     if (r.idx >= 0) {
-      const F24 xi = ld24(L.xs + r.idx * FP);
+      const F24 xi = ld24(xs + r.idx * FP);
       const float ui = L.u[r.idx];
       for (int j = r.lo; j < r.hi; ++j) {
         const float* y = L.ys + j * FP;
@@ -537,7 +546,7 @@ __global__ __launch_bounds__(EMD_T) void emd_grad_kernel(const float* feat, cons
       const F24 yj = ld24(L.ys + c.idx * FP);
       const float vj = L.v[c.idx];
       for (int i = c.lo; i < c.hi; ++i) {
-        const float cst = 1.f - dot24(yj, L.xs + i * FP);
+        const float cst = 1.f - dot24(yj, xs + i * FP);
         vs += __expf((-cst + L.u[i] + vj) * ir) * cst * inv12 * ir;
       }
     }
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(EMD_T) void emd_grad_kernel(const float* feat, cons
     // Cbar_ij += ub'_i P_ij + vb'_j Q_ij  ->  gx_i -= (...) y_j ; ub_i = -sum_j vb'_j Q_ij ; vb_j = -sum_i ub'_i P_ij
     float nu_ = 0.f, acc = 0.f;
     if (r.idx >= 0) {
-      const F24 xi = ld24(L.xs + r.idx * FP);
+      const F24 xi = ld24(xs + r.idx * FP);
       const float ui = L.u[r.idx], rl = L.tmp[r.idx], ubi = L.ub[r.idx];
       for (int j = r.lo; j < r.hi; ++j) {
         const float* y = L.ys + j * FP;
@@ -583,24 +592,37 @@ __global__ __launch_bounds__(EMD_T) void emd_grad_kernel(const float* feat, cons
       const F24 yj = ld24(L.ys + c.idx * FP);
       const float vj = L.v[c.idx];
       for (int i = c.lo; i < c.hi; ++i) {
-        const float M = (dot24(yj, L.xs + i * FP) - 1.f + L.u[i] + vj) * ir;
+        const float M = (dot24(yj, xs + i * FP) - 1.f + L.u[i] + vj) * ir;
         acc -= L.ub[i] * __expf(M - L.tmp[i]);
       }
     }
     L.pm[tid] = nu_; L.ps[tid] = acc;
   }
-  // slices of a row, in order, into the LDS that held x
+  // slices of a row, in order: into the LDS that held x, or (XG) straight into the output rows - one workgroup owns them
+  float* out = gx + (long)t[0] * FP;
   __syncthreads();
   for (int s = 0; s < r.S; ++s) {
     if (r.idx >= 0 && r.s == s) {
-      float* d = L.xs + r.idx * FP;
+      float* d = (XG ? out : L.xs) + r.idx * FP;
 #pragma unroll
-      for (int k = 0; k < FP; ++k) d[k] = (s ? d[k] : 0.f) + gxl[k];
+      for (int k = 0; k < FP; ++k) {
+        if (XG) {      // read-modify-write of global memory between waves: device-scope accesses, past the CU's L1
+          const float prev = s ? __hip_atomic_load(d + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+          __hip_atomic_store(d + k, prev + gxl[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          d[k] = (s ? d[k] : 0.f) + gxl[k];
+        }
+      }
     }
+    if (XG) __threadfence();
     __syncthreads();
   }
-  float* out = gx + (long)t[0] * FP;
-  for (int e = tid; e < n1 * FP; e += EMD_T) out[e] = L.xs[e] * gscale;
+  if (XG) {
+    for (int e = tid; e < n1 * FP; e += EMD_T)
+      out[e] = __hip_atomic_load(out + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) * gscale;
+  } else {
+    for (int e = tid; e < n1 * FP; e += EMD_T) out[e] = L.xs[e] * gscale;
+  }
 }
 
 static int gs(long n) { long b = (n + 255) / 256; return (int)(b < 1 ? 1 : (b > 8192 ? 8192 : b)); }
@@ -657,8 +679,8 @@ int mx_avgpool4(const float* in, const int* table, int ncrops, float* out, int b
   return MX_OK;
 }
 
-static size_t emd_lds(int maxn1, int maxn2, int grad) {
-  size_t f = (size_t)(maxn1 + maxn2) * FP + 2 * (size_t)(maxn1 + maxn2) + (size_t)maxn1 + 2 * EMD_T;
+static size_t emd_lds(int maxn1, int maxn2, int grad, int xg) {
+  size_t f = (size_t)((xg ? 0 : maxn1) + maxn2) * FP + 2 * (size_t)(maxn1 + maxn2) + (size_t)maxn1 + 2 * EMD_T;
   if (grad) f += (size_t)(maxn1 + 2 * maxn2);
   return f * sizeof(float);
 }
@@ -666,11 +688,17 @@ static size_t emd_lds(int maxn1, int maxn2, int grad) {
 int mx_emd_scores(const float* feat, const int* pairs, int npairs, int maxn1, int maxn2, float* score, float* traj, void* stream) {
   MX_CHECK_ARG(feat && pairs && score && npairs > 0, "emd_scores: bad args");
   MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_scores: crop larger than %d pixels", EMD_MAXP);
-  size_t sh = emd_lds(maxn1, maxn2, 0);
+  const int xg = emd_lds(maxn1, maxn2, 0, 0) > 160 * 1024;        // the largest pair does not fit: x stays in global memory
+  size_t sh = emd_lds(maxn1, maxn2, 0, xg);
   MX_CHECK_ARG(sh <= 160 * 1024, "emd_scores: LDS need %zu exceeds 160 KiB", sh);
-  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   const long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
-  hipLaunchKernelGGL(emd_score_kernel, dim3(npairs), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, score, traj, stride);
+  if (xg) {
+    hipFuncSetAttribute((const void*)emd_score_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(emd_score_kernel<true>, dim3(npairs), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, score, traj, stride);
+  } else {
+    if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_score_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(emd_score_kernel<false>, dim3(npairs), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, score, traj, stride);
+  }
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -686,12 +714,19 @@ int mx_emd_grad(const float* feat, const int* pairs, const int* best, int nsampl
                 const float* gup, float gscale, float* gx, void* stream) {
   MX_CHECK_ARG(feat && pairs && best && traj && gx && nsamples > 0, "emd_grad: bad args");
   MX_CHECK_ARG(maxn1 > 0 && maxn2 > 0 && maxn1 <= EMD_MAXP && maxn2 <= EMD_MAXP, "emd_grad: crop larger than %d pixels", EMD_MAXP);
-  size_t sh = emd_lds(maxn1, maxn2, 1);
+  const int xg = emd_lds(maxn1, maxn2, 1, 0) > 160 * 1024;
+  size_t sh = emd_lds(maxn1, maxn2, 1, xg);
   MX_CHECK_ARG(sh <= 160 * 1024, "emd_grad: LDS need %zu exceeds 160 KiB", sh);
-  if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
   const long stride = (long)(EMD_ITERS + 1) * (maxn1 + maxn2);
-  hipLaunchKernelGGL(emd_grad_kernel, dim3(nsamples), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup, gscale,
-                     gx);
+  if (xg) {
+    hipFuncSetAttribute((const void*)emd_grad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(emd_grad_kernel<true>, dim3(nsamples), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup,
+                       gscale, gx);
+  } else {
+    if (sh > 48 * 1024) hipFuncSetAttribute((const void*)emd_grad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+    hipLaunchKernelGGL(emd_grad_kernel<false>, dim3(nsamples), dim3(EMD_T), sh, (hipStream_t)stream, feat, pairs, best, traj, stride, gup,
+                       gscale, gx);
+  }
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -157,15 +157,33 @@ def _prefetch_transposes(backbone, cfg: NetCfg, tape: Tape, dev):
         return
     side = _WgradLane(dev).s
     side.wait_stream(torch.cuda.current_stream())            # the optimizer step that produced these weights
+    ws = []
+    for b in cfg.blocks:
+        m = _blk(backbone, b.index)
+        if b.expand and b.cexp % 4 == 0:
+            ws.append((m._expand_conv.weight, m._expand_conv.weight.view(b.cexp, b.cin)))
+        if b.cout % 4 == 0:
+            ws.append((m._project_conv.weight, m._project_conv.weight.view(b.cout, b.cexp)))
+    if not ws:
+        return
+    # one launch for all of them, into buffers that live with the backbone (the previous step's backward, the only reader, is
+    # behind the wait above); rebuilt when a weight has moved (load on another device, re-created parameters)
+    plan = getattr(backbone, "_wt_plan", None)
+    views = [v for _, v in ws]
+    if plan is None or not plan.matches(views):
+        # (building the plan uploads a table: not under stream capture - a captured step whose eager warm-up did not come
+        # through here transposes weight by weight, into the graph's own pool)
+        if plan is not None:                       # a captured graph may still write into its buffers: retired, not freed
+            backbone.__dict__.setdefault("_wt_plans_retired", []).append(plan)
+        plan = None if torch.cuda.is_current_stream_capturing() else ops.TransposePlan(views)
+        backbone._wt_plan = plan
     with torch.cuda.stream(side):
-        for b in cfg.blocks:
-            m = _blk(backbone, b.index)
-            if b.expand and b.cexp % 4 == 0:
-                w = m._expand_conv.weight
-                tape.wt[id(w)] = ops.transpose(w.view(b.cexp, b.cin))
-            if b.cout % 4 == 0:
-                w = m._project_conv.weight
-                tape.wt[id(w)] = ops.transpose(w.view(b.cout, b.cexp))
+        if plan is not None:
+            for (w, _), wt in zip(ws, plan.run()):
+                tape.wt[id(w)] = wt
+        else:
+            for w, v in ws:
+                tape.wt[id(w)] = ops.transpose(v)
         tape.wt_event = side.record_event()
 
 
@@ -181,7 +199,7 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
     lo, hi = cfg.stem_pad
     H0, W0 = (H + lo + hi - 3) // 2 + 1, (W + lo + hi - 3) // 2 + 1
     tape.H0, tape.W0 = H0, W0
-    if training and save:
+    if save:                                    # a backward will follow (train mode, or phase 2's eval-mode forward of view 1)
         _prefetch_transposes(backbone, cfg, tape, dev)
     # stem: im2col + MFMA GEMM (K = 27 padded to 28), BN statistics in the GEMM epilogue
     tape.cols = ops.stem_im2col(img, H0, W0, lo)

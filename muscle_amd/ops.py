@@ -75,6 +75,30 @@ def get_gemm_mode() -> int:
     return int(lib().mx_get_gemm_mode())
 
 
+class TransposePlan:
+    """Persistent W^T buffers of a fixed set of 2-D weights and the device table that transposes them all in one launch."""
+
+    def __init__(self, weights):
+        dev = weights[0].device
+        self.key = tuple((w.data_ptr(), tuple(w.shape)) for w in weights)
+        self.dst = [_f32(w.shape[1], w.shape[0], device=dev) for w in weights]
+        rows, tile = [], 0
+        for w, d in zip(weights, self.dst):
+            r, c = w.shape
+            rows.append([w.data_ptr(), d.data_ptr(), r, c, tile])
+            tile += ((r + 31) // 32) * ((c + 31) // 32)
+        self.n, self.tiles = len(rows), tile
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        torch.cuda.current_stream(dev).synchronize()     # built once: the table is in place whichever stream runs the launch
+
+    def matches(self, weights):
+        return len(weights) == self.n and all(k[0] == w.data_ptr() and k[1] == tuple(w.shape) for k, w in zip(self.key, weights))
+
+    def run(self):
+        call("mx_transpose_batch", ptr(self.table), self.n, self.tiles, stream())
+        return self.dst
+
+
 def transpose(W):
     """[rows, cols] -> contiguous [cols, rows] (weights)."""
     rows, cols = W.shape

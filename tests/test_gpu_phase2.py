@@ -105,3 +105,27 @@ def test_mcl_step_full_golden(fname, ptol):
     scale = np.maximum(ref[live, :1], 1e-3 * ref[live, 0].max())
     gtol = 3e-3 if lr == 0 else 5e-2
     assert np.all(np.abs(g[live] - ref[live]) <= gtol * scale), np.abs((g[live] - ref[live]) / scale).max()
+
+
+def test_emd_largest_crops_vs_oracle():
+    """Two views that overlap completely: view-2 quadrants pool to 28 x 28 and a stride of 28 leaves the view-1 windows at
+    28 x 28 unpooled (torchutils.py:262-286), 784 + 784 pixels per pair.  Their features alone are 150 KB, so the Sinkhorn
+    kernels keep x in global memory for such a launch (phase2.hip, XG); smaller overlaps take the all-LDS kernels."""
+    import muscle_amd as M
+    from oracle import mcl_oracle as O
+    v = 224
+    g = torch.Generator().manual_seed(11)
+    a = torch.nn.functional.normalize(torch.rand(1, 21, v, v, generator=g), dim=1)
+    b = torch.nn.functional.normalize(torch.rand(1, 21, v, v, generator=g), dim=1)
+    c = torch.tensor([[0, 0, v, v]], dtype=torch.int64)
+    geo = [(112, 112, 28, 28)]          # strides 28 / 28 -> 28 x 28, not pooled (the pool is for sides ABOVE 28): 25 windows
+    x1o = a.clone().requires_grad_()
+    cr1, cr2, _ = O.get_dynamic_crops(x1o, c, b, c, geo)
+    assert max(t.shape[2] * t.shape[3] for t in cr1[0]) == 784 and max(t.shape[2] * t.shape[3] for t in cr2[0]) == 784
+    lo = O.emd_dynamic(cr1, cr2)
+    lo.backward()
+    x1 = a.clone().to(DEV).requires_grad_()
+    d1, d2, _ = M.get_dynamic_crops(x1, c.to(DEV), b.to(DEV), c.to(DEV), geo)
+    l = M.EMD()(d1, d2, mode="dynamic")
+    l.backward()
+    close(l, float(lo), 1e-4); close(x1.grad, x1o.grad, 2e-3)

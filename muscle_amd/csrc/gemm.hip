@@ -984,7 +984,20 @@ static void launch_nt_split(const GemmArgs& g, int batch, hipStream_t st) {
     const double balance = rounds / (double)(long)(rounds + 0.999999);
     return eff * pad * balance;
   };
-  const bool narrow = forced ? forced == 1 : score(64, 0.92) > score(128, 1.0) + 1e-9;
+  // Long reductions (the project convs and their mirror, the expand data gradient: K = Cexp) are priced with a model fitted to
+  // measurements (tools/gemm_nj.py): a launch costs floor(rounds) + min(1, tail + 0.12) rounds of 768 workgroups - a partly
+  // filled last round is cheaper than a full one because its workgroups share their CU with fewer neighbours - and the
+  // 64-wide tile does 0.87 of the 128-wide tile's work per unit time.  (K = 3840 -> N = 640 took 876 us with the 64-wide tile
+  // the first rule picked and 788 us with the 128-wide one.)
+  static const int fitted = getenv("MX_GEMM_SPLIT_FITTED") ? atoi(getenv("MX_GEMM_SPLIT_FITTED")) : 1;   // 0: first rule only (A/B)
+  auto cost = [&](int bn, double eff) {
+    const double rounds = (double)cdiv(g.M, 128) * cdiv(g.N, bn) * batch / 768.0;
+    const double full = (double)(long)rounds, tail = rounds - full;
+    return (full + (tail > 0 ? (tail + 0.12 < 1.0 ? tail + 0.12 : 1.0) : 0.0)) * bn / eff;
+  };
+  const bool narrow = forced ? forced == 1
+                    : (g.K >= 1024 && fitted) ? cost(64, 0.87) < cost(128, 1.0)
+                                  : score(64, 0.92) > score(128, 1.0) + 1e-9;
   if (forced == 4) launch_nt_split_t<4>(g, batch, st);
   else if (narrow) launch_nt_split_t<1>(g, batch, st);
   else launch_nt_split_t<2>(g, batch, st);

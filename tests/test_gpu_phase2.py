@@ -129,3 +129,18 @@ def test_emd_largest_crops_vs_oracle():
     l = M.EMD()(d1, d2, mode="dynamic")
     l.backward()
     close(l, float(lo), 1e-4); close(x1.grad, x1o.grad, 2e-3)
+
+
+def test_emd_best_takes_the_first_minimum_of_the_reference_order():
+    """loss_multilabel.py:318 sorts the pair scores with a stable sort and takes the first: on a tie the pair enumerated first
+    wins.  The pair table reaches the kernels sorted by size, so the enumeration rank travels in column 5."""
+    from muscle_amd._lib import call, ptr, stream
+    score = torch.tensor([0.5, 0.25, 0.25, 0.75, 0.1, 0.1], dtype=torch.float32, device=DEV)
+    # rows {x_off, n1, y_off, n2, sample, rank}: sample 0 holds rows 0-3 (tie between rows 1 and 2: rank 7 vs rank 3), sample 1 rows 4-5
+    pairs = torch.tensor([[0, 4, 0, 4, 0, 0], [0, 4, 0, 4, 0, 7], [0, 4, 0, 4, 0, 3], [0, 4, 0, 4, 0, 1],
+                          [0, 4, 0, 4, 1, 9], [0, 4, 0, 4, 1, 8]], dtype=torch.int32, device=DEV)
+    best = torch.full((2,), -5, dtype=torch.int32, device=DEV)
+    loss = torch.zeros(1, dtype=torch.float32, device=DEV)
+    call("mx_emd_best", ptr(score), ptr(pairs), 6, 2, ptr(best), ptr(loss), stream())
+    assert best.tolist() == [2, 5]
+    close(loss, (0.25 + 0.1) / 2, 1e-6)

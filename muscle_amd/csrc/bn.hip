@@ -23,7 +23,7 @@ struct ColGeom {
 };
 
 static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that one block may span at most*/,
-                        int groups = 1 /*independent row ranges (samples) sharing the grid*/) {
+                        int groups = 1 /*independent row ranges (samples) sharing the grid*/, int planes = 1) {
   ColGeom g;
   g.rows = (int)rows; g.C = C; g.c4 = C / 4; g.rps = rps;
   // float4 columns per workgroup: the width that wastes the fewest of the 256 threads (both on the padded last column
@@ -47,7 +47,9 @@ static ColGeom col_geom(long rows, int C, int rps, long rows_limit /*rows that o
   // workgroups per reduction launch (tuning override MX_COLREDUCE_BLOCKS), swept twice on one box, ms per step:
   // 256: 153.3  512: 150.1/150.5  1024: 147.7/147.9  2048: 149.4/150.0  4096: 150.3/151.7
   static const long block_target = getenv("MX_COLREDUCE_BLOCKS") ? atol(getenv("MX_COLREDUCE_BLOCKS")) : 1024;
-  long target_blocks = block_target / ((long)colchunks * groups);
+  // (the five-plane SE / BN1 pass carries 10 loads per row and thread and a five-fold final sum: half as many workgroups suit it
+  //  better - tools/microbench.py pool, MX_COLREDUCE_BLOCKS 1024 / 512 / 256)
+  long target_blocks = (planes == 5 ? block_target / 2 : block_target) / ((long)colchunks * groups);
   if (target_blocks < 1) target_blocks = 1;
   long rpb = (rows_limit + target_blocks - 1) / target_blocks;
   if (rpb < 4L * g.rpp) rpb = 4L * g.rpp;
@@ -161,9 +163,9 @@ static int colreduce_parts(long rows, int C) {
 
 // geometry of the per-sample reductions (mx_pool_sum, mx_se_bn1_pool): falls back to one row block per sample when the
 // launch would need more arrival counters than the scratch header holds
-static ColGeom pool_geom(long rows, int C, int rps, dim3* grid) {
+static ColGeom pool_geom(long rows, int C, int rps, dim3* grid, int planes = 1) {
   const int N = (int)(rows / rps);
-  ColGeom g = col_geom(rows, C, rps, rps, N);
+  ColGeom g = col_geom(rows, C, rps, rps, N, planes);
   const int colchunks = cdiv(g.c4, g.tcols);
   if ((long)N * colchunks > MX_WS_COUNTERS) g.rows_per_block = rps;
   *grid = dim3(cdiv(rps, g.rows_per_block), colchunks, N);
@@ -172,7 +174,7 @@ static ColGeom pool_geom(long rows, int C, int rps, dim3* grid) {
 
 static long pool_ws_bytes(long rows, int C, int rps, int planes) {
   dim3 grid;
-  pool_geom(rows, C, rps, &grid);
+  pool_geom(rows, C, rps, &grid, planes);
   if (grid.x == 1) return 0;
   return MX_WS_COUNTER_BYTES + (long)grid.x * planes * (rows / rps) * C * 4;
 }
@@ -745,7 +747,7 @@ int mx_se_bn1_pool(const float* dA, const float* X, const float* scale, const fl
                "se_bn1_pool: bad args");
   const int N = (int)(rows / rows_per_sample);
   dim3 grid;
-  ColGeom g = pool_geom(rows, C, rows_per_sample, &grid);
+  ColGeom g = pool_geom(rows, C, rows_per_sample, &grid, 5);
   const long need = pool_ws_bytes(rows, C, rows_per_sample, 5);
   MX_CHECK_ARG(need == 0 || (ws && ws_bytes >= need && ((uintptr_t)ws & 15) == 0), "se_bn1_pool: workspace of %ld bytes required (mx_pool_ws)", need);
   hipLaunchKernelGGL(se_bn1_pool_kernel, grid, dim3(256), 0, (hipStream_t)stream, dA, X, scale, shift, g, out5, (long)N * C,

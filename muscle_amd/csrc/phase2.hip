@@ -168,8 +168,10 @@ __device__ __forceinline__ void bil_coord2(int d, int in, int out, int& i0, int&
   w1 = s - i0;
 }
 
+// grid (crops, 3): workgroup (crop, channel group of 8) - a crop per workgroup left the chip a third full at ~900 crops
 __global__ __launch_bounds__(256) void crop_resize_kernel(const float* src, const int* table, float* out, int K, int H, int W) {
   const int* t = table + blockIdx.x * 8;
+  const int kbeg = blockIdx.y * (FP / 3), kend = kbeg + FP / 3;
   const int n = t[0], y0 = t[1], x0 = t[2], lh = t[3], lw = t[4], rh = t[5], rw = t[6], off = t[7];
   const long HW = (long)H * W;
   for (int p = threadIdx.x; p < rh * rw; p += 256) {
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(256) void crop_resize_kernel(const float* src, cons
     bil_coord2(c, lw, rw, xa, xb, wx);
     const float* b = src + (long)n * K * HW;
     float* o = out + ((long)off + p) * FP;
-    for (int k = 0; k < FP; ++k) {
+    for (int k = kbeg; k < kend; ++k) {
       float v = 0.f;
       if (k < K) {
         const float* q = b + k * HW;
@@ -211,13 +213,18 @@ __global__ __launch_bounds__(256) void crop_resize_bwd_kernel(const float* gout_
                                                               int H, int W) {
   const int n = blockIdx.x, k0 = blockIdx.y * CROP_KG;
   const long HW = (long)H * W;
+  // grid.z cuts the image into bands of rows: workgroup (n, kg, band) owns the band's source pixels (96 workgroups for a batch
+  // of 32 left the chip idle: 680 us).  An element still has one adder, and still meets its crops in table order.
+  const int bh = (H + gridDim.z - 1) / gridDim.z, by0 = blockIdx.z * bh, by1 = min(H, by0 + bh);
   for (int ci = 0; ci < ncrops; ++ci) {
     const int* trow = table + ci * 8;
     if (trow[0] != n) continue;                   // (uniform over the workgroup)
     const int y0 = trow[1], x0 = trow[2], lh = trow[3], lw = trow[4], rh = trow[5], rw = trow[6];
+    const int s_lo = max(0, by0 - y0), s_hi = min(lh, by1 - y0);      // window rows inside this band
+    if (s_lo >= s_hi) continue;                   // (uniform: the barrier below is skipped by the whole workgroup)
     const float* gout = gout_all + (long)trow[7] * FP;
-    for (int sp = threadIdx.x; sp < lh * lw; sp += 256) {
-      const int sy = sp / lw, sx = sp % lw;
+    for (int sp = threadIdx.x; sp < (s_hi - s_lo) * lw; sp += 256) {
+      const int sy = s_lo + sp / lw, sx = sp % lw;
       int rlo, rhi, clo, chi;
       adj_range(sy, lh, rh, rlo, rhi);
       adj_range(sx, lw, rw, clo, chi);
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256) void avgpool4_kernel(const float* in, const in
   const int ioff = t[0], h = t[1], w = t[2], ooff = t[3];
   const int ph = h / 4, pw = w / 4;
   if (!bwd) {
-    for (int i = threadIdx.x; i < ph * pw * FP; i += 256) {
+    for (int i = threadIdx.x + 256 * blockIdx.y; i < ph * pw * FP; i += 256 * gridDim.y) {
       int k = i % FP, p = i / FP;
       int r = p / pw, c = p % pw;
       float s = 0.f;
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256) void avgpool4_kernel(const float* in, const in
       out[((long)ooff + p) * FP + k] = s * (1.f / 16.f);
     }
   } else {   // reads the pooled crop's gradient (at out_off), writes the unpooled crop's gradient (at in_off)
-    for (int i = threadIdx.x; i < h * w * FP; i += 256) {
+    for (int i = threadIdx.x + 256 * blockIdx.y; i < h * w * FP; i += 256 * gridDim.y) {
       int k = i % FP, p = i / FP;
       int r = p / w, c = p % w;
       float v = 0.f;
@@ -658,7 +665,7 @@ int mx_chan_l2norm(const float* x, const float* gy, float* out, int N, int K, lo
 
 int mx_crop_resize(const float* src, const int* table, int ncrops, float* out, int K, int H, int W, void* stream) {
   MX_CHECK_ARG(src && table && out && ncrops > 0 && K > 0 && K <= FP, "crop_resize: bad args");
-  hipLaunchKernelGGL(crop_resize_kernel, dim3(ncrops), dim3(256), 0, (hipStream_t)stream, src, table, out, K, H, W);
+  hipLaunchKernelGGL(crop_resize_kernel, dim3(ncrops, 3), dim3(256), 0, (hipStream_t)stream, src, table, out, K, H, W);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -666,15 +673,15 @@ int mx_crop_resize(const float* src, const int* table, int ncrops, float* out, i
 int mx_crop_resize_bwd(const float* gout, const int* table, int ncrops, float* gsrc, int nsamples, int K, int H, int W, void* stream) {
   MX_CHECK_ARG(gout && table && gsrc && ncrops > 0 && nsamples > 0 && K > 0 && K <= FP, "crop_resize_bwd: bad args");
   // samples = 1 + the largest sample index of the table is not known here: the grid covers `nsamples` given by the caller
-  hipLaunchKernelGGL(crop_resize_bwd_kernel, dim3(nsamples, cdiv(K, CROP_KG)), dim3(256), 0, (hipStream_t)stream, gout, table, ncrops, gsrc,
-                     K, H, W);
+  hipLaunchKernelGGL(crop_resize_bwd_kernel, dim3(nsamples, cdiv(K, CROP_KG), H >= 64 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, gout, table,
+                     ncrops, gsrc, K, H, W);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
 
 int mx_avgpool4(const float* in, const int* table, int ncrops, float* out, int bwd, void* stream) {
   MX_CHECK_ARG(in && table && out && ncrops > 0, "avgpool4: bad args");
-  hipLaunchKernelGGL(avgpool4_kernel, dim3(ncrops), dim3(256), 0, (hipStream_t)stream, in, table, out, bwd);
+  hipLaunchKernelGGL(avgpool4_kernel, dim3(ncrops, 8), dim3(256), 0, (hipStream_t)stream, in, table, out, bwd);   // 8 slices of a crop's elements
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -73,6 +73,12 @@ class Tape:
 
 _keep_cache: Dict[tuple, torch.Tensor] = {}
 MATERIALISE_ABOVE = int(os.environ.get("MUSCLE_MATERIALISE_ABOVE", "128"))      # project convs with Cout above this use a materialised activated input
+# Inference reads the activated input once (no weight gradient shares it): the operand prologue of the project GEMM beats the
+# extra pass at every width - batch 64, 448 / 512 / 768 px: 61.1 / 76.6 / 172.2 ms with the training threshold, 58.4 / 73.0 / 163.7 without
+MATERIALISE_ABOVE_EVAL = int(os.environ.get("MUSCLE_MATERIALISE_ABOVE_EVAL", str(1 << 30)))
+# ... where the GEMM has rows to spread the prologue's sigmoid over: the batch-1 multi-scale passes of infer_mcl.py (a few thousand
+# rows in the late stages) keep the materialised input (one 500x375 image, 8 passes: 40.4 ms against 42.4)
+EVAL_PROLOGUE_MIN_ROWS = int(os.environ.get("MUSCLE_EVAL_PROLOGUE_MIN_ROWS", "16384"))
 
 
 def _blk(backbone, i):
@@ -137,7 +143,7 @@ def _block_forward_eval(m, b: BlockCfg, f, ident, x, x_st, N, h, w, ho, wo):
                             m._se_expand.weight.view(b.cexp, b.se), m._se_expand.bias)
     d2 = d.view(Mo, b.cexp)
     res = x.view(M, b.cin) if b.skip else None
-    if b.cout > MATERIALISE_ABOVE:
+    if b.cout > MATERIALISE_ABOVE_EVAL or (Mo < EVAL_PROLOGUE_MIN_ROWS and b.cout > MATERIALISE_ABOVE):
         a = ops.bn_apply(d2, f["bn1"], gate=gate, rows_per_sample=ho * wo, act=True)
         out = ops.pw_fwd(a, f["Wp"], b.cout, bias=f["bp"], residual=res)
     else:

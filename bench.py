@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 from muscle_amd import arch, synth  # noqa: E402
 
-GEMM_CALLS = ("mx_pw_fwd", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile")
+GEMM_CALLS = ("mx_pw_fwd", "mx_pw_fwd_planes", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile")
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # same guide, dense bf16 MFMA (no sparsity)
 SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0    # split arithmetic: six bf16 products per fp32 product -> 416.7 fp32-equivalent
@@ -33,7 +33,7 @@ ARITH_MODE = {"fp32": 0, "split": 1}
 ARITH_TEXT = {
     "fp32": "exact-fp32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32) for every GEMM",
     "split": "fp32 operands split exactly into three bf16 terms (x = h + m + l), six of the nine cross products on "
-             "v_mfma_f32_32x32x16_bf16 with fp32 accumulation, for the MFMA-bound forward / data-gradient (K >= 128) and "
+             "v_mfma_f32_16x16x32_bf16 / 32x32x16_bf16 with fp32 accumulation, for the MFMA-bound forward / data-gradient (K >= 128) and "
              "weight-gradient GEMMs; the others on exact-fp32 MFMA; error vs fp64 equal to the fp32-MFMA kernels' (DESIGN.md section 3)"}
 HBM_PEAK_GBPS = 8000.0                # same guide: HBM3E spec; 6290 GB/s is what a float4 copy achieves
 # whole-step ceilings per GPU for B7 / 448x448 step-A: exact-fp32 MFMA and HBM (minimum-materialisation schedule)
@@ -74,6 +74,9 @@ class GemmTimer:
             if name == "mx_pw_fwd":
                 M, K, N = a[8], a[9], a[10]
                 return 2.0 * M * K * N, 0, M, N, K
+            if name == "mx_pw_fwd_planes":
+                M, K, N = a[3], a[4], a[5]
+                return 2.0 * M * K * N, 2, M, N, K              # second-generation split kernel: always split
             if name == "mx_pw_dgrad":
                 M, K, N = a[3], a[4], a[5]
                 return 2.0 * M * K * N, -1, M, N, K             # NN kernel: never split
@@ -83,7 +86,7 @@ class GemmTimer:
         def timed(name, *a):
             if me.on and name in GEMM_CALLS:
                 flop, kind, M, N, K = shape_of(name, a)
-                split = kind >= 0 and bool(_lib.lib().mx_gemm_uses_split(kind, M, N, K))
+                split = kind == 2 or (kind >= 0 and bool(_lib.lib().mx_gemm_uses_split(kind, M, N, K)))
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 inner(name, *a)

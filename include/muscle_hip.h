@@ -62,6 +62,20 @@ int mx_get_gemm_mode(void);
  * C[M,N] = A[M,K] W[N,K]^T; kind 1: weight gradient dW[M=Co,N=Ci] over K=R rows), else 0 - for measurement code. */
 int mx_gemm_uses_split(int kind, int M, int N, int K);
 
+/* Second-generation split kernel (round 4): the weight of a 1x1 convolution (model.py:44,63: `_expand_conv`, `_project_conv`) is
+ * split ONCE per optimizer step into three bf16 planes laid out as the kernel's LDS image (bytes: mx_pw_planes_bytes; K % 32 == 0,
+ * else MX_EARG = no image for this shape), and mx_pw_fwd_planes runs C[M,N] = A[M,K] * W[N,K]^T (+bias) (+residual) (relu)
+ * (+stats as mx_pw_fwd) on a PLAIN fp32 A against that image - same split arithmetic as mode 1 of mx_set_gemm_mode.
+ * mx_pw_planes_batch: n matrices in one launch; table = DEVICE array of n rows of 5 longs {src W[N][K] fp32, dst image, N, K,
+ * first_tile}, first_tile = running sum of mx_pw_planes_tiles, total_tiles = the full sum.
+ * mx_pw_fwd_uses_planes: 1 if, in the current mode, a GEMM of this shape should take mx_pw_fwd_planes (else call mx_pw_fwd). */
+long mx_pw_planes_bytes(int N, int K);
+int mx_pw_planes_tiles(int N, int K);
+int mx_pw_planes_batch(const long* table, int n, int total_tiles, void* stream);
+int mx_pw_fwd_uses_planes(int M, int K, int N);
+int mx_pw_fwd_planes(const float* A, const void* Wplanes, float* C, int M, int K, int N, int lda, int ldc,
+                     const float* bias, const float* residual, int relu, float* stats, void* stream);
+
 /* dst[cols,rows] = src[rows,cols]^T (conv weights): the data gradient runs as mx_pw_fwd against the transposed weight. */
 int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream);
 /* n such transposes in one launch (every 1x1 conv weight of the network, once per step).  table: DEVICE array of n rows of 5 longs

@@ -745,9 +745,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
     for (int i = 0; i < 2; ++i) {
       ra[i] = (oka[i] && kin) ? ld4(pa[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (AMODE == MX_BNACT) gt[i] = (oka[i] && kin && ga_off[i] >= 0) ? ld4(g.a.rowp + ga_off[i] + k0) : make_float4(1.f, 1.f, 1.f, 1.f);
-#ifndef MX_LAB_BGLOBAL
       if (i < NB) rb[i] = (okb[i] && kin) ? ld4(pb[i] + k0) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
     }
     if (AMODE != MX_PLAIN) {
       sc4 = kin ? ld4(g.a.c1 + k0 + ck) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -756,12 +754,8 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
   };
   auto put = [&](unsigned char* base, int plane, int off, float4 v) {
     unsigned h0, m0_, l0, h1, m1, l1;
-#ifdef MX_LAB_NOSPLIT      // tools/hip/gemm_lab only: what the kernel would cost without the VALU split (results are wrong)
-    h0 = m0_ = l0 = __float_as_uint(v.x) ^ __float_as_uint(v.y); h1 = m1 = l1 = __float_as_uint(v.z) ^ __float_as_uint(v.w);
-#else
     split3_pair(v.x, v.y, h0, m0_, l0);
     split3_pair(v.z, v.w, h1, m1, l1);
-#endif
     *reinterpret_cast<uint2*>(base + off) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(base + plane + off) = make_uint2(m0_, m1);
     *reinterpret_cast<uint2*>(base + 2 * plane + off) = make_uint2(l0, l1);
@@ -773,9 +767,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
       float4 v = ra[i];
       if (AMODE != MX_PLAIN && oka[i] && kin) v = nt_prologue<AMODE>(v, sc4, sh4, gt[AMODE == MX_BNACT ? i : 0]);
       put(st, PA_, woff[i], v);
-#ifndef MX_LAB_BGLOBAL
-      if (i < NB) put(st + 3 * PA_, PB_, woff[i], rb[i]);   // (weights split per workgroup: pre-split planes measured 2-6 %)
-#endif
+      if (i < NB) put(st + 3 * PA_, PB_, woff[i], rb[i]);
     }
   };
 
@@ -807,37 +799,18 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
   for (int kt = 0; kt < nk; ++kt) {
     const int cur = kt & 1;
     if (kt + 1 < nk) {
-#ifndef MX_LAB_NOSTORE
       store(smem + (cur ^ 1) * STAGE, (kt + 1) * 16);
-#endif
-#ifndef MX_LAB_NOLOAD
       if (kt + 2 < nk) load((kt + 2) * 16);
-#endif
     }
     const unsigned char* sa = smem + cur * STAGE;
     const unsigned char* sb = sa + 3 * PA_;
     bf16x8 av[2][3], bv[NJ][3];
-#if defined(MX_LAB_NOREAD)      // lab: the loop without its LDS fragment reads (MFMA + barrier floor)
-    if (kt == 0)
-#endif
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-#if defined(MX_LAB_READ2)       // lab: two planes' worth of LDS reads instead of three
-      if (p == 2) { av[0][2] = av[0][1]; av[1][2] = av[1][1]; for (int j = 0; j < NJ; ++j) bv[j][2] = bv[j][1]; break; }
-#endif
 #pragma unroll
       for (int i = 0; i < 2; ++i) av[i][p] = *reinterpret_cast<const bf16x8*>(sa + p * PA_ + fa[i]);
-#ifndef MX_LAB_BGLOBAL
 #pragma unroll
       for (int j = 0; j < NJ; ++j) bv[j][p] = *reinterpret_cast<const bf16x8*>(sb + p * PB_ + fb[j]);
-#else
-      // lab: as if the weights were pre-split, pre-swizzled fragment images in global memory (timing only, garbage values)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const long frag = ((long)(tile_n * (BN / 32) + wn * NJ + j) * nk + kt) * 3 + p;
-        bv[j][p] = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const unsigned char*>(B) + frag * 1024 + lane * 16);
-      }
-#endif
     }
     // six products, smallest terms first: (w,a) = (h,l) (l,h) (m,m) (h,m) (m,h) (h,h); product-major so that consecutive
     // MFMAs write different accumulators; the weight fragment is the first operand (see the epilogue)
@@ -849,9 +822,7 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv[j][PW[t]], av[i][PX[t]], acc[i][j], 0, 0, 0);
-#ifndef MX_LAB_NOSYNC
     __syncthreads();
-#endif
   }
   // epilogue: acc[i][j][4 gq + e] = C[m = 32 i + l31][n = 32 j + 8 gq + 4 hf + e].  Bias / residual / relu / statistics in
   // registers; the values then cross a per-wave LDS patch [32][WNC] so that a store instruction writes whole rows
@@ -947,6 +918,177 @@ __global__ __launch_bounds__(256, NJ == 4 ? 2 : 3) void gemm_nt_split_kernel(Gem
   }
 }
 
+// =====================================================================================================================
+// Split-arithmetic NT GEMM, second generation (round 4): no operand crosses a VGPR on its way to LDS, and only the weights
+// go through LDS at all.
+//
+// What bounded gemm_nt_split_kernel (profiles/r03_split_gemm_loop_dissection.txt): ~100 of 286 us on the large layers were
+// the operand path - the VALU split of BOTH operands in EVERY workgroup (the weights re-split by each of the 196..3136 M
+// tiles), twelve ds_write_b64 per thread and K step, register staging one short K step ahead.  Here:
+//   * the WEIGHTS are split once per step into three bf16 planes stored as the LDS image itself (mx_pw_planes_batch: per
+//     32-deep K step and plane a run of [Npad rows][64 B], the 16-byte chunks of a row permuted by swz_w), so a workgroup's
+//     share is copied by LDS-DMA (global_load_lds_dwordx4: 1 KB per wave instruction, linear on both sides), two stages;
+//   * the ACTIVATIONS never enter LDS: with a 4 x 1 wave layout a wave is the ONLY reader of its 32 rows, so each lane loads
+//     its own fragments straight from HBM one K step ahead (two 16-byte loads per row tile; the four k groups of a row take
+//     chunks q and 4 + q of the 128-byte line, so one load instruction covers 16 rows x 64 contiguous bytes - the weight
+//     image is built in the same k order) and splits them in registers: 88 VALU operations per 96 MFMAs, no redundancy;
+//   * v_mfma_f32_16x16x32_bf16 (K = 32 per instruction, the shape that holds the higher clock on random data,
+//     MI355X_MICROARCH.md "DVFS give-back" item 7): a lane's weight fragment is one ds_read_b128 of a plane; the accumulator
+//     layout is gemm_nt_kernel's, so the epilogue (bias / residual / relu / statistics / 16-byte stores straight from
+//     registers) is nt_epilogue unchanged;
+//   * LDS: 24 KB per stage at 128 columns, 3 workgroups per CU; one barrier per K step.
+// Same arithmetic as the first generation: x = h + m + l exactly, six products (h,l) (l,h) (m,m) (h,m) (m,h) (h,h).
+// Conflict-free ds_read_b128: the lane groups of a b128 read ({0-3,12-15,20-27}, ...) hold every row l15 = 0..15 once, with
+// the k group q = lane >> 4 taking two values that differ exactly where bit2 ^ bit3 of the row differs; XOR-ing the chunk
+// index with 3 * bit3(row) makes the 16-byte slot index a bijection of the four row bits in every group
+// (MI355X_MICROARCH.md, LDS).
+// Measured against the first generation in one process (tools/hip/gemm_lab planes, profiles/r04_gemm_lab_planes.txt), M = 25088:
+// 384 -> 2304 278 -> 234 us, 2304 -> 384 289 -> 231, 640 -> 3840 711 -> 596, 3840 -> 640 722 -> 573, 224 -> 1344 111 -> 93,
+// 1344 -> 224 111 -> 97, 160 -> 960 65 -> 55, 960 -> 160 75 -> 65 (190-215 TFLOP/s fp32-equivalent on the K >= 384 layers).
+// Also built and measured there, not kept: the activations through LDS as an fp32 image filled by LDS-DMA (80 KB of LDS, 2
+// workgroups per CU: equal on the long-K layers, 5-12 % slower on the short-K ones), three LDS stages at 1 workgroup per CU
+// (30-50 % slower), a start delay for the second / third resident workgroup of a CU against lockstep epilogues (slower).
+static __device__ __forceinline__ int swz_w(int row) { return ((row >> 3) & 1) * 3; }                        // bf16 plane, 4 chunks per row
+
+static __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// pre-split image of a weight matrix W[N][K] (K % 32 == 0): planes[((kt * 3 + p) * Npad + n) * 64 + c' * 16 + 2 e] =
+// bf16 term p of W[n][32 kt + 4 c + (e < 4 ? e : 12 + e)] with c = c' ^ swz_w(n) (chunk c = k 4c..4c+3 and 16+4c..16+4c+3 of
+// the K step: the order gemm_nt_split3_kernel's lanes load the activations in); rows n >= N zero; Npad = N rounded up to 128
+// table: rows of 5 longs {src, dst, N, K, first_tile}; a tile = (K step, group of 64 rows) -> Npad/64 * K/32 tiles per matrix
+__global__ __launch_bounds__(256) void split_planes_kernel(const long* __restrict__ table, int njobs) {
+  __shared__ int job_s;
+  if (threadIdx.x == 0) {
+    int j = 0;
+    while (j + 1 < njobs && table[(j + 1) * 5 + 4] <= (long)blockIdx.x) ++j;
+    job_s = j;
+  }
+  __syncthreads();
+  const long* e = table + job_s * 5;
+  const float* src = reinterpret_cast<const float*>(e[0]);
+  unsigned char* dst = reinterpret_cast<unsigned char*>(e[1]);
+  const int N = (int)e[2], K = (int)e[3], Npad = (N + 127) & ~127;
+  const int tile = (int)(blockIdx.x - e[4]);
+  const int rg = Npad / 64, kt = tile / rg, n = (tile % rg) * 64 + (threadIdx.x >> 2);
+  const int cp = threadIdx.x & 3, c = cp ^ swz_w(n);
+  unsigned h[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
+  if (n < N) {
+    const float* s = src + (long)n * K + 32 * kt + 4 * c;
+    const float4 x0 = ld4(s), x1 = ld4(s + 16);
+    split3_pair(x0.x, x0.y, h[0], m[0], l[0]);
+    split3_pair(x0.z, x0.w, h[1], m[1], l[1]);
+    split3_pair(x1.x, x1.y, h[2], m[2], l[2]);
+    split3_pair(x1.z, x1.w, h[3], m[3], l[3]);
+  }
+  const long ps = (long)Npad * 64;
+  unsigned char* d = dst + ((long)(kt * 3) * Npad + n) * 64 + cp * 16;
+  *reinterpret_cast<uint4*>(d) = make_uint4(h[0], h[1], h[2], h[3]);
+  *reinterpret_cast<uint4*>(d + ps) = make_uint4(m[0], m[1], m[2], m[3]);
+  *reinterpret_cast<uint4*>(d + 2 * ps) = make_uint4(l[0], l[1], l[2], l[3]);
+}
+
+template <int TN>
+__global__ __launch_bounds__(256, 3) void gemm_nt_split3_kernel(GemmArgs g) {
+  constexpr int BM = 128, BN = 16 * TN;
+  constexpr int W_PLANE = BN * 64, STAGE = 3 * W_PLANE;
+  constexpr int WPIECES = 3 * BN / 16, WPW = WPIECES / 4;
+  static_assert(WPIECES % 4 == 0, "every wave issues the same number of LDS-DMA loads per stage");
+  static_assert(4 * 2 * BN * 4 <= 2 * STAGE, "statistics staging does not fit");
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, q = lane >> 4;
+  int tile_m = blockIdx.x, tile_n = blockIdx.y;
+  if (g.xcd_nt > 0) {
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    tile_n = j % g.xcd_nt;
+    tile_m = (j / g.xcd_nt) * 8 + xcd;
+    if (tile_m >= g.mt) return;
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const long zb = blockIdx.z;
+  const float* A = g.a.p + zb * g.sa;
+  const unsigned char* WP = reinterpret_cast<const unsigned char*>(g.b.p);
+  float* C = g.c + zb * g.sc;
+  const int nk = g.K >> 5;
+  const long npad64 = (long)g.ldb * 64;
+
+  const float* ap[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int gr = min(m0 + 32 * wave + 16 * i + l15, g.M - 1);   // rows past M re-read the last row (their outputs are not stored)
+    ap[i] = A + (long)gr * g.lda + 4 * q;
+  }
+  const unsigned char* wsrc[WPW];
+  int wdst[WPW];
+#pragma unroll
+  for (int i = 0; i < WPW; ++i) {
+    const int pw = wave + 4 * i, p = pw / (BN / 16), rp = pw % (BN / 16);
+    wsrc[i] = WP + ((long)p * g.ldb + n0 + 16 * rp) * 64 + lane * 16;
+    wdst[i] = p * W_PLANE + rp * 1024;
+  }
+  auto issue_w = [&](int kt) {
+    unsigned char* st = smem + (kt & 1) * STAGE;
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) glds16(wsrc[i] + 3 * npad64 * kt, st + wdst[i]);
+  };
+  f32x4 raw[2][2];
+  auto load_a = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      raw[i][0] = *reinterpret_cast<const f32x4*>(ap[i] + 32 * kt);
+      raw[i][1] = *reinterpret_cast<const f32x4*>(ap[i] + 32 * kt + 16);
+    }
+  };
+
+  f32x4 acc[2][TN];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int woff = l15 * 64 + ((q ^ swz_w(l15)) << 4);
+
+  issue_w(0);
+  load_a(0);
+  for (int kt = 0; kt < nk; ++kt) {
+    // this wave's loads of step kt (weight pieces by LDS-DMA, its own activation rows) are done; split before the barrier
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    bf16x8 af[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      unsigned h[4], m[4], l[4];
+      split3_pair(raw[i][0][0], raw[i][0][1], h[0], m[0], l[0]);
+      split3_pair(raw[i][0][2], raw[i][0][3], h[1], m[1], l[1]);
+      split3_pair(raw[i][1][0], raw[i][1][1], h[2], m[2], l[2]);
+      split3_pair(raw[i][1][2], raw[i][1][3], h[3], m[3], l[3]);
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      af[i][0] = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+      af[i][1] = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+      af[i][2] = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+    }
+    __builtin_amdgcn_s_barrier();      // every wave's share of stage kt has landed; every read of the other stage is retired
+    if (kt + 1 < nk) { issue_w(kt + 1); load_a(kt + 1); }
+    const unsigned char* st = smem + (kt & 1) * STAGE;
+    constexpr int PW[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      bf16x8 wf[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) wf[p] = *reinterpret_cast<const bf16x8*>(st + woff + p * W_PLANE + j * 1024);
+#pragma unroll
+      for (int t = 0; t < 6; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PW[t]], af[i][PX[t]], acc[i][j], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+  nt_epilogue<4, 1, 2, TN>(g, C, tile_m, m0, n0, acc, reinterpret_cast<float*>(smem), tid);
+}
+
 // 0 = exact-fp32 MFMA everywhere; 1 (default since round 3) = split arithmetic for the MFMA-bound forward / data-gradient /
 // weight-gradient shapes, exact-fp32 MFMA for the rest; 2 = split arithmetic for every NT GEMM (tests).  Process-wide;
 // MX_GEMM_SPLIT sets the initial value.  Every golden / oracle parity test runs in modes 0 AND 1 with the same tolerances
@@ -1001,6 +1143,34 @@ static void launch_nt_split(const GemmArgs& g, int batch, hipStream_t st) {
   if (forced == 4) launch_nt_split_t<4>(g, batch, st);
   else if (narrow) launch_nt_split_t<1>(g, batch, st);
   else launch_nt_split_t<2>(g, batch, st);
+}
+
+// ---- second-generation split kernel: pre-split weight planes (mx_pw_planes_batch) -----------------------------------
+template <int TN>
+static void launch_nt_split3_t(const GemmArgs& g, int batch, hipStream_t st) {
+  constexpr int BN = 16 * TN;
+  const int mt = cdiv(g.M, 128), nt = cdiv(g.N, BN);
+  GemmArgs a = g;
+  a.mt = mt;
+  a.xcd_nt = 0;
+  dim3 grid(mt, nt, batch);
+  if (nt >= 2 && nt <= 16 && mt >= 64) { a.xcd_nt = nt; grid = dim3(8 * cdiv(mt, 8) * nt, 1, batch); }
+  hipLaunchKernelGGL((gemm_nt_split3_kernel<TN>), grid, dim3(256), 0, st, a);
+}
+
+// 128 x 128 or 128 x 64.  Tiles are dealt over 256 CUs: time ~ (tiles per CU + half a tile of tail) x tile width, the 64-wide
+// tile doing 0.85 of the wide tile's work per unit time (measured 0.84-0.96 on the M = 25088 layers); a grid of fewer than
+// ~1.2 wide tiles per CU always takes the narrow tile (M = 6272: 2304 -> 384 108 -> 91 us, M = 12544: 1152 -> 192 61 -> 51).
+static int g_split_nj = getenv("MX_GEMM_SPLIT_NJ") ? atoi(getenv("MX_GEMM_SPLIT_NJ")) : 0;     // 1: force 128 x 64, 2: force 128 x 128
+static void launch_nt_split3(const GemmArgs& g, int batch, hipStream_t st) {
+  auto cost = [&](int bn, double eff) {
+    const double per_cu = (double)cdiv(g.M, 128) * cdiv(g.N, bn) * batch / 256.0;
+    return (per_cu + 0.5) * bn / eff;
+  };
+  const long wide_tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * batch;
+  const bool narrow = g_split_nj ? g_split_nj == 1 : (wide_tiles <= 300 || cost(64, 0.85) < cost(128, 1.0));
+  if (narrow) launch_nt_split3_t<4>(g, batch, st);
+  else launch_nt_split3_t<8>(g, batch, st);
 }
 
 // tile table of the second-generation NT kernel: {BM, BN}; every entry has 128 rows
@@ -1193,6 +1363,52 @@ int mx_transpose_batch(const long* table, int n, int total_tiles, void* stream) 
 int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream) {
   MX_CHECK_ARG(src && dst && rows > 0 && cols > 0, "transpose: bad arguments");
   hipLaunchKernelGGL(transpose_kernel, dim3(cdiv(cols, 32), cdiv(rows, 32)), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// ---- pre-split weight planes --------------------------------------------------------------------------------------
+// bytes of the image mx_pw_planes writes for a weight W[N][K]; MX_EARG when the shape has none (K % 32 != 0)
+long mx_pw_planes_bytes(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32) return MX_EARG;
+  return (long)((N + 127) & ~127) * K * 6;
+}
+
+// number of workgroups (tiles) mx_pw_planes_batch needs for one matrix
+int mx_pw_planes_tiles(int N, int K) {
+  if (N <= 0 || K <= 0 || K % 32) return MX_EARG;
+  return (((N + 127) & ~127) / 64) * (K / 32);
+}
+
+// n weight matrices in one launch.  table: DEVICE array of n rows of 5 longs {src W[N][K] fp32, dst image, N, K, first_tile};
+// first_tile = running sum of mx_pw_planes_tiles over the rows before; total_tiles = the full sum
+int mx_pw_planes_batch(const long* table, int n, int total_tiles, void* stream) {
+  MX_CHECK_ARG(table && n > 0 && total_tiles > 0, "pw_planes_batch: bad arguments");
+  hipLaunchKernelGGL(split_planes_kernel, dim3(total_tiles), dim3(256), 0, (hipStream_t)stream, table, n);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// 1 when, in the current mode, a forward / data-gradient GEMM of this shape should be run through mx_pw_fwd_planes
+int mx_pw_fwd_uses_planes(int M, int K, int N) {
+  static const int on = getenv("MX_SPLIT2") ? atoi(getenv("MX_SPLIT2")) : 1;
+  return (on && M > 0 && K % 32 == 0 && nt_uses_split(N, K)) ? 1 : 0;
+}
+
+// C[M,N] = A[M,K] * W[N,K]^T (+bias) (+residual) (relu) with W given as its pre-split image (mx_pw_planes_batch) and a plain A:
+// split arithmetic, second-generation kernel.
+int mx_pw_fwd_planes(const float* A, const void* Wplanes, float* C, int M, int K, int N, int lda, int ldc,
+                     const float* bias, const float* residual, int relu, float* stats, void* stream) {
+  MX_CHECK_ARG(A && Wplanes && C, "pw_fwd_planes: null pointer");
+  MX_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 32 == 0, "pw_fwd_planes: bad extents M=%d N=%d K=%d (K must be a multiple of 32)", M, N, K);
+  MX_CHECK_ARG(lda % 4 == 0 && lda >= K && ldc >= N, "pw_fwd_planes: bad leading dimensions lda=%d ldc=%d", lda, ldc);
+  MX_CHECK_ARG((((uintptr_t)A | (uintptr_t)Wplanes | (uintptr_t)C) & 15) == 0, "pw_fwd_planes: pointers must be 16-byte aligned");
+  GemmArgs g{};
+  g.a = MxOperand{A, nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.b = MxOperand{reinterpret_cast<const float*>(Wplanes), nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.c = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = (N + 127) & ~127; g.ldc = ldc;
+  g.bias = bias; g.residual = residual; g.relu = relu; g.stats = stats;
+  launch_nt_split3(g, 1, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

@@ -69,6 +69,8 @@ class Tape:
     blocks: List[BlockTape] = field(default_factory=list)
     wt: Dict[int, torch.Tensor] = field(default_factory=dict)     # id(conv weight) -> transposed copy for the data gradient
     wt_event: Optional["torch.cuda.Event"] = None                 # ... valid on the main stream after this event
+    wp: Dict[int, int] = field(default_factory=dict)              # id(conv weight) -> pre-split image of W (forward GEMMs)
+    wtp: Dict[int, int] = field(default_factory=dict)             # id(conv weight) -> pre-split image of W^T (data gradients)
 
 
 _keep_cache: Dict[tuple, torch.Tensor] = {}
@@ -155,14 +157,12 @@ def _block_forward_eval(m, b: BlockCfg, f, ident, x, x_st, N, h, w, ho, wo):
 EVAL_FOLD = os.environ.get("MUSCLE_EVAL_FOLD", "1") == "1"
 
 
-def _prefetch_transposes(backbone, cfg: NetCfg, tape: Tape, dev):
-    """The data-gradient GEMMs run as forward GEMMs against W^T (ops.pw_dgrad).  The ~110 small transposes depend on
-    nothing but the weights, so they are issued on the side stream at the start of the forward, where they fill the gaps
-    of the main stream's kernel chain instead of sitting on the backward's critical path (5 + 2 us each there)."""
-    if not (WGRAD_SIDE_STREAM and ops.DGRAD_AS_FORWARD):
-        return
-    side = _WgradLane(dev).s
-    side.wait_stream(torch.cuda.current_stream())            # the optimizer step that produced these weights
+def _prepare_weights(backbone, cfg: NetCfg, tape: Tape, dev, backward: bool):
+    """Per-step derivatives of the 1x1 conv weights (ops.WeightPlan).  The pre-split images of W feed the forward GEMMs of the
+    second-generation split kernel: one launch on the main stream, ahead of the stem.  With `backward`, the data-gradient GEMMs
+    run as forward GEMMs against W^T (ops.pw_dgrad): the ~110 transposes (one launch) and the images of W^T (one launch)
+    depend on nothing but the weights, so they go to the side stream at the start of the forward, where they fill the gaps of
+    the main stream's kernel chain instead of sitting on the backward's critical path."""
     ws = []
     for b in cfg.blocks:
         m = _blk(backbone, b.index)
@@ -172,21 +172,40 @@ def _prefetch_transposes(backbone, cfg: NetCfg, tape: Tape, dev):
             ws.append((m._project_conv.weight, m._project_conv.weight.view(b.cout, b.cexp)))
     if not ws:
         return
-    # one launch for all of them, into buffers that live with the backbone (the previous step's backward, the only reader, is
-    # behind the wait above); rebuilt when a weight has moved (load on another device, re-created parameters)
+    # buffers and tables live with the backbone (the previous step's backward, the only other reader, is behind the stream order);
+    # rebuilt when a weight has moved (load on another device, re-created parameters)
     plan = getattr(backbone, "_wt_plan", None)
     views = [v for _, v in ws]
     if plan is None or not plan.matches(views):
-        # (building the plan uploads a table: not under stream capture - a captured step whose eager warm-up did not come
-        # through here transposes weight by weight, into the graph's own pool)
+        # (building the plan uploads tables: not under stream capture - a captured step whose eager warm-up did not come
+        # through here transposes weight by weight, into the graph's own pool, and runs the first-generation split kernel)
         if plan is not None:                       # a captured graph may still write into its buffers: retired, not freed
             backbone.__dict__.setdefault("_wt_plans_retired", []).append(plan)
-        plan = None if torch.cuda.is_current_stream_capturing() else ops.TransposePlan(views)
+        plan = None if torch.cuda.is_current_stream_capturing() else ops.WeightPlan(views)
         backbone._wt_plan = plan
+    if plan is not None and ops.get_gemm_mode() != 0:
+        for (w, _), im in zip(ws, plan.run_forward()):
+            if im is not None:
+                tape.wp[id(w)] = im
+    if not (backward and ops.DGRAD_AS_FORWARD):
+        return
+    side = _WgradLane(dev).s
+    if side is None:
+        if plan is not None:
+            wts, ims = plan.run_backward()
+            for (w, _), wt, im in zip(ws, wts, ims):
+                tape.wt[id(w)] = wt
+                if im is not None and ops.get_gemm_mode() != 0:
+                    tape.wtp[id(w)] = im
+        return
+    side.wait_stream(torch.cuda.current_stream())            # the optimizer step that produced these weights
     with torch.cuda.stream(side):
         if plan is not None:
-            for (w, _), wt in zip(ws, plan.run()):
+            wts, ims = plan.run_backward()
+            for (w, _), wt, im in zip(ws, wts, ims):
                 tape.wt[id(w)] = wt
+                if im is not None and ops.get_gemm_mode() != 0:
+                    tape.wtp[id(w)] = im
         else:
             for w, v in ws:
                 tape.wt[id(w)] = ops.transpose(v)
@@ -205,8 +224,9 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
     lo, hi = cfg.stem_pad
     H0, W0 = (H + lo + hi - 3) // 2 + 1, (W + lo + hi - 3) // 2 + 1
     tape.H0, tape.W0 = H0, W0
-    if save:                                    # a backward will follow (train mode, or phase 2's eval-mode forward of view 1)
-        _prefetch_transposes(backbone, cfg, tape, dev)
+    # save: a backward will follow (train mode, or phase 2's eval-mode forward of view 1)
+    if save or training or not EVAL_FOLD:
+        _prepare_weights(backbone, cfg, tape, dev, backward=save)
     # stem: im2col + MFMA GEMM (K = 27 padded to 28), BN statistics in the GEMM epilogue
     tape.cols = ops.stem_im2col(img, H0, W0, lo)
     C0 = cfg.stem_out
@@ -256,7 +276,8 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
         if b.expand:
             assert x_st is None
             st0 = None
-            t.e_raw = ops.pw_fwd(x.view(M, b.cin), m._expand_conv.weight.view(b.cexp, b.cin), b.cexp, want_stats=training)
+            t.e_raw = ops.pw_fwd(x.view(M, b.cin), m._expand_conv.weight.view(b.cexp, b.cin), b.cexp, want_stats=training,
+                                 planes=tape.wp.get(id(m._expand_conv.weight)))
             if training:
                 t.e_raw, st0 = t.e_raw
             t.e_raw = t.e_raw.view(N, h, w, b.cexp)
@@ -280,7 +301,8 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
             # through the per-CU load path) once per tile: measured 100 -> 63 TFLOP/s at K=3840, N=640.  One streaming
             # pass writes the activated tensor instead; it is kept for the weight gradient.
             t.a = ops.bn_apply(d2, t.bn1, gate=t.gate, rows_per_sample=ho * wo, act=True)
-            t.p_raw = ops.pw_fwd(t.a, m._project_conv.weight.view(b.cout, b.cexp), b.cout, want_stats=training)
+            t.p_raw = ops.pw_fwd(t.a, m._project_conv.weight.view(b.cout, b.cexp), b.cout, want_stats=training,
+                                 planes=tape.wp.get(id(m._project_conv.weight)))
         else:
             t.p_raw = ops.pw_fwd(d2, m._project_conv.weight.view(b.cout, b.cexp), b.cout, a_mode=ops.BNACT,
                                  a_scale=t.bn1.scale, a_shift=t.bn1.shift, a_gate=t.gate, rows_per_sample=ho * wo,
@@ -451,8 +473,8 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         else:
             lane.wgrad(dp, d2, sink.of(m._project_conv.weight).view(b.cout, b.cexp), x_mode=ops.BNACT, x_scale=t.bn1.scale,
                        x_shift=t.bn1.shift, x_gate=t.gate, rows_per_sample=hw)
-        ga = ops.pw_dgrad(dp, m._project_conv.weight.view(b.cout, b.cexp), b.cexp,
-                          wt=tape.wt.get(id(m._project_conv.weight)))                         # dL/d(act*gate) [Mo,Cexp]
+        ga = ops.pw_dgrad(dp, m._project_conv.weight.view(b.cout, b.cexp), b.cexp, wt=tape.wt.get(id(m._project_conv.weight)),
+                          planes=tape.wtp.get(id(m._project_conv.weight)))                    # dL/d(act*gate) [Mo,Cexp]
         lane.flush()
         del dp
         # One pass over (ga, d_raw) yields the SE gate gradient sum_hw ga*act AND the per-sample pieces of the BN1 backward
@@ -507,6 +529,7 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
             elif b.expand:
                 lane.wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
                 g_in = ops.pw_dgrad(dz, m._expand_conv.weight.view(b.cexp, b.cin), b.cin, wt=tape.wt.get(id(m._expand_conv.weight)),
+                                    planes=tape.wtp.get(id(m._expand_conv.weight)),
                                     residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)
                 lane.flush()
                 g_out = g_in.view(N, t.H, t.W, b.cin)

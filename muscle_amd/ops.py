@@ -49,9 +49,22 @@ def _scratch(device, nbytes):
 
 
 # ---- GEMMs ------------------------------------------------------------------------------------
+_uses_planes: dict = {}
+
+
+def _planes_take(M, K, N_out):
+    """Does a plain-A GEMM of this shape go to the second-generation split kernel in the current arithmetic?  (cached per mode)"""
+    key = (get_gemm_mode(), M, K, N_out)
+    r = _uses_planes.get(key)
+    if r is None:
+        r = _uses_planes[key] = bool(lib().mx_pw_fwd_uses_planes(M, K, N_out))
+    return r
+
+
 def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None, rows_per_sample=1,
-           bias=None, residual=None, relu=False, want_stats=False, out=None, ldc=None):
-    """A: [M, K]; W: [N_out, K] -> [M, N_out] (and, if want_stats, the partial BN statistics [P, 2, N_out])."""
+           bias=None, residual=None, relu=False, want_stats=False, out=None, ldc=None, planes=None):
+    """A: [M, K]; W: [N_out, K] -> [M, N_out] (and, if want_stats, the partial BN statistics [P, 2, N_out]).
+    planes: the pre-split image of W (WeightPlan), used when A is plain and the shape runs in split arithmetic."""
     M, K = A.shape
     ldc = ldc or N_out
     if out is None:
@@ -59,8 +72,12 @@ def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None
     stats = None
     if want_stats:
         stats = _f32(lib().mx_pw_fwd_parts(M, N_out, K), 2, N_out, device=A.device)
-    call("mx_pw_fwd", ptr(A), a_mode, ptr(a_scale), ptr(a_shift), ptr(a_gate), rows_per_sample, ptr(W), ptr(out),
-         M, K, N_out, A.stride(0), ldc, ptr(bias), ptr(residual), int(relu), ptr(stats), stream())
+    if planes is not None and a_mode == PLAIN and _planes_take(M, K, N_out):
+        call("mx_pw_fwd_planes", ptr(A), planes, ptr(out), M, K, N_out, A.stride(0), ldc, ptr(bias), ptr(residual), int(relu),
+             ptr(stats), stream())
+    else:
+        call("mx_pw_fwd", ptr(A), a_mode, ptr(a_scale), ptr(a_shift), ptr(a_gate), rows_per_sample, ptr(W), ptr(out),
+             M, K, N_out, A.stride(0), ldc, ptr(bias), ptr(residual), int(relu), ptr(stats), stream())
     return (out, stats) if want_stats else out
 
 
@@ -99,6 +116,67 @@ class TransposePlan:
         return self.dst
 
 
+class PlanesPlan:
+    """Pre-split bf16 images (mx_pw_planes_batch) of a fixed set of 2-D fp32 matrices [N, K]: one buffer, one launch.
+    images[i] is the device address of matrix i's image, or None where the shape has none (K % 32 != 0)."""
+
+    def __init__(self, mats):
+        dev = mats[0].device
+        L = lib()
+        rows, tile, off = [], 0, 0
+        sizes = []
+        for m in mats:
+            n, k = m.shape
+            nb = L.mx_pw_planes_bytes(n, k) if m.is_contiguous() else -1
+            sizes.append(nb)
+            if nb > 0:
+                off += (nb + 1023) & ~1023
+        self.buf = torch.empty(max(off, 1024), dtype=torch.uint8, device=dev)
+        base, off = self.buf.data_ptr(), 0
+        self.images = []
+        for m, nb in zip(mats, sizes):
+            if nb <= 0:
+                self.images.append(None)
+                continue
+            n, k = m.shape
+            rows.append([m.data_ptr(), base + off, n, k, tile])
+            self.images.append(base + off)
+            tile += L.mx_pw_planes_tiles(n, k)
+            off += (nb + 1023) & ~1023
+        self.n, self.tiles = len(rows), tile
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev) if rows else None
+        torch.cuda.current_stream(dev).synchronize()     # built once: the table is in place whichever stream runs the launch
+
+    def run(self):
+        if self.n:
+            call("mx_pw_planes_batch", ptr(self.table), self.n, self.tiles, stream())
+        return self.images
+
+
+class WeightPlan:
+    """What the GEMMs of a step derive from the 1x1 conv weights, rebuilt once per step in three launches: W^T for the data
+    gradients (TransposePlan), the pre-split images of W (forward) and of W^T (data gradient) for the second-generation
+    split kernel."""
+
+    def __init__(self, weights):
+        self.t = TransposePlan(weights)
+        self.key = self.t.key
+        self.fwd = PlanesPlan(weights)
+        self.bwd = PlanesPlan(self.t.dst)
+
+    def matches(self, weights):
+        return self.t.matches(weights)
+
+    def run_forward(self):
+        """images of W, for the forward GEMMs (enqueue on the stream that runs them)"""
+        return self.fwd.run()
+
+    def run_backward(self):
+        """(W^T list, images of W^T): nothing before the backward reads them - the side stream is the place"""
+        wt = self.t.run()
+        return wt, self.bwd.run()
+
+
 def transpose(W):
     """[rows, cols] -> contiguous [cols, rows] (weights)."""
     rows, cols = W.shape
@@ -110,12 +188,15 @@ def transpose(W):
 DGRAD_AS_FORWARD = True      # dX = G W as a forward GEMM against W^T (row-major LDS images, 16-column tiles); False: NN kernel
 
 
-def pw_dgrad(G, W, N_in, *, residual=None, out=None, wt=None):
-    """G: [M, K=Cout]; W: [Cout, Cin] -> dX [M, Cin].  wt: W^T [Cin, Cout] if the caller already has it."""
+def pw_dgrad(G, W, N_in, *, residual=None, out=None, wt=None, planes=None):
+    """G: [M, K=Cout]; W: [Cout, Cin] -> dX [M, Cin].  wt: W^T [Cin, Cout] if the caller already has it, planes: its pre-split image."""
     M, K = G.shape
     if out is None:
         out = _f32(M, N_in, device=G.device)
     if DGRAD_AS_FORWARD and K % 4 == 0:
+        if planes is not None and _planes_take(M, K, N_in):
+            call("mx_pw_fwd_planes", ptr(G), planes, ptr(out), M, K, N_in, G.stride(0), N_in, None, ptr(residual), 0, None, stream())
+            return out
         call("mx_pw_fwd", ptr(G), PLAIN, None, None, None, 1, ptr(wt if wt is not None else transpose(W)), ptr(out), M, K, N_in, G.stride(0), N_in,
              None, ptr(residual), 0, None, stream())
         return out

@@ -48,6 +48,7 @@ def _one_step(name, n, size, view, ep, seed, disturb):
     return losses, arena, params, bufs
 
 
+@pytest.mark.both_arith            # exact fp32 AND the library's default arithmetic (split kernels, weight planes)
 @pytest.mark.parametrize("name,n,size,view,ep", [("efficientnet-b0", 4, 64, 32, 4), ("efficientnet-b3", 4, 96, 48, 4),
                                                   ("efficientnet-b0", 4, 96, 64, 12)])        # ep 12: + PixPro + EMD, second backward + Adam
 def test_step_is_bit_reproducible(name, n, size, view, ep):

@@ -59,6 +59,7 @@ def test_adam_device_scalars_match_host_scalars():
     assert ob.state_dict()["state"][0]["step"] == 7
 
 
+@pytest.mark.both_arith            # the replay must equal the eager step in the library's default arithmetic too
 @pytest.mark.parametrize("ep", [0, 4])
 def test_graphed_step_matches_eager(ep):
     import muscle_amd

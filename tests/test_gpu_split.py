@@ -76,6 +76,73 @@ def test_split_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, mode, opts):
         assert a <= 1e-5 and b <= 1e-5
 
 
+@pytest.mark.parametrize("M,K,N,opts", [
+    (25088, 384, 2304, "stats"), (6272, 2304, 384, "stats+res"), (777, 640, 21, "bias+relu"), (3001, 64, 48, "res"),
+    (12544, 224, 1344, "stats"), (4096, 1344, 224, "res+stats"), (130, 160, 200, ""), (128, 32, 128, "stats"), (1, 96, 130, "bias")])
+def test_planes_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, opts):
+    """Second-generation split kernel (mx_pw_fwd_planes: weight planes split once, LDS-DMA, activations straight to registers,
+    16x16x32 MFMA) against fp64, beside the exact-fp32 kernel and the first-generation split kernel on the same inputs; ragged
+    rows / columns, every epilogue option, bit-identical from run to run."""
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * (K ** -0.5)
+    bias = torch.randn(N, device=DEV, generator=g) if "bias" in opts else None
+    res = torch.randn(M, N, device=DEV, generator=g) if "res" in opts else None
+    kw = dict(bias=bias, residual=res, relu="relu" in opts, want_stats="stats" in opts)
+    want = _ref(A, W, None, None, None, 1, bias, res, "relu" in opts, 0)
+    plan = ops.PlanesPlan([W])
+    (image,) = plan.run()
+    assert image is not None
+    outs = []
+    for gm, planes in ((0, None), (2, None), (2, image), (2, image)):
+        muscle_amd.set_gemm_mode(gm)
+        try:
+            assert planes is None or ops._planes_take(M, K, N)
+            out = ops.pw_fwd(A, W, N, planes=planes, **kw)
+        finally:
+            muscle_amd.set_gemm_mode(0)
+        outs.append(out)
+    if "stats" in opts:
+        assert torch.equal(outs[2][0], outs[3][0]) and torch.equal(outs[2][1], outs[3][1])
+        for _, st in outs:
+            s = st.double().sum(0)
+            assert float((s[0] - want.sum(0)).abs().max() / want.sum(0).abs().max()) <= 1e-5
+            assert float((s[1] - (want * want).sum(0)).abs().max() / (want * want).sum(0).abs().max()) <= 1e-5
+        outs = [o for o, _ in outs]
+    else:
+        assert torch.equal(outs[2], outs[3])
+    errs = [float((o.double() - want).abs().max()) for o in outs[:3]]
+    scale_ = float(want.abs().max())
+    assert errs[0] <= 2e-6 * scale_ + 1e-6, errs                 # the exact-fp32 kernel itself
+    assert errs[2] <= 1.5 * errs[0] + 2e-7 * scale_, errs        # the planes kernel is as close to fp64
+    assert errs[2] <= 1.5 * errs[1] + 2e-7 * scale_, errs        # ... and as close as the first-generation split kernel
+
+
+def test_planes_image_is_rebuilt_from_the_current_weight():
+    """The image is a function of the weight at the time of PlanesPlan.run(): after an in-place update, run() again gives the new
+    product; shapes with K % 32 != 0 have no image and stay on the first-generation kernels."""
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(5)
+    A = torch.randn(1024, 256, device=DEV, generator=g)
+    W = torch.randn(192, 256, device=DEV, generator=g)
+    W2 = torch.randn(192, 40, device=DEV, generator=g)
+    plan = ops.PlanesPlan([W, W2])
+    im, none = plan.run()
+    assert none is None and im is not None
+    muscle_amd.set_gemm_mode(1)
+    try:
+        a = ops.pw_fwd(A, W, 192, planes=im)
+        W.mul_(2.0)
+        plan.run()
+        b = ops.pw_fwd(A, W, 192, planes=im)
+    finally:
+        muscle_amd.set_gemm_mode(0)
+    assert torch.equal(b, 2.0 * a)                                # scaling by two is exact in every term
+
+
 def test_split_mode_leaves_small_shapes_on_fp32_mfma_in_mode_1():
     """mode 1 only switches the MFMA-bound shapes: a K = 48 GEMM must give bit-identical results in modes 0 and 1."""
     import muscle_amd

@@ -2,6 +2,7 @@
 // enabled and times / dissects the pointwise GEMMs on the B7 layer shapes without PyTorch.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -munsafe-fp-atomics tools/hip/gemm_lab.hip -o gpurun_out/gemm_lab
 //   gemm_lab time            per-shape time / TFLOP/s of fwd, dgrad, wgrad (production dispatch)
+//   gemm_lab planes [M K N]  first- against second-generation split kernel (time, results against each other and fp64)
 //   gemm_lab stamps M K N    per-workgroup phase shares of the forward GEMM (prologue / main loop / epilogue) and clock
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -187,7 +188,83 @@ static int run_check(int M, int K, int N) {
   return (worst_ref < 1e-3 && worst_st < 1e-4) ? 0 : 2;
 }
 
+// first-generation split kernel (mx_pw_fwd) against the second generation (mx_pw_fwd_planes: pre-split weight planes by
+// LDS-DMA, activations straight to registers, 16x16x32 MFMA) on one shape: interleaved timing in one process, results against
+// each other and against fp64
+static int run_planes(int M, int K, int N, bool check) {
+  float* A = dalloc((long)M * K, 1, 1.f); float* W = dalloc((long)N * K, 2, 0.05f);
+  float* C1 = dalloc((long)M * N, 4, 0.f); float* C2 = dalloc((long)M * N, 5, 0.f);
+  float* R = dalloc((long)M * N, 13, 1.f); float* bias = dalloc(N, 14, 1.f);
+  const int parts = mx_pw_fwd_parts(M, N, K);
+  float* st1 = dalloc((long)parts * 2 * N, 7, 0.f); float* st2 = dalloc((long)parts * 2 * N, 8, 0.f);
+  const long pb = mx_pw_planes_bytes(N, K);
+  if (pb <= 0) { printf("  M=%d K=%d N=%d: no planes for this shape\n", M, K, N); return 0; }
+  void* planes; CK(hipMalloc(&planes, pb));
+  long row[5] = {(long)W, (long)planes, N, K, 0};
+  long* table; CK(hipMalloc(&table, sizeof(row))); CK(hipMemcpy(table, row, sizeof(row), hipMemcpyHostToDevice));
+  const int tiles = mx_pw_planes_tiles(N, K);
+  float tp = time_us([&] { mx_pw_planes_batch(table, 1, tiles, nullptr); });
+  const double fl = 2.0 * M * K * N;
+  // variants: 0 gen1 | 1 gen3 128 wide | 2 gen3 64 wide | 3 gen3, the library's own choice
+  float best[4] = {1e30f, 1e30f, 1e30f, 1e30f};
+  bool extras = false;                 // timing: statistics only (the expand forward); check: bias + residual as well
+  auto run_v = [&](int v, float* Cout, float* stout) {
+    const float* b_ = extras ? bias : nullptr; const float* r_ = extras ? R : nullptr;
+    if (v == 0) { mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, Cout, M, K, N, K, N, b_, r_, 0, stout, nullptr); return; }
+    g_split_nj = v == 1 ? 2 : v == 2 ? 1 : 0;
+    mx_pw_fwd_planes(A, planes, Cout, M, K, N, K, N, b_, r_, 0, stout, nullptr);
+    g_split_nj = 0;
+  };
+  for (int round = 0; round < 3; ++round)
+    for (int v = 0; v < 4; ++v) best[v] = std::min(best[v], time_us([&] { run_v(v, v ? C2 : C1, v ? st2 : st1); }, 5));
+  printf("  M=%d K=%d N=%d: gen1 %7.1f us %5.1f TF | gen3 128w %7.1f %5.1f | gen3 64w %7.1f %5.1f | gen3 auto %7.1f %5.1f | planes %4.1f us\n", M, K, N,
+         best[0], fl / best[0] / 1e6, best[1], fl / best[1] / 1e6, best[2], fl / best[2] / 1e6, best[3], fl / best[3] / 1e6, tp);
+  fflush(stdout);
+  int rc = 0;
+  if (check) {
+    extras = true;
+    for (int v = 1; v < 3; ++v) {
+      CK(hipMemset(C2, 0xff, (size_t)M * N * 4));
+      CK(hipMemset(st2, 0xff, (size_t)parts * 2 * N * 4));
+      run_v(0, C1, st1);
+      run_v(v, C2, st2);
+      CK(hipDeviceSynchronize());
+      std::vector<float> hA((long)M * K), hW((long)N * K), hR((long)M * N), hb(N), h1((long)M * N), h2((long)M * N), s1((long)parts * 2 * N), s2((long)parts * 2 * N);
+      CK(hipMemcpy(hA.data(), A, hA.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hW.data(), W, hW.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(hR.data(), R, hR.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), bias, hb.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(h1.data(), C1, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), C2, h2.size() * 4, hipMemcpyDeviceToHost));
+      CK(hipMemcpy(s1.data(), st1, s1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(s2.data(), st2, s2.size() * 4, hipMemcpyDeviceToHost));
+      double d12 = 0, e1 = 0, e2 = 0, ds = 0;
+      for (long i = 0; i < (long)M * N; ++i) { const double d = fabs((double)h1[i] - h2[i]); if (!(d <= d12)) d12 = d; }   // (NaN-proof maximum)
+      for (long i = 0; i < (long)parts * 2 * N; ++i) { const double d = fabs((double)s1[i] - s2[i]) / (fabs((double)s1[i]) + 1.0); if (!(d <= ds)) ds = d; }
+      for (int t = 0; t < 200; ++t) {
+        const long r = t < 8 ? (t < 4 ? t : M - 1 - (t - 4)) : ((long)t * 7919 + 13) % M;
+        for (int c = 0; c < N; c += (t < 8 ? 1 : 37)) {
+          double acc = (double)hb[c] + hR[r * N + c];
+          for (int k = 0; k < K; ++k) acc += (double)hA[r * K + k] * hW[(long)c * K + k];
+          e1 = std::max(e1, fabs(acc - h1[r * N + c])); e2 = std::max(e2, fabs(acc - h2[r * N + c]));
+        }
+      }
+      const bool ok = d12 < 1e-4 && e2 < 1.5 * e1 + 1e-6 && ds < 5e-5;
+      printf("    check %s: vs gen1 max|d| %.3g; vs fp64: gen1 %.3g gen3 %.3g; statistics rel %.3g %s\n", v == 1 ? "128w" : " 64w", d12, e1, e2, ds, ok ? "" : "FAILED");
+      if (!ok) rc = 2;
+    }
+  }
+  for (float* p : {A, W, C1, C2, R, bias, st1, st2}) CK(hipFree(p));
+  CK(hipFree(planes)); CK(hipFree(table));
+  return rc;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "planes")) {
+    int rc = 0;
+    if (argc >= 5) return run_planes(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), true);
+    static const Shape sh[] = {{25088, 384, 2304}, {25088, 2304, 384}, {25088, 640, 3840}, {25088, 3840, 640}, {25088, 224, 1344},
+                               {25088, 1344, 224}, {25088, 160, 960}, {25088, 960, 160}, {6272, 384, 2304}, {6272, 2304, 384},
+                               {12544, 192, 1152}, {12544, 1152, 192}, {25000, 160, 960}, {1000, 320, 200}};
+    for (const Shape& s : sh) rc |= run_planes(s.M, s.K, s.N, s.M <= 25000 || s.K == 384);
+    return rc;
+  }
   if (argc >= 5 && !strcmp(argv[1], "check")) return run_check(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
   if (argc >= 2 && !strcmp(argv[1], "time")) { run_time(); return 0; }
   if (argc >= 5 && !strcmp(argv[1], "time1")) {      // forward GEMM of one shape (plain A, statistics)

@@ -61,6 +61,7 @@ class GemmTimer:
 
     def __init__(self):
         self.pairs = []       # (event, event, flop of the launch, ran in split arithmetic?)
+        self.calls = 0        # every mx_* entry point called while the timer is on
         self.dw = []          # (event, event, algorithmic bytes) of the fused depthwise backward: the slowest HBM-bound kernel
         self.on = False
 
@@ -84,6 +85,8 @@ class GemmTimer:
             return 2.0 * R * Co * Ci, (1 if name == "mx_pw_wgrad_tile" else -1), Co, Ci, R
 
         def timed(name, *a):
+            if me.on:
+                me.calls += 1
             if me.on and name in GEMM_CALLS:
                 flop, kind, M, N, K = shape_of(name, a)
                 split = kind == 2 or (kind >= 0 and bool(_lib.lib().mx_gemm_uses_split(kind, M, N, K)))
@@ -209,6 +212,57 @@ def short_run(model_name, batch_n, size, epoch, warm, steps, dev, seed):
             "workload": f"{model_name} {size}x{size} batch {batch_n}, epoch-{epoch} gates"}
 
 
+def short_run_dec(dev, warm=2, steps=10):
+    """BASELINE.json configs[3] on one GPU: train_muscle.py loop body (decoder mode + BEACON FieldLoss, lambda 0.05, k 128),
+    EfficientNet-B7 448x448 batch 16, last_pooling=True, synthetic soft pseudo-labels."""
+    import numpy as np
+    import muscle_amd
+    n, size = 16, 448
+    torch.manual_seed(0)
+    model = muscle_amd.MuSCLe(21, "efficientnet-b7", layers=3, last_pooling=True, mode="dec").to(dev)
+    opt = muscle_amd.FusedAdam(model.live_parameters("seg") if hasattr(model, "live_parameters") else model.parameters(), lr=1e-5, weight_decay=5e-5)
+    label = synth.synth_labels(n, 7)
+    batch = {"img": torch.from_numpy(synth.normal(7, "img", (n, 3, size, size)).astype(np.float32)).to(dev),
+             "label": torch.from_numpy(label).to(dev),
+             "mask": torch.from_numpy(synth.synth_soft_mask(label, size, 7)).to(dev)}
+    for _ in range(warm):
+        muscle_amd.muscle_step(model, opt, batch, lamb=0.05, step=7, k=128)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        muscle_amd.muscle_step(model, opt, batch, lamb=0.05, step=7, k=128)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    v = n * steps / dt
+    return {"value": v, "unit": "images/sec", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warm,
+            "ceiling_fp32_mfma": 1290.0, "frac_of_ceiling": v / 1290.0,
+            "workload": "train_muscle.py loop body (decoder + BEACON, lambda 0.05, k 128), efficientnet-b7 448x448 batch 16, last_pooling=True"}
+
+
+def short_run_infer(dev, steps=3):
+    """BASELINE.json configs[4]: infer_mcl.py's batched eval forward (cam_lr), EfficientNet-B7, batch 64, 448 / 512 / 768."""
+    import muscle_amd
+    torch.manual_seed(0)
+    model = muscle_amd.MuSCLe(21, "efficientnet-b7", layers=3, last_pooling=False).to(dev).eval()
+    model.fold_eval_bn()
+    out = {}
+    for size, ceil in ((448, 1800.0), (512, 1380.0), (768, 613.0)):
+        x = torch.randn(64, 3, size, size, device=dev)
+        with torch.no_grad():
+            model(x, cam="cam_lr")
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                model(x, cam="cam_lr")
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+        out[str(size)] = {"value": 64 / dt, "unit": "images/sec", "ms_per_batch": dt * 1e3, "steps": steps,
+                          "ceiling_fp32_mfma": ceil, "frac_of_ceiling": 64 / dt / ceil}
+        del x
+    out["workload"] = "infer_mcl.py eval forward (cam='cam_lr', BatchNorm folded), efficientnet-b7, batch 64, 448 / 512 / 768"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -313,6 +367,7 @@ def main():
     barrier()
     inst_dt = time.perf_counter() - t1
     timer.on = False
+    calls_main = timer.calls
     engine.WGRAD_SIDE_STREAM = overlap
     # Beside the contract value: the same K steps in the OTHER GEMM arithmetic (include/muscle_hip.h mx_set_gemm_mode)
     beside = None
@@ -376,10 +431,11 @@ def main():
     flops = flops_img * a.batch * inst_steps
     achieved = flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else None
     peak, split_share = timer.blended_peak()
-    traffic = None
+    traffic, tj = None, {}
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and (a.model, a.size, a.batch, full) == ("efficientnet-b7", 448, 32, False):
-        traffic = json.load(open(tpath)).get("gemm_hbm_bytes_per_launch")     # measured for this workload only
+        tj = json.load(open(tpath))
+        traffic = tj.get("gemm_hbm_bytes_per_launch")     # measured for this workload only
     res = {
         "metric": "images/sec (whole node), MCL EfficientNet-B7 448x448 bs=32/GPU" if (a.model, a.size, a.batch) == ("efficientnet-b7", 448, 32)
         else f"images/sec (whole node), MCL {a.model} {a.size}x{a.size} bs={a.batch}/GPU",
@@ -419,6 +475,11 @@ def main():
         per_gpu = imgs / dt / world
         res["roofline"]["step_frac_mfma"] = per_gpu / STEP_CEILING_MFMA_IMGS
         res["roofline"]["step_frac_hbm"] = per_gpu / STEP_CEILING_HBM_IMGS
+        # whole-step traffic and launch count from the committed PMC / kernel-trace pass of this workload (profiles/traffic.json)
+        res["roofline"]["step_traffic_GB"] = tj.get("step_traffic_GB")
+        res["roofline"]["step_traffic_algorithmic_GB"] = 6.46 * a.batch            # minimum-materialisation schedule
+        res["roofline"]["launches_per_step_all"] = tj.get("launches_per_step_all")
+        res["roofline"]["mx_calls_per_step"] = calls_main // max(inst_steps, 1)
     if beside is not None:
         res["fp32_mfma" if other == "fp32" else "split_mfma"] = beside
     dws = timer.dw_summary()
@@ -432,10 +493,15 @@ def main():
     if world == 1 and not a.no_configs and (a.model, a.size, a.batch, full) == ("efficientnet-b7", 448, 32, False):
         del model, opt, out
         torch.cuda.empty_cache()
-        res["configs"] = {
-            "config2": short_run("efficientnet-b0", 16, 448, a.epoch, 10, 50, dev, 2000),      # BASELINE.json configs[1]
-            "stepfull": short_run("efficientnet-b7", 32, 448, 12, 1, 3, dev, 1000),             # epoch >= 12 gates, headline model
-        }
+        res["configs"] = {"config2": short_run("efficientnet-b0", 16, 448, a.epoch, 10, 50, dev, 2000)}      # BASELINE.json configs[1]
+        res["configs"]["config2"].update(ceiling_hbm=6550.0, frac_of_ceiling=res["configs"]["config2"]["value"] / 6550.0)
+        torch.cuda.empty_cache()
+        res["configs"]["stepfull"] = short_run("efficientnet-b7", 32, 448, 12, 2, 10, dev, 1000)       # epoch >= 12 gates, headline model
+        torch.cuda.empty_cache()
+        res["configs"]["config4_1gpu"] = short_run_dec(dev)                                            # BASELINE.json configs[3], one GPU
+        torch.cuda.empty_cache()
+        res["configs"]["config5"] = short_run_infer(dev)                                               # BASELINE.json configs[4]
+        torch.cuda.empty_cache()
     muscle_amd.set_gemm_mode(0)
     if world == 1 and not a.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline(a.model, a.size, view, a.epoch)

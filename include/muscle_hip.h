@@ -322,7 +322,9 @@ int mx_cls_loss(int mode, const float* x, int ldx, const float* y, int ldy, floa
                 void* stream);
 
 /* image_level_contrast (loss_multilabel.py:36-66): out2 = {loss, #valid anchor rows}; gemb = d loss / d emb;
- * workspace: N*D + N floats.  N <= 64, D <= 1024. */
+ * workspace: N*D + 2*N*N + 4*N + 16 floats, 16-byte aligned.  N <= 64, D <= 1024.  The pair matrix exp(e_i . e_j / 0.1) (a dense
+ * N x N x D contraction) and the gradient's [N x N] x [N x D] product run on v_mfma_f32_16x16x4_f32 in ceil(N/16) workgroups
+ * when D % 16 == 0 (one VALU workgroup otherwise). */
 int mx_imc(const float* emb, const float* label, int N, int D, int L, float* out2, float* gemb, float* workspace, void* stream);
 
 /* cam_softmaxnorm (train_mcl.py:30-36) on NCHW [N,K,HW]; bwd != 0: out = d/dx given gy */

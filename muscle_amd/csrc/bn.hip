@@ -506,14 +506,20 @@ __global__ __launch_bounds__(256) void bn_reduce_finalize_kernel(const float* pa
 // One workgroup = 64 channels x NL sample lanes (NL = 16: 1024 threads; the kernel is latency-bound - a chain of SQ dependent
 // W1 loads per sample group - so more lanes, not more work per lane: 23.5 -> 12 us at C = 2304); gh [N][SQ] is staged in LDS.
 constexpr int B1_NL = 16;
+// STAGED = false: gh is read from global memory (batches whose [N][SQ] table outgrows 64 KB of LDS: B7 above 76 samples per
+// GPU); same sums in the same order, so the result does not depend on which variant ran.
+template <bool STAGED>
 __global__ __launch_bounds__(64 * B1_NL) void bn1_sums_finalize_kernel(const float* pooled /*[5][N][C]*/, const float* gate, const float* gh,
                                                                       const float* W1, float inv_hw, float* add, int N, int C, int SQ,
                                                                       BnBwdFin b) {
-  extern __shared__ float ghs[];                      // [N][SQ], then 2 x [NL][64] doubles
+  extern __shared__ float smem_b1[];                  // STAGED: [N][SQ], then 2 x [NL][64] doubles; else the doubles only
   const int cl = threadIdx.x & 63, nl = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  for (int i = threadIdx.x; i < N * SQ; i += 64 * B1_NL) ghs[i] = gh[i];
-  __syncthreads();
+  const float* ghs = STAGED ? smem_b1 : gh;
+  if (STAGED) {
+    for (int i = threadIdx.x; i < N * SQ; i += 64 * B1_NL) smem_b1[i] = gh[i];
+    __syncthreads();
+  }
   const long plane = (long)N * C;
   double s0 = 0.0, s1 = 0.0;
   if (c < C) {
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(64 * B1_NL) void bn1_sums_finalize_kernel(const flo
       }
     }
   }
-  double* red = reinterpret_cast<double*>(ghs + ((N * SQ + 1) & ~1));
+  double* red = reinterpret_cast<double*>(smem_b1 + (STAGED ? ((N * SQ + 1) & ~1) : 0));
   __syncthreads();
   red[nl * 64 + cl] = s0; red[B1_NL * 64 + nl * 64 + cl] = s1;
   __syncthreads();
@@ -761,11 +767,15 @@ int mx_bn1_sums_finalize(const float* pooled5, const float* gate, const float* g
                          float* dgamma, float* dbeta, float* c1, float* c2, float* c3, void* stream) {
   MX_CHECK_ARG(pooled5 && gate && gh && W1 && add && N > 0 && C > 0 && SQ > 0 && count > 0, "bn1_sums_finalize: bad args");
   MX_CHECK_ARG(gamma && mean && rstd && dgamma && dbeta && c1 && c2 && c3, "bn1_sums_finalize: null pointer");
-  const size_t shb = (size_t)((N * SQ + 1) & ~1) * sizeof(float) + 2 * B1_NL * 64 * sizeof(double);
-  MX_CHECK_ARG(shb <= 64 * 1024, "bn1_sums_finalize: N*SQ = %d too large for LDS staging", N * SQ);
+  const size_t redb = 2 * B1_NL * 64 * sizeof(double);
+  const size_t shb = (size_t)((N * SQ + 1) & ~1) * sizeof(float) + redb;
   BnBwdFin b{count, gamma, mean, rstd, training, dgamma, dbeta, c1, c2, c3};
-  hipLaunchKernelGGL(bn1_sums_finalize_kernel, dim3(cdiv(C, 64)), dim3(64 * B1_NL), shb, (hipStream_t)stream, pooled5, gate, gh, W1, inv_hw,
-                     add, N, C, SQ, b);
+  if (shb <= 64 * 1024)
+    hipLaunchKernelGGL(bn1_sums_finalize_kernel<true>, dim3(cdiv(C, 64)), dim3(64 * B1_NL), shb, (hipStream_t)stream, pooled5, gate, gh, W1,
+                       inv_hw, add, N, C, SQ, b);
+  else      // the table does not fit the default dynamic-LDS limit: read it from global memory (L2-resident, N*SQ*4 bytes)
+    hipLaunchKernelGGL(bn1_sums_finalize_kernel<false>, dim3(cdiv(C, 64)), dim3(64 * B1_NL), redb, (hipStream_t)stream, pooled5, gate, gh, W1,
+                       inv_hw, add, N, C, SQ, b);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

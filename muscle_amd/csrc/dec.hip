@@ -522,7 +522,9 @@ int mx_avgpool3s2(const float* x, float* y, int N, int H, int W, int C, int bwd,
 
 int mx_resize_nhwc_bwd(const float* gdst, float* gsrc, int N, int Hs, int Ws, int C, int Hd, int Wd, void* stream) {
   MX_CHECK_ARG(gdst && gsrc && N > 0 && Hs > 0 && Ws > 0 && Hd > 0 && Wd > 0 && C > 0, "resize_nhwc_bwd: bad args");
-  hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(gs((long)N * Hd * Wd * C)), dim3(256), 0, (hipStream_t)stream, gdst, gsrc, N, Hs,
+  MX_CHECK_ARG(C % 4 == 0 && (((uintptr_t)gdst | (uintptr_t)gsrc) & 15) == 0,
+               "resize_nhwc_bwd: C=%d must be a multiple of 4 and the tensors 16-byte aligned (the gather moves float4 channel groups)", C);
+  hipLaunchKernelGGL(resize_nhwc_bwd_kernel, dim3(gs((long)N * Hs * Ws * (C / 4))), dim3(256), 0, (hipStream_t)stream, gdst, gsrc, N, Hs,
                      Ws, C, Hd, Wd);
   MX_LAUNCH_CHECK();
   return MX_OK;

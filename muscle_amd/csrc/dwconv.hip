@@ -222,7 +222,8 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
       return;
     }
     // the groups of a sample are joined by the last workgroup to arrive, in group order (no atomics: the squeeze, and with it
-    // the whole eval forward, gives the same bits whatever the batch size and the run)
+    // the whole eval forward, gives the same bits in every run; across batch sizes only while dw_fwd_geom cuts a sample into the
+    // same groups - tiles per group follows target / N - which tests/test_gpu_determinism.py checks for the sizes it runs)
     if (own) mx_st_wt(a.poolpart + ((long)gi * a.N + n_fix) * a.C + c0 + tid, v);
     if (!mx_last_arriver(a.counters + n_fix * gridDim.y + blockIdx.y, a.gpp, &last_flag)) return;
     if (own) {
@@ -796,6 +797,7 @@ static void dw_fwd_geom(int N, int Ho, int Wo, int C, int S, bool pooled, int* t
     long per = g / N;
     if (per < 1) per = 1;
     if (per > ntile) per = ntile;
+    if ((long)N * chunks > MX_WS_COUNTERS) per = 1;      // more (sample, chunk) pairs than arrival counters: one group per sample, no hand-off
     *tpb = cdiv(ntile, per);
     *gpp = cdiv(ntile, *tpb);
     *groups = N * (*gpp);

@@ -189,6 +189,194 @@ __global__ __launch_bounds__(1024) void imc_kernel(const float* emb, const float
 }
 
 // ---------------------------------------------------------------------------
+// IMC on the matrix cores (round 4; loss_multilabel.py:36-66: s = exp(e_i . e_j / 0.1) over all pairs is the dense
+// N x N x D contraction E E^T).  Two launches of ceil(N/16) workgroups, one per block of 16 anchor rows:
+//   imc_gram_kernel: row norms; wave w computes the 16 x 16 tile (block, w) of emb emb^T on v_mfma_f32_16x16x4_f32 (one
+//     16-byte load per operand, lane and four MFMAs); epilogue in registers: cosine, exp, the P / G pair masks from the
+//     labels, the four row sums over j > i (DPP row reduction, then the waves' shares added in wave order), per-row loss and
+//     its two derivatives.  Leaves s, the masks, the normalised embeddings of its rows and the per-row terms in the workspace.
+//   imc_grad_kernel: g_e[i] = sum_j Wsym[i][j] e_j as a second MFMA product ([16 x N] x [N x D], the tiles of a row block
+//     spread over the four waves, kept in registers), then back through the normalisation; workgroup 0 adds the blocks' losses
+//     in block order.
+// Every sum has a fixed order: bit-reproducible.  D % 16 == 0 (else the one-workgroup kernel above runs).
+// workspace (floats): E [N][D] | nrm [N] | S [N][N] | F [N][N] | k1 [N] | k2 [N] | block loss, valid [2][4]
+// ---------------------------------------------------------------------------
+typedef float lf32x4 __attribute__((ext_vector_type(4)));
+static __device__ __forceinline__ float imc_row16_sum(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xf, 0xf, false));   // row_ror:8
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xf, 0xf, false));   // row_ror:4
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x122, 0xf, 0xf, false));   // row_ror:2
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x121, 0xf, 0xf, false));   // row_ror:1
+  return v;
+}
+
+struct ImcWs { float *E, *nrm, *S, *F, *k1, *k2, *blk; };
+static __host__ __device__ __forceinline__ ImcWs imc_ws(float* ws, int N, int D) {
+  ImcWs w;
+  w.E = ws; w.nrm = w.E + (long)N * D; w.S = w.nrm + N; w.F = w.S + N * N; w.k1 = w.F + N * N; w.k2 = w.k1 + N; w.blk = w.k2 + N;
+  return w;
+}
+
+__global__ __launch_bounds__(256) void imc_gram_kernel(const float* __restrict__ emb, const float* __restrict__ label, int N, int D, int L,
+                                                       float* ws) {
+  __shared__ float nrm_s[IMC_MAXN];
+  __shared__ float lab_s[IMC_MAXN * 32];
+  __shared__ float rs[4][16][4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int i0 = blockIdx.x * 16;
+  const ImcWs w = imc_ws(ws, N, D);
+  for (int i = tid; i < N * L; i += 256) lab_s[(i / L) * 32 + i % L] = label[i];
+  for (int i = wave; i < N; i += 4) {
+    float s = 0.f;
+    for (int d = 4 * lane; d < D; d += 256) { const float4 v = ld4(emb + (long)i * D + d); s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w; }
+    s = sqrtf(wave_sum(s));
+    if (lane == 0) nrm_s[i] = s;
+    if (i >= i0 && i < i0 + 16) {
+      const float dn = fmaxf(s, 1e-6f);
+      for (int d = 4 * lane; d < D; d += 256) {
+        float4 v = ld4(emb + (long)i * D + d);
+        v.x /= dn; v.y /= dn; v.z /= dn; v.w /= dn;
+        st4(w.E + (long)i * D + d, v);
+      }
+      if (lane == 0) w.nrm[i] = s;
+    }
+  }
+  __syncthreads();
+  float sp[4] = {0.f, 0.f, 0.f, 0.f}, sn[4] = {0.f, 0.f, 0.f, 0.f}, vp[4] = {0.f, 0.f, 0.f, 0.f}, vn[4] = {0.f, 0.f, 0.f, 0.f};
+  if (16 * wave < N) {
+    const int ra = min(i0 + l15, N - 1), rb = min(16 * wave + l15, N - 1);
+    const float* pa = emb + (long)ra * D + 4 * g;
+    const float* pb = emb + (long)rb * D + 4 * g;
+    lf32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int k = 0; k < D; k += 16) {
+      const float4 a4 = ld4(pa + k), b4 = ld4(pb + k);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, b4.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, b4.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, b4.w, acc, 0, 0, 0);
+    }
+    const int j = 16 * wave + l15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = i0 + 4 * g + r;                            // acc[r] = emb_i . emb_j
+      if (i < N && j < N) {
+        const float cosv = acc[r] / (fmaxf(nrm_s[i], 1e-6f) * fmaxf(nrm_s[j], 1e-6f));
+        const float s = __expf(cosv / 0.1f);
+        int same = 1, inter = 0;
+        for (int c = 0; c < L; ++c) {
+          const float a = lab_s[i * 32 + c], b = lab_s[j * 32 + c];
+          if (a != b) same = 0;
+          inter += ((long)a & (long)b) ? 1 : 0;
+        }
+        const int P = same, G = inter == 0;
+        w.S[i * N + j] = s;
+        w.F[i * N + j] = (float)(P | (G << 1));
+        if (j > i) {
+          if (P) { sp[r] += s; vp[r] += 1.f; }
+          if (G) { sn[r] += s; vn[r] += 1.f; }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float a = imc_row16_sum(sp[r]), b = imc_row16_sum(sn[r]), c = imc_row16_sum(vp[r]), d = imc_row16_sum(vn[r]);
+    if (l15 == 0) { rs[wave][4 * g + r][0] = a; rs[wave][4 * g + r][1] = b; rs[wave][4 * g + r][2] = c; rs[wave][4 * g + r][3] = d; }
+  }
+  __syncthreads();
+  __shared__ float rl[16], rv[16];
+  if (tid < 16) {
+    const int i = i0 + tid;
+    float a = 1e-6f, b = 1e-6f, c = 0.f, d = 0.f;
+    for (int wv = 0; wv < 4; ++wv) { a += rs[wv][tid][0]; b += rs[wv][tid][1]; c += rs[wv][tid][2]; d += rs[wv][tid][3]; }
+    const bool valid = i < N && c >= 1.f && d >= 1.f && d > c;
+    rl[tid] = valid ? -logf(a / (a + b)) / N : 0.f;
+    rv[tid] = valid ? 1.f : 0.f;
+    if (i < N) {
+      w.k1[i] = valid ? (-1.f / a + 1.f / (a + b)) / N : 0.f;   // d loss / d sp
+      w.k2[i] = valid ? (1.f / (a + b)) / N : 0.f;              // d loss / d sn
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float l = 0.f, v = 0.f;
+    for (int t = 0; t < 16; ++t) { l += rl[t]; v += rv[t]; }
+    w.blk[blockIdx.x] = l; w.blk[4 + blockIdx.x] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void imc_grad_kernel(int N, int D, float* ws, float* __restrict__ out, float* __restrict__ gemb) {
+  __shared__ float Wm[16][IMC_MAXN + 4];
+  __shared__ float k1s[IMC_MAXN], k2s[IMC_MAXN];
+  __shared__ float dg[4][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
+  const int i0 = blockIdx.x * 16, NB = gridDim.x;
+  const ImcWs w = imc_ws(ws, N, D);
+  if (blockIdx.x == 0 && tid == 0) {
+    float l = 0.f, v = 0.f;
+    for (int b = 0; b < NB; ++b) { l += w.blk[b]; v += w.blk[4 + b]; }
+    out[0] = l; out[1] = v;
+  }
+  if (tid < N) { k1s[tid] = w.k1[tid]; k2s[tid] = w.k2[tid]; }
+  __syncthreads();
+  const int Np = (N + 3) & ~3;
+  for (int p = tid; p < 16 * IMC_MAXN; p += 256) {
+    const int r = p / IMC_MAXN, j = p % IMC_MAXN, i = i0 + r;
+    float v = 0.f;
+    if (i < N && j < N && j != i) {
+      const int f = (int)w.F[i * N + j], mn = min(i, j);
+      v = ((f & 1 ? k1s[mn] : 0.f) + (f & 2 ? k2s[mn] : 0.f)) * w.S[i * N + j] / 0.1f;
+    }
+    Wm[r][j] = v;
+  }
+  __syncthreads();
+  // g_e tiles of this wave: columns 16 t .. 16 t + 15 for t = wave, wave + 4, ...; acc[r] = g_e[i0 + 4 g + r][16 t + l15]
+  constexpr int MAXT = 1024 / 16 / 4;
+  lf32x4 acc[MAXT];
+  const int nt = D / 16;
+  float dot[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < MAXT; ++u) {
+    acc[u] = lf32x4{0.f, 0.f, 0.f, 0.f};
+    const int t = wave + 4 * u;
+    if (t < nt) {
+      for (int k = 0; k < Np; k += 4) {
+        const int j = min(k + g, N - 1);                          // Wm is zero beyond N
+        acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(Wm[l15][k + g], w.E[(long)j * D + 16 * t + l15], acc[u], 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = min(i0 + 4 * g + r, N - 1);
+        dot[r] += acc[u][r] * w.E[(long)i * D + 16 * t + l15];
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float a = imc_row16_sum(dot[r]);
+    if (l15 == 0) dg[wave][4 * g + r] = a;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int rr = 4 * g + r, i = i0 + rr;
+    if (i >= N) continue;
+    const float dotge = dg[0][rr] + dg[1][rr] + dg[2][rr] + dg[3][rr];
+    const float s = w.nrm[i];
+#pragma unroll
+    for (int u = 0; u < MAXT; ++u) {
+      const int t = wave + 4 * u;
+      if (t < nt) {
+        const int d = 16 * t + l15;
+        const float ge = acc[u][r];
+        gemb[(long)i * D + d] = (s > 1e-6f) ? (ge - w.E[(long)i * D + d] * dotge) / s : ge / 1e-6f;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
 // cam_softmaxnorm (train_mcl.py:30-36) on NCHW [N, K, H, W]: fg = softmax over channels 1..K-1,
 // bg = 1 - max fg.  One thread per pixel; channel reads are plane-strided, x-contiguous.
 // ---------------------------------------------------------------------------
@@ -430,7 +618,15 @@ int mx_cls_loss(int mode, const float* x, int ldx, const float* y, int ldy, floa
 int mx_imc(const float* emb, const float* label, int N, int D, int L, float* out2, float* gemb, float* workspace, void* stream) {
   MX_CHECK_ARG(emb && label && out2 && gemb && workspace, "imc: null pointer");
   MX_CHECK_ARG(N > 0 && N <= IMC_MAXN && D > 0 && D <= 1024 && L > 0, "imc: N=%d (<=64) D=%d (<=1024) L=%d", N, D, L);
-  hipLaunchKernelGGL(imc_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, emb, label, N, D, L, out2, gemb, workspace);
+  static const int mfma = getenv("MX_IMC_MFMA") ? atoi(getenv("MX_IMC_MFMA")) : 1;
+  if (mfma && D % 16 == 0 && L <= 32 && (((uintptr_t)emb | (uintptr_t)workspace) & 15) == 0) {
+    const int nb = cdiv(N, 16);
+    hipLaunchKernelGGL(imc_gram_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, emb, label, N, D, L, workspace);
+    MX_LAUNCH_CHECK();
+    hipLaunchKernelGGL(imc_grad_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, N, D, workspace, out2, gemb);
+  } else {
+    hipLaunchKernelGGL(imc_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, emb, label, N, D, L, out2, gemb, workspace);
+  }
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

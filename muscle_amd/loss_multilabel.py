@@ -95,7 +95,7 @@ class _IMC(torch.autograd.Function):
         N, D = emb.shape
         out = torch.empty(2, dtype=torch.float32, device=emb.device)
         gemb = torch.empty_like(emb)
-        ws = torch.empty(N * D + N, dtype=torch.float32, device=emb.device)
+        ws = torch.empty(N * D + 2 * N * N + 4 * N + 16, dtype=torch.float32, device=emb.device)
         call("mx_imc", ptr(emb), ptr(label), N, D, label.shape[1], ptr(out), ptr(gemb), ptr(ws), stream())
         ctx.save_for_backward(gemb)
         ctx.mark_non_differentiable(out)

@@ -48,6 +48,20 @@ def _scratch(device, nbytes):
     return buf.data_ptr(), buf.numel()
 
 
+def _call_ws(name, *args):
+    """call() for the entry points whose scratch starts with arrival counters that every launch leaves at zero: if the call fails
+    (an argument error before the launch, or a launch error), the counters of this stream's scratch are re-zeroed, so a failed
+    call cannot poison the ordered reductions that use the buffer next."""
+    try:
+        call(name, *args)
+    except Exception:
+        key = (torch.cuda.current_device(), stream())
+        buf = _scratch_bufs.get(key)
+        if buf is not None:
+            buf[:65536].zero_()
+        raise
+
+
 # ---- GEMMs ------------------------------------------------------------------------------------
 _uses_planes: dict = {}
 
@@ -415,7 +429,7 @@ def se_bn1_pool(dA2d, X2d, st: BNState, rows_per_sample):
     N = rows // rows_per_sample
     out = _f32(5, N, C, device=X2d.device)
     ws, wsn = _scratch(X2d.device, lib().mx_pool_ws(rows, C, rows_per_sample, 5))
-    call("mx_se_bn1_pool", ptr(dA2d), ptr(X2d), ptr(st.scale), ptr(st.shift), rows, C, rows_per_sample, ptr(out), ws, wsn, stream())
+    _call_ws("mx_se_bn1_pool", ptr(dA2d), ptr(X2d), ptr(st.scale), ptr(st.shift), rows, C, rows_per_sample, ptr(out), ws, wsn, stream())
     return out
 
 
@@ -436,8 +450,8 @@ def pool_sum(X2d, rows_per_sample, *, G=None, st: Optional[BNState] = None, act=
     rows, C = X2d.shape
     out = _f32(rows // rows_per_sample, C, device=X2d.device)
     ws, wsn = _scratch(X2d.device, lib().mx_pool_ws(rows, C, rows_per_sample, 1))
-    call("mx_pool_sum", ptr(X2d), ptr(G), ptr(st.scale) if st else None, ptr(st.shift) if st else None, int(act), rows, C,
-         rows_per_sample, ptr(out), ws, wsn, stream())
+    _call_ws("mx_pool_sum", ptr(X2d), ptr(G), ptr(st.scale) if st else None, ptr(st.shift) if st else None, int(act), rows, C,
+             rows_per_sample, ptr(out), ws, wsn, stream())
     return out
 
 
@@ -449,9 +463,9 @@ def dwconv_fwd(X, W, K, S, pad_lo, Ho, Wo, *, st: Optional[BNState] = None, want
     stats = _f32(lib().mx_dwconv_fwd_parts(N, Ho, Wo, C, S), 2, C, device=X.device) if want_stats else None
     pooled = _f32(N, C, device=X.device) if pool is not None else None
     ws, wsn = _scratch(X.device, lib().mx_dwconv_fwd_ws(N, Ho, Wo, C, S)) if pool is not None else (None, 0)
-    call("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),
-         ptr(pool[0]) if pool is not None else None, ptr(pool[1]) if pool is not None else None, ptr(pooled), ws, wsn,
-         N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
+    _call_ws("mx_dwconv_fwd", ptr(X), ptr(st.scale) if st else None, ptr(st.shift) if st else None, ptr(W), ptr(Y), ptr(stats),
+             ptr(pool[0]) if pool is not None else None, ptr(pool[1]) if pool is not None else None, ptr(pooled), ws, wsn,
+             N, H, Wd, C, K, S, pad_lo, Ho, Wo, stream())
     if pool is not None:
         return Y, pooled
     return (Y, stats) if want_stats else Y

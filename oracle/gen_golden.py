@@ -775,6 +775,13 @@ def main_config2(src, tree):
     gen_step(src, tree, "efficientnet-b0", 4, 448, 224, 4, 5, "step_b0_448_ep4.npz", cam_stride=16)
 
 
+def main_config1(src, tree):
+    """BASELINE.json configs[0]: train_mcl.py on EfficientNet-B0, 2 synthetic 224x224 images, 21 classes, one step - the
+    reference's own loop body at exactly that shape (epoch-4 gates; with two images IMC has no qualifying anchor row and
+    returns the Python float 0.0, train_mcl.py:194 skips it)."""
+    gen_step(src, tree, "efficientnet-b0", 2, 224, 112, 4, 7, "step_b0_224_n2_ep4.npz", cam_stride=8)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
@@ -800,6 +807,7 @@ def main():
     gen_eval_units(src)
     main_fullsize(src, tree)
     main_config2(src, tree)
+    main_config1(src, tree)
     gen_input_units(src)
 
 
@@ -809,6 +817,9 @@ if __name__ == "__main__":
     elif "--config2" in sys.argv:
         torch.set_num_threads(8)
         main_config2(load_reference(), train_script_ast())
+    elif "--config1" in sys.argv:
+        torch.set_num_threads(8)
+        main_config1(load_reference(), train_script_ast())
     elif "--fullsize" in sys.argv:
         torch.set_num_threads(8)
         main_fullsize(load_reference(), train_script_ast())

@@ -19,6 +19,22 @@ from test_gpu_model import build, close, DEV, T, test_mcl_step_phase1_golden as 
 
 pytestmark = [pytest.mark.gpu, pytest.mark.both_arith]
 FIX = "step_b0_448_ep4.npz"
+FIX1 = "step_b0_224_n2_ep4.npz"          # BASELINE.json configs[0]: B0, 2 images, 224x224, one step (oracle/gen_golden.py --config1)
+
+
+def test_config1_b0_224_n2_train_forward_vs_reference():
+    """configs[0]'s own shape on the GPU: the reference's loop body on EfficientNet-B0, 2 synthetic 224x224 images, 21 classes
+    (train_mcl.py:153-199) - forward tensors against the fixture."""
+    _forward_vs_reference(FIX1)
+
+
+@pytest.mark.parametrize("imc_sync", [False, True])
+def test_config1_b0_224_n2_step_vs_reference(imc_sync):
+    """... and the whole step: seven loss terms (IMC falls through to the Python float 0.0 with two images), gradient summaries, the
+    set of grad-less parameters, the Adam update, BatchNorm buffers."""
+    G = gu.load(FIX1)
+    assert not bool(G["loss_is_tensor"][0]) and float(G["losses"][4]) == 0.0
+    _step_vs_reference(FIX1, imc_sync)
 
 
 def test_b0_448_train_forward_vs_reference():

@@ -137,3 +137,40 @@ def test_decoder_step_is_bit_reproducible():
                      torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()))
     for tag, x, y in zip(("losses + norm", "gradient arena", "parameters"), *runs):
         assert np.array_equal(x, y), (tag, float(np.abs(x.astype(np.float64) - y.astype(np.float64)).max()))
+
+
+@pytest.mark.parametrize("n,hw,c", [(8, 112 * 112, 288), (4, 224 * 224, 32), (2, 56 * 56, 480)])
+def test_ordered_pooled_sums_multi_block_join_under_load(n, hw, c):
+    """The "last arriver finishes" hand-off of the per-sample reductions (csrc/common.h mx_last_arriver: write-through partials,
+    one agent-scope counter add per workgroup, one acquire in the last one) at shapes where a sample IS cut into several row
+    blocks (mx_pool_ws > 0 - the 64-96 px step tests mostly are not), with a second stream keeping the chip and the L2s busy:
+    pool_sum and se_bn1_pool must give the same bits in every run, equal a float64 reference to fp32 round-off, and leave the
+    arrival counters at zero."""
+    from muscle_amd import ops
+    from muscle_amd._lib import lib
+    rows = n * hw
+    assert lib().mx_pool_ws(rows, c, hw, 1) > 0 and lib().mx_pool_ws(rows, c, hw, 5) > 0        # several row blocks per sample
+    g = torch.Generator(device=DEV).manual_seed(n + c)
+    X = torch.randn(rows, c, device=DEV, generator=g)
+    dA = torch.randn(rows, c, device=DEV, generator=g)
+    st = ops.BNState(torch.rand(c, device=DEV, generator=g) + 0.5, torch.randn(c, device=DEV, generator=g) * 0.2, None, None)
+    side = torch.cuda.Stream()
+    junk = torch.randn(64 << 20, device=DEV)
+    outs = []
+    for rep in range(4):
+        if rep % 2:
+            with torch.cuda.stream(side):
+                for _ in range(30):
+                    junk = junk * 1.0001 + 0.5
+        p1 = ops.pool_sum(X, hw, st=st, act=True)
+        p5 = ops.se_bn1_pool(dA, X, st, hw)
+        torch.cuda.synchronize()
+        outs.append((p1.clone(), p5.clone()))
+    for p1, p5 in outs[1:]:
+        assert torch.equal(p1, outs[0][0]) and torch.equal(p5, outs[0][1])
+    z = X.double() * st.scale.double() + st.shift.double()
+    want = (z * torch.sigmoid(z)).view(n, hw, c).sum(1)
+    err = float((outs[0][0].double() - want).abs().max() / want.abs().max())
+    assert err <= 2e-6, err
+    for key, buf in ops._scratch_bufs.items():
+        assert int(buf[:65536].view(torch.int32).abs().sum()) == 0, key          # every launch leaves its counters at zero

@@ -50,3 +50,34 @@ def test_two_ranks_same_batch_reproduce_single_process_update(tmp_path, backend)
     # parameters: Adam's first update is lr * sign(g): identical except where a round-off gradient changes sign
     d = np.abs(r0["params"].astype(np.float64) - single["params"].astype(np.float64))
     assert d.max() <= 2.05e-4 and (d > 1e-6).mean() < 0.02, (d.max(), (d > 1e-6).mean())
+
+
+def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed with both ranks on
+    the one GPU of the box and the exchange over gloo (MUSCLE_DIST_BACKEND / MUSCLE_SHARE_GPU): the N > 1 flow of bench.py at
+    HEAD - barriers, MAX over ranks of both arithmetic legs, rank 0 printing ONE JSON line - must keep working while no
+    multi-GPU node is available to run it for real.  The launcher is a fresh child started before this process... it touches
+    no GPU itself."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MUSCLE_DIST_BACKEND="gloo", MUSCLE_SHARE_GPU="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--model", "efficientnet-b3", "--batch", "8", "--size", "224"]
+    r = subprocess.run(cmd, env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 16
+    assert "fp32_mfma" in d and d["fp32_mfma"]["value"] > 0            # the other arithmetic's leg ran with WORLD_SIZE = 2 as well
+    assert d["roofline"]["achieved"] > 0

@@ -126,6 +126,30 @@ def test_imc_golden():
     assert float(ln) == 0.0 and float(info[1]) == 0.0
 
 
+@pytest.mark.parametrize("n,d", [(32, 640), (37, 320), (64, 1024), (16, 48), (7, 36)])
+def test_imc_mfma_vs_oracle(n, d):
+    """IMC at the headline size (32 x 640: E E^T and the gradient's second product on v_mfma_f32_16x16x4_f32, one workgroup per
+    16 anchor rows) and on ragged / maximal shapes, against the oracle's closed form (loss_multilabel.py:36-66) incl. its
+    gradient; (7, 36) takes the one-workgroup kernel (D % 16 != 0).  Bit-identical from run to run."""
+    import muscle_amd as M
+    from oracle import mcl_oracle as O
+    emb = T(synth.normal(SEED + n, "imc.big", (n, d)).astype(np.float32))
+    lab = T(synth.synth_labels(n, SEED + d))
+    lab[n // 2] = lab[0]                                   # at least one identical-label pair
+    e_ref = emb.clone().requires_grad_()
+    want = O.image_level_contrast(e_ref, lab)
+    assert torch.is_tensor(want)
+    want.backward()
+    outs = []
+    for _ in range(2):
+        e = emb.to(DEV).requires_grad_()
+        li = M.image_level_contrast(e, lab.to(DEV))
+        li.backward()
+        outs.append((li.detach().clone(), e.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    close(outs[0][0], want.detach().numpy(), 2e-5); close(outs[0][1], e_ref.grad.numpy(), 5e-5)
+
+
 def test_softmaxnorm_golden():
     import muscle_amd as M
     cam = T(synth.normal(SEED, "cam", (2, 21, 9, 11)).astype(np.float32)).to(DEV).requires_grad_()

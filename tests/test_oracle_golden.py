@@ -192,7 +192,9 @@ def test_forward_eval_b7(fname):
 STEP_FILES = ["step_b0_ep0.npz", "step_b0_ep4.npz", "step_b0_ep4_imc0.npz", "step_b0_ep12.npz",
               "step_b0_ep12_lr0.npz", "step_b3_ep12.npz", "step_b3_ep12_lr0.npz", "step_b7_ep4.npz",
               # the headline size (B7, 448x448 image, 224x224 views): pins the oracle where bench.py times it
-              "step_b7_448_ep4.npz", "step_b7_448_ep12_lr0.npz"]
+              "step_b7_448_ep4.npz", "step_b7_448_ep12_lr0.npz",
+              # BASELINE.json configs[0]: B0, 2 images, 224x224 (the cpu_baseline.config1 workload)
+              "step_b0_224_n2_ep4.npz"]
 
 
 @pytest.mark.parametrize("fname", STEP_FILES)

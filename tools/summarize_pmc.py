@@ -29,16 +29,19 @@ def family(n):
         return "gemm_kernel<%s>" % {"0": "NT fwd", "1": "NN dgrad", "2": "TN wgrad"}[m.group(1)]
     if n.startswith("gemm_nt_kernel"):
         return "gemm_nt_kernel<NT fwd + dgrad>"
+    if n.startswith("gemm_nt_split3_kernel"):
+        return "gemm_nt_split3_kernel<NT fwd + dgrad, split arithmetic, weight planes>"
     if n.startswith("gemm_nt_split_kernel"):
         return "gemm_nt_split_kernel<NT fwd + dgrad, split arithmetic>"
     if n.startswith("dw_bwd_fused_kernel"):
         return "dw_bwd_fused_kernel<%s>" % re.match(r"dw_bwd_fused_kernel<(\d)", n).group(1)
     return re.sub(r"<.*", "", n)
 
-GEMM_FAMILIES = ("gemm_kernel", "gemm_nt_kernel", "gemm_nt_split_kernel", "wgrad_small_kernel", "wgrad_tile_kernel", "wgrad_split_kernel")
+GEMM_FAMILIES = ("gemm_kernel", "gemm_nt_kernel", "gemm_nt_split_kernel", "gemm_nt_split3_kernel", "wgrad_small_kernel", "wgrad_tile_kernel", "wgrad_split_kernel")
 GEMM_AUX = ("wgrad_parts_reduce_kernel",)      # bytes belong to the weight-gradient GEMMs, launches are not counted
 
 dirs = dict(a.split("=") for a in sys.argv[2:])
+steps_profiled = int(dirs.pop("steps", "0"))        # steps=N: the passes cover N whole steps -> whole-step traffic and launch count
 res = {}
 fetch, cf = load(dirs["fetch"]); write, _ = load(dirs["write"]); mfma, cm = load(dirs["mfma"])
 for fam in sorted(cf, key=lambda f: -fetch[f]["_dur"]):
@@ -63,7 +66,13 @@ gl = sum(cf[f] for f in cf if f.startswith(GEMM_FAMILIES))
 gb = sum(2.0 * fetch[f].get("FETCH_SIZE", 0.0) * 1024 + write[f].get("WRITE_SIZE", 0.0) * 1024 for f in cf if f.startswith(GEMM_FAMILIES + GEMM_AUX))
 if len(sys.argv) > 1 and gl:
     tp = os.path.join(os.path.dirname(sys.argv[1]), "traffic.json")
-    json.dump({"source": "tools/summarize_pmc.py over the three --pmc passes named in " + os.path.basename(sys.argv[1]),
+    extra = {}
+    if steps_profiled > 0:
+        tot = sum(2.0 * fetch[f].get("FETCH_SIZE", 0.0) * 1024 + write[f].get("WRITE_SIZE", 0.0) * 1024 for f in cf)
+        extra = {"steps_profiled": steps_profiled, "step_traffic_GB": tot / steps_profiled / 1e9,
+                 "launches_per_step_all": sum(cf.values()) / steps_profiled,
+                 "step_traffic_is": "sum over ALL kernels of 2 x FETCH_SIZE + WRITE_SIZE (memory-side of L2: Infinity-Cache hits included) per step"}
+    json.dump({"source": "tools/summarize_pmc.py over the three --pmc passes named in " + os.path.basename(sys.argv[1]), **extra,
                "gemm_launches_profiled": gl, "gemm_hbm_bytes_per_launch": gb / gl,
                "per_family_MB_per_launch": {f: {"read": res[f]["read_MB_per_launch"], "write": res[f]["write_MB_per_launch"], "mfma_util": res[f]["mfma_util"]}
                                             for f in res if f.startswith(GEMM_FAMILIES)}}, open(tp, "w"), indent=1)

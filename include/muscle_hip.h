@@ -92,6 +92,17 @@ int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, 
 int mx_pw_dgrad_bnbwd(const float* G, const float* X, const float* coef, const float* Wt, float* dX, float* dZ, int M, int K, int N,
                       int ldg, int ldx, const float* residual, void* stream);
 
+/* The BatchNorm-0 backward apply dZ = c1*G + c2*X + c3 (model.py:45 backward; coef = [3][K] as mx_bn_bwd_finalize leaves it) folded into
+ * BOTH consumers of dZ in split arithmetic, so that dZ is never written (round 4):
+ *   mx_pw_dgrad_bnbwd_planes: dX[M,N] = dZ[M,K] * Wt[N,K]^T (+residual), Wt given as its pre-split image (mx_pw_planes_batch);
+ *   mx_pw_wgrad_tile_bnbwd:   dW[Co,Ci] += dZ[R,Co]^T X[R,Ci] (G, G2 = the BatchNorm input, [R, ldg]); scratch = mx_pw_wgrad_tile_ws(R,Co,Ci,0);
+ *                             shapes: mx_pw_wgrad_tile_bnbwd_ok (1 = the split-arithmetic tiled kernel takes it in the current mode). */
+int mx_pw_dgrad_bnbwd_planes(const float* G, const float* X, const float* coef, const void* WtPlanes, float* dX, int M, int K, int N,
+                             int ldg, int ldx, const float* residual, void* stream);
+int mx_pw_wgrad_tile_bnbwd_ok(int R, int Co, int Ci);
+int mx_pw_wgrad_tile_bnbwd(const float* G, const float* G2, const float* coef, const float* X, float* dW, int R, int Co, int Ci,
+                           int ldg, int ldx, void* ws, long ws_bytes, void* stream);
+
 /* dW[Co,Ci] += G[R,Co]^T * X'[R,Ci]: weight gradient, general kernel (the shapes the two below do not take).  The R pixel
  * rows are split into slices; with more than one slice each adds into its own partial matrix in `ws` (mx_pw_wgrad_ws bytes)
  * and the partial matrices are added to dW in slice order. */

@@ -990,8 +990,13 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const long* __restric
   *reinterpret_cast<uint4*>(d + 2 * ps) = make_uint4(l[0], l[1], l[2], l[3]);
 }
 
-template <int TN>
-__global__ __launch_bounds__(256, 3) void gemm_nt_split3_kernel(GemmArgs g) {
+// AMODE = MX_BNBWD: the A operand is the BatchNorm backward apply dZ = c1*G + c2*X + c3 (per channel k) formed in registers from
+// TWO tensors as the lane loads its fragments (g.a.p = G, g.a.rowp = X, same leading dimension; g.a.c1 = the [3][K] coefficient
+// table): the expand convolution's data gradient reads (G, e_raw) instead of a materialised dZ, and the 2R + 1W pass that wrote
+// dZ is gone (the weight gradient takes the same prologue on its G operand, wgrad.hip).  Costs 4 more activation loads, 6
+// L1-resident coefficient loads and 32 FMAs per lane and K step; the kernel then runs two workgroups per CU.
+template <int TN, int AMODE>
+__global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 16 * TN;
   constexpr int W_PLANE = BN * 64, STAGE = 3 * W_PLANE;
   constexpr int WPIECES = 3 * BN / 16, WPW = WPIECES / 4;
@@ -1036,11 +1041,24 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_split3_kernel(GemmArgs g) {
     for (int i = 0; i < WPW; ++i) glds16(wsrc[i] + 3 * npad64 * kt, st + wdst[i]);
   };
   f32x4 raw[2][2];
+  f32x4 rawx[AMODE == MX_BNBWD ? 2 : 1][2], cf[AMODE == MX_BNBWD ? 3 : 1][2];
+  const long xoff = AMODE == MX_BNBWD ? (g.a.rowp + zb * g.sa) - A : 0;      // X[r][k] sits xoff floats from G[r][k]
   auto load_a = [&](int kt) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       raw[i][0] = *reinterpret_cast<const f32x4*>(ap[i] + 32 * kt);
       raw[i][1] = *reinterpret_cast<const f32x4*>(ap[i] + 32 * kt + 16);
+      if (AMODE == MX_BNBWD) {
+        rawx[AMODE == MX_BNBWD ? i : 0][0] = *reinterpret_cast<const f32x4*>(ap[i] + xoff + 32 * kt);
+        rawx[AMODE == MX_BNBWD ? i : 0][1] = *reinterpret_cast<const f32x4*>(ap[i] + xoff + 32 * kt + 16);
+      }
+    }
+    if (AMODE == MX_BNBWD) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        cf[AMODE == MX_BNBWD ? c : 0][0] = *reinterpret_cast<const f32x4*>(g.a.c1 + (long)c * g.K + 32 * kt + 4 * q);
+        cf[AMODE == MX_BNBWD ? c : 0][1] = *reinterpret_cast<const f32x4*>(g.a.c1 + (long)c * g.K + 32 * kt + 4 * q + 16);
+      }
     }
   };
 
@@ -1059,6 +1077,14 @@ __global__ __launch_bounds__(256, 3) void gemm_nt_split3_kernel(GemmArgs g) {
     bf16x8 af[2][3];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      if (AMODE == MX_BNBWD) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            raw[i][u][e] = cf[0][u][e] * raw[i][u][e] + (cf[AMODE == MX_BNBWD ? 1 : 0][u][e] * rawx[AMODE == MX_BNBWD ? i : 0][u][e] +
+                                                         cf[AMODE == MX_BNBWD ? 2 : 0][u][e]);
+      }
       unsigned h[4], m[4], l[4];
       split3_pair(raw[i][0][0], raw[i][0][1], h[0], m[0], l[0]);
       split3_pair(raw[i][0][2], raw[i][0][3], h[1], m[1], l[1]);
@@ -1155,7 +1181,8 @@ static void launch_nt_split3_t(const GemmArgs& g, int batch, hipStream_t st) {
   a.xcd_nt = 0;
   dim3 grid(mt, nt, batch);
   if (nt >= 2 && nt <= 16 && mt >= 64) { a.xcd_nt = nt; grid = dim3(8 * cdiv(mt, 8) * nt, 1, batch); }
-  hipLaunchKernelGGL((gemm_nt_split3_kernel<TN>), grid, dim3(256), 0, st, a);
+  if (g.a.mode == MX_BNBWD) hipLaunchKernelGGL((gemm_nt_split3_kernel<TN, MX_BNBWD>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_nt_split3_kernel<TN, MX_PLAIN>), grid, dim3(256), 0, st, a);
 }
 
 // 128 x 128 or 128 x 64.  Tiles are dealt over 256 CUs: time ~ (tiles per CU + half a tile of tail) x tile width, the 64-wide
@@ -1408,6 +1435,24 @@ int mx_pw_fwd_planes(const float* A, const void* Wplanes, float* C, int M, int K
   g.b = MxOperand{reinterpret_cast<const float*>(Wplanes), nullptr, nullptr, nullptr, MX_PLAIN, 1};
   g.c = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = (N + 127) & ~127; g.ldc = ldc;
   g.bias = bias; g.residual = residual; g.relu = relu; g.stats = stats;
+  launch_nt_split3(g, 1, (hipStream_t)stream);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// dX[M,N] = dZ[M,K] * Wt[N,K]^T (+ residual) with dZ = c1*G + c2*X + c3 (coef = [3][K], as mx_bn_bwd_finalize leaves it) formed in
+// the operand load of the second-generation split kernel from G and X [M, ldg]; Wt given as its pre-split image.  dZ is NOT written.
+int mx_pw_dgrad_bnbwd_planes(const float* G, const float* X, const float* coef, const void* WtPlanes, float* dX, int M, int K, int N,
+                             int ldg, int ldx, const float* residual, void* stream) {
+  MX_CHECK_ARG(G && X && coef && WtPlanes && dX, "pw_dgrad_bnbwd_planes: null pointer");
+  MX_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 32 == 0, "pw_dgrad_bnbwd_planes: bad extents M=%d N=%d K=%d (K must be a multiple of 32)", M, N, K);
+  MX_CHECK_ARG(ldg % 4 == 0 && ldg >= K && ldx >= N, "pw_dgrad_bnbwd_planes: bad leading dimensions");
+  MX_CHECK_ARG((((uintptr_t)G | (uintptr_t)X | (uintptr_t)coef | (uintptr_t)WtPlanes | (uintptr_t)dX) & 15) == 0, "pw_dgrad_bnbwd_planes: pointers must be 16-byte aligned");
+  GemmArgs g{};
+  g.a = MxOperand{G, coef, coef + K, X, MX_BNBWD, 1};
+  g.b = MxOperand{reinterpret_cast<const float*>(WtPlanes), nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.c = dX; g.M = M; g.N = N; g.K = K; g.lda = ldg; g.ldb = (N + 127) & ~127; g.ldc = ldx;
+  g.residual = residual;
   launch_nt_split3(g, 1, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;

@@ -275,6 +275,8 @@ struct WtArgs {
   int accumulate;          // groups == 1: part == dW, add instead of store
   int total;               // number of workgroup ids (8 * ceil(groups / 8) * tiles)
   int order;               // 0: XCD-aware (tiles of a group on one XCD); 1: group-major; 2: tile-major
+  const float* G2;         // wgrad_split_kernel<*, true>: the G operand is c1*G + c2*G2 + c3 per column (BatchNorm backward apply
+  const float* gcoef;      //   folded into the load; gcoef = [3][Co]); G2 shares G's leading dimension
 };
 
 template <int TE, int TF, int XMODE>
@@ -423,7 +425,10 @@ static __device__ __forceinline__ void wsplit3_pair(float x0, float x1, unsigned
   l = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
 }
 
-template <int XMODE>
+// GBN: the G operand is the BatchNorm backward apply c1*G + c2*G2 + c3 (per column), formed from two tensors by the loader threads
+// (their columns are fixed, so the three coefficient vectors are loaded once): the expand convolution's weight gradient reads
+// (G, e_raw) instead of a materialised dZ - see gemm_nt_split3_kernel<*, MX_BNBWD> for the data-gradient half.
+template <int XMODE, bool GBN>
 __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WtArgs a) {
   constexpr int PLANE = 128 * 64;                           // bytes: [128 columns][32 k] bf16
   __shared__ __attribute__((aligned(16))) unsigned char smem[6 * PLANE];     // G h/m/l, X h/m/l
@@ -445,19 +450,31 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WtArgs a) {
   const bool colok = col0 < (isx ? a.Ci : a.Co);
   const float* base = isx ? a.X.p : a.G;
   const int ld = isx ? a.ldx : a.ldg;
-  float4 rv[8], gt[XMODE == MX_BNACT ? 8 : 1];
+  float4 rv[8], gt[(XMODE == MX_BNACT || GBN) ? 8 : 1];      // gt: the SE gate rows (X side) / the second tensor (G side)
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  float4 gc1 = sc, gc2 = sh, gc3 = sh;
   if (XMODE != MX_PLAIN && isx && colok) { sc = ld4(a.X.c1 + col0); sh = ld4(a.X.c2 + col0); }
+  if (GBN && !isx && colok) { gc1 = ld4(a.gcoef + col0); gc2 = ld4(a.gcoef + a.Co + col0); gc3 = ld4(a.gcoef + 2 * a.Co + col0); }
   auto load = [&](long r0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const long r = r0 + 8 * rg + i;
       const bool ok = colok && r < r_end;
       rv[i] = ok ? ld4(base + r * ld + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (XMODE == MX_BNACT) gt[i] = (ok && isx && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + col0) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (XMODE == MX_BNACT && (!GBN || isx)) gt[i] = (ok && isx && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + col0) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (GBN && !isx) gt[i] = ok ? ld4(a.G2 + r * ld + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   auto store = [&](long r0) {
+    if (GBN && !isx) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (!(colok && r0 + 8 * rg + i < r_end)) continue;      // rows past the group's end stay zero
+        const float4 g4 = rv[i], x4 = gt[GBN ? i : 0];
+        rv[i] = make_float4(gc1.x * g4.x + (gc2.x * x4.x + gc3.x), gc1.y * g4.y + (gc2.y * x4.y + gc3.y),
+                            gc1.z * g4.z + (gc2.z * x4.z + gc3.z), gc1.w * g4.w + (gc2.w * x4.w + gc3.w));
+      }
+    }
     if (XMODE != MX_PLAIN && isx) {
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -680,10 +697,36 @@ long mx_pw_wgrad_tile_ws(int R, int Co, int Ci, int x_mode) {
   return p.groups > 1 ? (long)p.groups * Co * Ci * 4 : 16;
 }
 
+static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, const float* X, int x_mode, const float* x_scale,
+                           const float* x_shift, const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg,
+                           int ldx, void* ws, long ws_bytes, void* stream);
+
 // dW[Co,Ci] += G[R,Co]^T X'[R,Ci], large outputs: tiled, deterministic (partial tiles per row group, fixed-order reduce).
 int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
                      const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,
                      void* ws, long ws_bytes, void* stream) {
+  return wgrad_tile_impl(G, nullptr, nullptr, X, x_mode, x_scale, x_shift, x_gate, rows_per_sample, dW, R, Co, Ci, ldg, ldx, ws, ws_bytes, stream);
+}
+
+// 1 when mx_pw_wgrad_tile_bnbwd takes this shape in the current mode (the split-arithmetic tiled kernel), else 0
+int mx_pw_wgrad_tile_bnbwd_ok(int R, int Co, int Ci) { return mx_wgrad_uses_split(R, Co, Ci) ? 1 : 0; }
+
+// dW[Co,Ci] += dZ[R,Co]^T X[R,Ci] with dZ = c1*G + c2*G2 + c3 per column (coef = [3][Co], as mx_bn_bwd_finalize leaves it) formed in
+// the operand load: the weight-gradient half of the BatchNorm-backward fold (mx_pw_dgrad_bnbwd_planes is the other).  Shapes:
+// mx_pw_wgrad_tile_bnbwd_ok; scratch: mx_pw_wgrad_tile_ws(R, Co, Ci, 0).
+int mx_pw_wgrad_tile_bnbwd(const float* G, const float* G2, const float* coef, const float* X, float* dW, int R, int Co, int Ci,
+                           int ldg, int ldx, void* ws, long ws_bytes, void* stream) {
+  MX_CHECK_ARG(G2 && coef, "wgrad_tile_bnbwd: null pointer");
+  MX_CHECK_ARG((((uintptr_t)G2 | (uintptr_t)coef) & 15) == 0, "wgrad_tile_bnbwd: pointers must be 16-byte aligned");
+  MX_CHECK_ARG(mx_wgrad_uses_split(R, Co, Ci), "wgrad_tile_bnbwd: shape R=%d Co=%d Ci=%d is not one the split kernel takes (mx_pw_wgrad_tile_bnbwd_ok)", R, Co, Ci);
+  return wgrad_tile_impl(G, G2, coef, X, MX_PLAIN, nullptr, nullptr, nullptr, 1, dW, R, Co, Ci, ldg, ldx, ws, ws_bytes, stream);
+}
+
+}  // extern "C"
+
+static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, const float* X, int x_mode, const float* x_scale,
+                           const float* x_shift, const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg,
+                           int ldx, void* ws, long ws_bytes, void* stream) {
   MX_CHECK_ARG(G && X && dW && ws, "wgrad_tile: null pointer");
   MX_CHECK_ARG(((uintptr_t)dW & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)G & 15) == 0 && ((uintptr_t)X & 15) == 0,
                "wgrad_tile: pointers must be 16-byte aligned");
@@ -698,14 +741,16 @@ int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_
   a.rows_per_group = p.rows_per_group; a.groups = p.groups; a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci;
   a.accumulate = p.groups == 1;
   a.order = wt_order();
+  a.G2 = G2; a.gcoef = gcoef;
   a.part = a.accumulate ? dW : (float*)ws;
   hipStream_t st = (hipStream_t)stream;
   if (wt_use_split(Co, Ci)) {
     const dim3 grid(8 * cdiv(a.groups, 8) * a.tiles_co * a.tiles_ci);
     a.total = grid.x;
-    if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN>), grid, dim3(256), 0, st, a);
-    else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_split_kernel<MX_BNACT>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((wgrad_split_kernel<MX_AFFINE>), grid, dim3(256), 0, st, a);
+    if (a.G2) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, true>), grid, dim3(256), 0, st, a);
+    else if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, false>), grid, dim3(256), 0, st, a);
+    else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_split_kernel<MX_BNACT, false>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((wgrad_split_kernel<MX_AFFINE, false>), grid, dim3(256), 0, st, a);
   } else if (p.te == 4 && p.tf == 4) wt_launch<4, 4>(a, st);
   else if (p.te == 4) wt_launch<4, 2>(a, st);
   else if (p.tf == 4) wt_launch<2, 4>(a, st);
@@ -717,5 +762,3 @@ int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_
   }
   return MX_OK;
 }
-
-}  // extern "C"

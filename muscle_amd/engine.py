@@ -354,6 +354,13 @@ FUSED_DW_BACKWARD = True
 # per step without against 133.0 / 133.2 with it - the second operand stream and the dz stores of the N-tile-0 workgroups
 # cost the MFMA-bound GEMMs more than the 8.5 ms pass gives back a third of.  Off; kept as an option.
 FOLD_BN0_APPLY = os.environ.get("MUSCLE_FOLD_BN0", "0") == "1"
+# Round 4: dZ = c1*G + c2*X + c3 formed in the operand loads of BOTH consumers (the second-generation split data gradient, whose
+# activations go straight to registers, and the split weight gradient's loader threads), dZ never written: the 2R + 1W pass over
+# the Cexp-wide tensors of the 28 x 28 stages disappears (-2.3 ms of bn_bwd_apply per step, -13 GB of traffic).  Measured
+# A/B/A/B on one box (profiles/r04_fold_bn0_both_ab.txt): 107.4 / 107.7 ms per step without, 109.9 / 110.0 with - the folded GEMMs
+# lose more (+5.3 ms: 192 registers take the data gradient from 3 to 2 workgroups per CU, 222 the weight gradient from 3 to 2 waves
+# per SIMD) than the pass costs.  Off; MUSCLE_FOLD_BN0_BOTH=1 turns it on (kernels and tests stay: tests/test_gpu_split.py).
+FOLD_BN0_BOTH = os.environ.get("MUSCLE_FOLD_BN0_BOTH", "0") == "1"
 # Weight-gradient GEMMs on a second HIP stream (MUSCLE_WGRAD_STREAM=0 turns it off; `engine.WGRAD_SIDE_STREAM` can be
 # flipped at run time).  Nothing in the backward chain consumes them (only the optimizer and the gradient exchange do),
 # they are MFMA-bound, and the chain between two of them (BN backward, SE, depthwise) is HBM-bound.  Measured on
@@ -406,6 +413,12 @@ class _WgradLane:
                     _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MUSCLE_WGRAD_PRIO", "0")))
             self.s = _side_streams[key]
 
+    def wgrad_bnbwd(self, G, G2, coef, X, dW):
+        """Queue dW += (c1*G + c2*G2 + c3)^T X (ops.pw_wgrad_bnbwd)."""
+        if self.s is None:
+            return ops.pw_wgrad_bnbwd(G, G2, coef, X, dW)
+        self.pending.append((G, X, dW, {"_bnbwd": (G2, coef)}))
+
     def wgrad(self, G, X, dW, **kw):
         """Queue dW += G^T X'.  It is launched by the next flush(), i.e. right after the data-gradient GEMM of the same
         conv has been enqueued on the main stream: two MFMA-bound GEMMs side by side gain nothing, a weight-gradient GEMM
@@ -420,10 +433,13 @@ class _WgradLane:
         self.s.wait_stream(torch.cuda.current_stream())     # operands ready, the data-gradient GEMM done
         with torch.cuda.stream(self.s):
             for G, X, dW, kw in self.pending:
-                ops.pw_wgrad(G, X, dW, **kw)
+                if "_bnbwd" in kw:
+                    ops.pw_wgrad_bnbwd(G, kw["_bnbwd"][0], kw["_bnbwd"][1], X, dW)
+                else:
+                    ops.pw_wgrad(G, X, dW, **kw)
         # the caller drops G and X before the side stream has read them: they stay referenced until join() (one dz per
         # block, ~10 GB for B7/448/bs32 of 288; no record_stream, so the same code can be captured into a hipGraph)
-        self.keep.extend((G, X) for G, X, _, _ in self.pending)
+        self.keep.extend((G, X, kw.get("_bnbwd")) for G, X, _, kw in self.pending)
         self.pending = []
 
     def progress(self, done, module):
@@ -510,14 +526,24 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
             raw2 = dw_in.view(M, dw_in.shape[3])
             gx2 = gx.view(M, dw_in.shape[3])
             fold = fused and b.expand and FOLD_BN0_APPLY and ops.DGRAD_AS_FORWARD and b.cexp % 4 == 0
+            # round 4: the apply folded into BOTH consumers (dZ never written) where both run in split arithmetic
+            wtp = tape.wtp.get(id(m._expand_conv.weight)) if b.expand else None
+            fold2 = (fused and b.expand and FOLD_BN0_BOTH and not fold and wtp is not None and ops.DGRAD_AS_FORWARD
+                     and ops.bnbwd_fold_takes(M, b.cexp, b.cin))
             if fused:
                 c0 = ops.bn_bwd_coeffs(part0, M, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training)
-                if not fold:
+                if not fold and not fold2:
                     dz = ops.bn_bwd_apply_plain(gx2, raw2, c0, gx2)
             else:
                 dz = ops.bn_backward(gx2, raw2, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training,
                                      act=dw_st, out=gx2)
-            if fold:
+            if fold2:
+                lane.wgrad_bnbwd(gx2, raw2, c0, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
+                g_in = ops.pw_dgrad_bnbwd_planes(gx2, raw2, c0, wtp, b.cin,
+                                                 residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)
+                lane.flush()
+                g_out = g_in.view(N, t.H, t.W, b.cin)
+            elif fold:
                 # the BN0 backward apply rides in the data-gradient GEMM's operand load (which also writes dz for the weight
                 # gradient): one pass over the Cexp-wide tensors less than bn_bwd_apply + GEMM
                 g_in, dz = ops.pw_dgrad_bnbwd(gx2, raw2, c0, m._expand_conv.weight.view(b.cexp, b.cin), b.cin,

@@ -229,6 +229,35 @@ def pw_dgrad_bnbwd(G, X, coef, W, N_in, *, residual=None, wt=None):
     return out, dz
 
 
+def pw_dgrad_bnbwd_planes(G, X, coef, planes, N_in, *, residual=None):
+    """dX = dZ W with dZ = c1*G + c2*X + c3 formed in the GEMM's operand load (second-generation split kernel, W^T given as its
+    pre-split image); dZ is not materialised - the weight gradient folds the same expression (pw_wgrad_bnbwd)."""
+    M, K = G.shape
+    out = _f32(M, N_in, device=G.device)
+    call("mx_pw_dgrad_bnbwd_planes", ptr(G), ptr(X), ptr(coef), planes, ptr(out), M, K, N_in, G.stride(0), N_in, ptr(residual), stream())
+    return out
+
+
+def bnbwd_fold_takes(M, K, N):
+    """Can BOTH consumers of dZ [M, K] (data gradient against W^T [N, K], weight gradient dW [K, N]) fold the BatchNorm backward
+    apply in the current arithmetic?"""
+    key = ("fold", get_gemm_mode(), M, K, N)
+    r = _uses_planes.get(key)
+    if r is None:
+        r = _uses_planes[key] = bool(_planes_take(M, K, N) and lib().mx_pw_wgrad_tile_bnbwd_ok(M, K, N)
+                                     and lib().mx_pw_wgrad_small_ws(M, K, N, PLAIN) <= 0)
+    return r
+
+
+def pw_wgrad_bnbwd(G, G2, coef, X, dW):
+    """dW[Co, Ci] += (c1*G + c2*G2 + c3)[R, Co]^T X[R, Ci] (split-arithmetic tiled kernel only: bnbwd_fold_takes)."""
+    R, Co = G.shape
+    Ci = X.shape[1]
+    need = lib().mx_pw_wgrad_tile_ws(R, Co, Ci, PLAIN)
+    ws = _wgrad_workspace(G.device, max(need, 16))
+    call("mx_pw_wgrad_tile_bnbwd", ptr(G), ptr(G2), ptr(coef), ptr(X), ptr(dW), R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())
+
+
 _wgrad_ws: dict = {}
 _wgrad_ws_retired: list = []      # outgrown workspaces stay alive: captured graphs keep writing to them
 WGRAD_TILE = os.environ.get("MUSCLE_WGRAD_TILE", "1") == "1"   # large outputs: tiled deterministic kernel (wgrad.hip) instead of the atomic TN GEMM

@@ -120,6 +120,49 @@ def test_planes_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, opts):
     assert errs[2] <= 1.5 * errs[1] + 2e-7 * scale_, errs        # ... and as close as the first-generation split kernel
 
 
+@pytest.mark.parametrize("M,K,N,res", [(25088, 960, 160, True), (6272, 2304, 384, False), (3001, 384, 130, True), (700, 1344, 224, False)])
+def test_bnbwd_fold_in_both_consumers_matches_fp64(M, K, N, res):
+    """The BatchNorm backward apply dZ = c1*G + c2*X + c3 folded into BOTH consumers of dZ (mx_pw_dgrad_bnbwd_planes: the data gradient's
+    operand load; mx_pw_wgrad_tile_bnbwd: the weight gradient's G operand) against float64, beside the unfused pair (bn_bwd_apply, then
+    the same two GEMMs on the materialised dZ); bit-identical from run to run."""
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    G = torch.randn(M, K, device=DEV, generator=g)
+    X = torch.randn(M, K, device=DEV, generator=g)
+    coef = torch.stack([torch.rand(K, device=DEV, generator=g) + 0.5, torch.randn(K, device=DEV, generator=g) * 0.3,
+                        torch.randn(K, device=DEV, generator=g) * 0.1]).contiguous()
+    Wt = torch.randn(N, K, device=DEV, generator=g) * (K ** -0.5)           # W^T of the expand conv [Cin, Cexp]
+    Xin = torch.randn(M, N, device=DEV, generator=g)                         # the block input x
+    R = torch.randn(M, N, device=DEV, generator=g) if res else None
+    dz64 = coef[0].double() * G.double() + coef[1].double() * X.double() + coef[2].double()
+    want_dx = dz64 @ Wt.double().t() + (R.double() if res else 0)
+    want_dw = dz64.t() @ Xin.double()
+    plan = ops.PlanesPlan([Wt])               # (kept alive: the image lives in the plan's buffer)
+    (image,) = plan.run()
+    muscle_amd.set_gemm_mode(1)
+    try:
+        if not ops.bnbwd_fold_takes(M, K, N):
+            pytest.skip("shape not folded in mode 1")
+        dz = ops.bn_bwd_apply_plain(G, X, coef, torch.empty_like(G))
+        dx_ref = ops.pw_dgrad(dz, None, N, wt=Wt, planes=image, residual=R)
+        dw_ref = torch.zeros(K, N, device=DEV)
+        ops.pw_wgrad(dz, Xin, dw_ref)
+        outs = []
+        for _ in range(2):
+            dx = ops.pw_dgrad_bnbwd_planes(G, X, coef, image, N, residual=R)
+            dw = torch.zeros(K, N, device=DEV)
+            ops.pw_wgrad_bnbwd(G, X, coef, Xin, dw)
+            outs.append((dx, dw))
+    finally:
+        muscle_amd.set_gemm_mode(0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for got, ref, want in ((outs[0][0], dx_ref, want_dx), (outs[0][1], dw_ref, want_dw)):
+        scale = float(want.abs().max())
+        e_got, e_ref = float((got.double() - want).abs().max()), float((ref.double() - want).abs().max())
+        assert e_got <= 1.5 * e_ref + 3e-7 * scale, (e_got, e_ref, scale)
+
+
 def test_planes_image_is_rebuilt_from_the_current_weight():
     """The image is a function of the weight at the time of PlanesPlan.run(): after an in-place update, run() again gives the new
     product; shapes with K % 32 != 0 have no image and stay on the first-generation kernels."""

@@ -118,15 +118,43 @@ def fold_eval_bn(backbone, cfg: NetCfg):
     SE squeeze and the project GEMM's operand prologue.  One launch per block (mx_fold_block): done once per model load by
     MuSCLe.fold_eval_bn(), or per forward when no cache is installed (always correct; the no-grad forward of view 2 in
     the training loop, train_mcl.py:205-206, is that case: the weights have just been stepped)."""
-    out = {}
+    dev = backbone._conv_stem.weight.device
+    # the folded tensors live with the backbone and are overwritten by every fold (the per-step refold of the training loop's
+    # no-grad forward allocates nothing), so the pre-split images of the folded weights (ops.PlanesPlan: one table, one launch)
+    # can be built once as well
+    arena = backbone.__dict__.get("_fold_arena")
+    key = (str(dev), tuple(b.index for b in cfg.blocks))
+    if arena is not None and (arena["key"] != key or arena["ptrs"] != tuple(t.data_ptr() for _, _, t in arena["mats"])):
+        # another device / block list, or a copy of the module (copy.deepcopy clones the tensors, the plan's table would still
+        # name the original's): start over; the old buffers stay alive (a captured graph may still use them)
+        backbone.__dict__.setdefault("_fold_arenas_retired", []).append(arena)
+        arena = None
+    fresh = arena is None
+    if fresh:
+        arena = {"key": key, "blocks": {}}
     for b in cfg.blocks:
         m = _blk(backbone, b.index)
-        out[b.index] = ops.fold_block(m._expand_conv.weight.view(b.cexp, b.cin) if b.expand else None, m._bn0 if b.expand else None,
-                                      m._bn1, m._project_conv.weight.view(b.cout, b.cexp), m._bn2)
-    dev = backbone._conv_stem.weight.device
-    cmax = max(b.cexp for b in cfg.blocks)
-    out["one"] = torch.ones(cmax, dtype=torch.float32, device=dev)
-    out["zero"] = torch.zeros(cmax, dtype=torch.float32, device=dev)
+        arena["blocks"][b.index] = ops.fold_block(m._expand_conv.weight.view(b.cexp, b.cin) if b.expand else None, m._bn0 if b.expand else None,
+                                                  m._bn1, m._project_conv.weight.view(b.cout, b.cexp), m._bn2, out=arena["blocks"].get(b.index))
+    if fresh:
+        cmax = max(b.cexp for b in cfg.blocks)
+        arena["one"] = torch.ones(cmax, dtype=torch.float32, device=dev)
+        arena["zero"] = torch.zeros(cmax, dtype=torch.float32, device=dev)
+        mats = []
+        for b in cfg.blocks:
+            f = arena["blocks"][b.index]
+            if b.expand:
+                mats.append((b.index, "We_planes", f["We"]))
+            mats.append((b.index, "Wp_planes", f["Wp"]))
+        arena["mats"] = mats
+        arena["ptrs"] = tuple(t.data_ptr() for _, _, t in mats)
+        arena["plan"] = None if torch.cuda.is_current_stream_capturing() else ops.PlanesPlan([t for _, _, t in mats])
+        backbone.__dict__["_fold_arena"] = arena
+    if arena["plan"] is not None:
+        for (bi, name, _), im in zip(arena["mats"], arena["plan"].run()):
+            arena["blocks"][bi][name] = im
+    out = dict(arena["blocks"])
+    out["one"], out["zero"] = arena["one"], arena["zero"]
     out["fingerprint"] = fold_fingerprint(backbone, cfg)
     return out
 
@@ -136,7 +164,7 @@ def _block_forward_eval(m, b: BlockCfg, f, ident, x, x_st, N, h, w, ho, wo):
     depthwise kernel, BN2 + skip ride in the project GEMM's epilogue.  HBM: in + 2*exp + 2*dw + out (+ skip)."""
     M, Mo = N * h * w, N * ho * wo
     if b.expand:
-        e = ops.pw_fwd(x.view(M, b.cin), f["We"], b.cexp, bias=f["be"]).view(N, h, w, b.cexp)      # = bn0(conv(x))
+        e = ops.pw_fwd(x.view(M, b.cin), f["We"], b.cexp, bias=f["be"], planes=f.get("We_planes")).view(N, h, w, b.cexp)      # = bn0(conv(x))
         dw_in, dw_st = e, BNState(ident[0][:b.cexp], ident[1][:b.cexp], None, None)                 # swish on load
     else:
         dw_in, dw_st = x, x_st
@@ -147,7 +175,7 @@ def _block_forward_eval(m, b: BlockCfg, f, ident, x, x_st, N, h, w, ho, wo):
     res = x.view(M, b.cin) if b.skip else None
     if b.cout > MATERIALISE_ABOVE_EVAL or (Mo < EVAL_PROLOGUE_MIN_ROWS and b.cout > MATERIALISE_ABOVE):
         a = ops.bn_apply(d2, f["bn1"], gate=gate, rows_per_sample=ho * wo, act=True)
-        out = ops.pw_fwd(a, f["Wp"], b.cout, bias=f["bp"], residual=res)
+        out = ops.pw_fwd(a, f["Wp"], b.cout, bias=f["bp"], residual=res, planes=f.get("Wp_planes"))
     else:
         out = ops.pw_fwd(d2, f["Wp"], b.cout, a_mode=ops.BNACT, a_scale=f["bn1"].scale, a_shift=f["bn1"].shift, a_gate=gate,
                          rows_per_sample=ho * wo, bias=f["bp"], residual=res)

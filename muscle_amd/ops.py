@@ -332,17 +332,21 @@ def bn_finalize(stats, count, bn: torch.nn.BatchNorm2d, training: bool) -> BNSta
     return BNState(b0, b1, b2, b3)
 
 
-def fold_block(We, bn0, bn1, Wp, bn2):
-    """Eval-mode BatchNorm folded into one block's 1x1 convolutions (mx_fold_block): dict We / be / bn1 / Wp / bp."""
+def fold_block(We, bn0, bn1, Wp, bn2, out=None):
+    """Eval-mode BatchNorm folded into one block's 1x1 convolutions (mx_fold_block): dict We / be / bn1 / Wp / bp.
+    out: a dict returned by an earlier call for the same block - its tensors are overwritten instead of allocated."""
     dev = Wp.device
     cout, cexp = Wp.shape
     cin = We.shape[1] if We is not None else cexp
-    f = {}
-    vec = _f32(3, cexp, device=dev)
-    if We is not None:
-        f["We"], f["be"] = _f32(cexp, cin, device=dev), vec[0]
-    f["bn1"] = BNState(vec[1], vec[2], None, None)
-    f["Wp"], f["bp"] = _f32(cout, cexp, device=dev), _f32(cout, device=dev)
+    if out is not None:
+        f, vec = out, out["_vec"]
+    else:
+        f = {}
+        vec = f["_vec"] = _f32(3, cexp, device=dev)
+        if We is not None:
+            f["We"], f["be"] = _f32(cexp, cin, device=dev), vec[0]
+        f["bn1"] = BNState(vec[1], vec[2], None, None)
+        f["Wp"], f["bp"] = _f32(cout, cexp, device=dev), _f32(cout, device=dev)
 
     def four(bn):
         return (ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var), float(bn.eps))

@@ -255,7 +255,36 @@ static int run_planes(int M, int K, int N, bool check) {
   return rc;
 }
 
+// second-generation split kernel: N tiles per XCD-local chunk (MX_SPLIT3_XCD_CHUNK)
+static void run_chunk(int M, int K, int N) {
+  float* A = dalloc((long)M * K, 1, 1.f); float* W = dalloc((long)N * K, 2, 0.05f);
+  float* C2 = dalloc((long)M * N, 5, 0.f);
+  float* st2 = dalloc((long)mx_pw_fwd_parts(M, N, K) * 2 * N, 8, 0.f);
+  void* planes; CK(hipMalloc(&planes, mx_pw_planes_bytes(N, K)));
+  long row[5] = {(long)W, (long)planes, N, K, 0};
+  long* table; CK(hipMalloc(&table, sizeof(row))); CK(hipMemcpy(table, row, sizeof(row), hipMemcpyHostToDevice));
+  mx_pw_planes_batch(table, 1, mx_pw_planes_tiles(N, K), nullptr);
+  const int cv[] = {1000, 16, 12, 10, 8, 6, 4};      // (lists of up to 16 N tiles are never cut: only N > 2048 reacts)
+  float best[7]; for (float& b : best) b = 1e30f;
+  for (int round = 0; round < 3; ++round)
+    for (int i = 0; i < 7; ++i) {
+      g_split3_xcd_chunk = cv[i];
+      best[i] = std::min(best[i], time_us([&] { mx_pw_fwd_planes(A, planes, C2, M, K, N, K, N, nullptr, nullptr, 0, st2, nullptr); }, 5));
+    }
+  g_split3_xcd_chunk = 6;
+  printf("  M=%d K=%d N=%d:", M, K, N);
+  for (int i = 0; i < 7; ++i) printf("  chunk %-4d %6.1f", cv[i], best[i]);
+  printf("\n"); fflush(stdout);
+  for (float* p : {A, W, C2, st2}) CK(hipFree(p));
+  CK(hipFree(planes)); CK(hipFree(table));
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "chunk")) {
+    static const Shape sh[] = {{25088, 384, 2304}, {25088, 640, 3840}, {25088, 224, 1344}, {25088, 160, 960}, {25088, 2304, 384}, {25088, 3840, 640}, {6272, 384, 2304}};
+    for (const Shape& s : sh) run_chunk(s.M, s.K, s.N);
+    return 0;
+  }
   if (argc >= 2 && !strcmp(argv[1], "planes")) {
     int rc = 0;
     if (argc >= 5) return run_planes(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), true);

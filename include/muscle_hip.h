@@ -219,12 +219,16 @@ int mx_dwconv_bwd_weight(const float* X, const float* scale, const float* shift,
  * dd = c1*g + c2*D + c3 with g = (dA*gate + add)*swish'(a1*D + b1) is formed while staging (never stored);
  * gX = dwconv^T(dd) [* swish'(a0*X+b0) when a0] [+ residual]; dW += sum dd*act(X); when a0 is given,
  * part[mx_dwconv_bwd_fused_parts()][2][C] = BatchNorm-0 backward partial sums (sum g, sum g*X) of the written gX.
- * dw_scratch[mx_dwconv_bwd_fused_parts()][C*K*K] is workspace (per-workgroup dW rows, summed into dW by a second launch). */
+ * dw_scratch[mx_dwconv_bwd_fused_parts()][C*K*K] is workspace (per-workgroup dW rows, summed into dW by a second launch; with
+ * dW == NULL that launch is left to the caller: mx_dw_parts_reduce(dw_scratch, parts, C*K*K, dW) on any stream ordered behind this call -
+ * nothing consumes a depthwise weight gradient before the optimizer, so it need not sit on the backward's critical path). */
 int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C, int K);
 int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
                         const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
                         const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,
                         int Wd, int C, int K, int pad_lo, void* stream);
+
+int mx_dw_parts_reduce(const float* part, int P, int n, float* dW, void* stream);
 
 /* ---- SE excitation (model.py:83-84) and stem patches (model.py:131,175) -------------------------------- */
 

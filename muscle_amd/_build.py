@@ -39,7 +39,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
-    flags = FLAGS + [f"-DMX_ABI_HASH={abi_hash()}"] + os.environ.get("MUSCLE_EXTRA_FLAGS", "").split()   # A/B builds
+    extra = os.environ.get("MUSCLE_EXTRA_FLAGS", "").split()                                             # A/B builds
+    if any(f.startswith("-DMX_LAB") for f in extra):
+        # timing-only switches that change results belong to tools/hip/gemm_lab.hip, never to the shipped library
+        raise RuntimeError("MUSCLE_EXTRA_FLAGS: -DMX_LAB_* switches are lab-only (tools/hip/gemm_lab.hip); refusing to build them into libmuscle_hip.so")
+    flags = FLAGS + [f"-DMX_ABI_HASH={abi_hash()}"] + extra
     # the flag list (incl. the header hash) is a staleness input: a changed flag or ABI rebuilds everything
     stamp = os.path.join(objdir, "flags.txt")
     if not os.path.exists(stamp) or open(stamp).read() != " ".join(flags):

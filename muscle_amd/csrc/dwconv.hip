@@ -919,7 +919,7 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
                         const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
                         const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,
                         int Wd, int C, int K, int pad_lo, void* stream) {
-  MX_CHECK_ARG(dA && D && gate && add && a1 && b1 && c1 && c2 && c3 && X && W && gX && dW && dw_scratch, "dwconv_bwd_fused: null pointer");
+  MX_CHECK_ARG(dA && D && gate && add && a1 && b1 && c1 && c2 && c3 && X && W && gX && dw_scratch, "dwconv_bwd_fused: null pointer");
   MX_CHECK_ARG((a0 == nullptr) == (b0 == nullptr), "dwconv_bwd_fused: a0/b0 come together");
   MX_CHECK_ARG(!a0 || part, "dwconv_bwd_fused: BN0 present -> part required");
   MX_CHECK_ARG((K == 3 || K == 5) && pad_lo == (K - 1) / 2, "dwconv_bwd_fused: stride 1 with symmetric pad only (K=%d pad=%d)", K, pad_lo);
@@ -947,7 +947,17 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
     else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 8, 16, 8>), grid, dim3(256), 0, (hipStream_t)stream, a);
   }
   MX_LAUNCH_CHECK();
-  launch_dw_parts_reduce(dw_scratch, groups, C * K * K, dW, (hipStream_t)stream);
+  if (dW) {                        // dW == null: the caller adds the partial rows later (mx_dw_parts_reduce), e.g. off the critical path
+    launch_dw_parts_reduce(dw_scratch, groups, C * K * K, dW, (hipStream_t)stream);
+    MX_LAUNCH_CHECK();
+  }
+  return MX_OK;
+}
+
+// dW[n] += sum over the P partial rows part[P][n] in row order: the second half of mx_dwconv_bwd_fused when it was called with dW == null
+int mx_dw_parts_reduce(const float* part, int P, int n, float* dW, void* stream) {
+  MX_CHECK_ARG(part && dW && P > 0 && n > 0, "dw_parts_reduce: bad arguments");
+  launch_dw_parts_reduce(part, P, n, dW, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }

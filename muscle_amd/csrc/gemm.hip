@@ -1430,7 +1430,13 @@ int mx_pw_planes_batch(const long* table, int n, int total_tiles, void* stream) 
 // 1 when, in the current mode, a forward / data-gradient GEMM of this shape should be run through mx_pw_fwd_planes
 int mx_pw_fwd_uses_planes(int M, int K, int N) {
   static const int on = getenv("MX_SPLIT2") ? atoi(getenv("MX_SPLIT2")) : 1;
-  return (on && M > 0 && K % 32 == 0 && nt_uses_split(N, K)) ? 1 : 0;
+  static const int early = getenv("MX_SPLIT3_EARLY") ? atoi(getenv("MX_SPLIT3_EARLY")) : 1;
+  if (!on || M <= 0 || K % 32) return 0;
+  if (nt_uses_split(N, K)) return 1;
+  // the HBM-bound data gradients of stages 2-3 (K = 288 -> 48 at 401 408 rows, 480 -> 80 at 100 352): the second-generation
+  // kernel streams their long operand straight into registers and beats the exact-fp32 kernel there too (137 -> 127 us,
+  // 102 -> 78 us; tools/hip/gemm_lab planes); narrower outputs / shorter reductions stay where they are (32 -> 32: 73 vs 90 us)
+  return (g_gemm_mode == 1 && early && K >= 192 && N >= 48) ? 1 : 0;
 }
 
 // C[M,N] = A[M,K] * W[N,K]^T (+bias) (+residual) (relu) with W given as its pre-split image (mx_pw_planes_batch) and a plain A:

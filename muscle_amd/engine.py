@@ -447,6 +447,12 @@ class _WgradLane:
             return ops.pw_wgrad_bnbwd(G, G2, coef, X, dW)
         self.pending.append((G, X, dW, {"_bnbwd": (G2, coef)}))
 
+    def dw_reduce(self, scratch, dW):
+        """Queue the addition of a depthwise weight gradient's partial rows (ops.dw_parts_reduce): no consumer before Adam."""
+        if self.s is None:
+            return ops.dw_parts_reduce(scratch, dW)
+        self.pending.append((scratch, None, dW, {"_dwreduce": True}))
+
     def wgrad(self, G, X, dW, **kw):
         """Queue dW += G^T X'.  It is launched by the next flush(), i.e. right after the data-gradient GEMM of the same
         conv has been enqueued on the main stream: two MFMA-bound GEMMs side by side gain nothing, a weight-gradient GEMM
@@ -461,7 +467,9 @@ class _WgradLane:
         self.s.wait_stream(torch.cuda.current_stream())     # operands ready, the data-gradient GEMM done
         with torch.cuda.stream(self.s):
             for G, X, dW, kw in self.pending:
-                if "_bnbwd" in kw:
+                if "_dwreduce" in kw:
+                    ops.dw_parts_reduce(G, dW)
+                elif "_bnbwd" in kw:
                     ops.pw_wgrad_bnbwd(G, kw["_bnbwd"][0], kw["_bnbwd"][1], X, dW)
                 else:
                     ops.pw_wgrad(G, X, dW, **kw)
@@ -538,7 +546,7 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
             # stride 1: BN1 data gradient, depthwise weight + data gradients and the BN0 backward sums in one kernel
             gx, part0 = ops.dwconv_bwd_fused(ga.view(N, t.Ho, t.Wo, b.cexp), t.d_raw, t.gate, add, t.bn1, c1, dw_in, dw_st,
                                              m._depthwise_conv.weight, sink.of(m._depthwise_conv.weight), b.kernel, b.pad_lo,
-                                             residual=None if dw_st is not None else skip_res)
+                                             residual=None if dw_st is not None else skip_res, defer=lane.dw_reduce)
             del ga
         else:
             # BN1 backward with g = (ga*gate + add) * swish'(bn1(d_raw)), in place over ga

@@ -443,8 +443,16 @@ def bn_bwd_apply_plain(G2d, X2d, c, out):
     return out
 
 
-def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNState], W, dW, K, pad_lo, *, residual=None):
-    """Stride-1 fused backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> gate; returns (gX, BN0 partial sums or None)."""
+def dw_parts_reduce(scratch, dW):
+    """dW += the partial rows a deferred dwconv_bwd_fused left in `scratch` [P, C*K*K]."""
+    P, n = scratch.shape
+    call("mx_dw_parts_reduce", ptr(scratch), P, n, ptr(dW), stream())
+
+
+def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNState], W, dW, K, pad_lo, *, residual=None, defer=None):
+    """Stride-1 fused backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> gate; returns (gX, BN0 partial sums or None).
+    defer: a callable taking (scratch, dW) - the addition of the weight gradient's partial rows is handed to it (e.g. queued for
+    the side stream) instead of being launched behind the kernel."""
     N, H, Wd, C = X.shape
     gX = _f32(N, H, Wd, C, device=X.device)
     P = lib().mx_dwconv_bwd_fused_parts(N, H, Wd, C, K)
@@ -453,7 +461,9 @@ def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNStat
     cb, cs = c1.data_ptr(), 4 * c1.shape[1]
     call("mx_dwconv_bwd_fused", ptr(dA), ptr(D), ptr(gate), ptr(add), ptr(st1.scale), ptr(st1.shift), cb, cb + cs,
          cb + 2 * cs, ptr(X), ptr(st0.scale) if st0 else None, ptr(st0.shift) if st0 else None, ptr(W), ptr(residual), ptr(gX),
-         ptr(dW), ptr(scratch), ptr(part), N, H, Wd, C, K, pad_lo, stream())
+         None if defer is not None else ptr(dW), ptr(scratch), ptr(part), N, H, Wd, C, K, pad_lo, stream())
+    if defer is not None:
+        defer(scratch, dW)
     return gX, part
 
 

@@ -364,3 +364,13 @@ def test_irn_search_paths_table():
         for p in mine:
             assert p[-1] == (0, 0) and abs(p[0][0]) + abs(p[0][1]) == max(abs(y) + abs(x) for y, x in p)
     assert len(indexing.search_paths(5)) == 34      # 4 + 9 + 9 + 7 + 5 directions inside the radius-5 half disc
+
+
+def test_build_refuses_lab_switches(monkeypatch):
+    """Timing-only -DMX_LAB_* switches (they change results) must never reach the shipped library through MUSCLE_EXTRA_FLAGS."""
+    from muscle_amd import _build
+    monkeypatch.setenv("MUSCLE_EXTRA_FLAGS", "-DMX_LAB_NOSPLIT")
+    with pytest.raises(RuntimeError, match="lab-only"):
+        _build.build(verbose=False)
+    src = "".join(open(os.path.join(ROOT, "muscle_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "muscle_amd", "csrc")))
+    assert "MX_LAB_" not in src

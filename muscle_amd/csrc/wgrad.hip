@@ -580,19 +580,20 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
   if (wt_use_split(Co, Ci)) {
     p->te = p->tf = 4;
     p->tiles_co = cdiv(Co, 128); p->tiles_ci = cdiv(Ci, 128);
-    const int tiles = p->tiles_co * p->tiles_ci, slots = 256 * 2;
+    // Row groups of the split kernel.  Standalone, many small work items are fastest (g = 32 at up to ~100 tiles: 1344 x 224 132 ->
+    // 118 us; profiles/r04_wgrad_split_groups.txt) - but the weight gradients run on the side stream BESIDE the HBM-bound kernels
+    // of the backward chain, and there every extra group is a partial matrix written and read back through the memory system
+    // those kernels live on: in the step g = 8 for every shape is the optimum (B7 / 448 / batch 32, one box: g = 2 / 4 / 6 / 8 /
+    // 16 / 24 / the standalone-best rule: 131.8 / 111.3 / 104.9 / 102.6 / 104.9 / 105.5 / 105.8 ms per step).  Eight = one group
+    // per XCD under the XCD-aware ids.  Shapes with fewer than 40 output tiles (1344 x 224: 22) take 16 (8 / 16 / 24 there:
+    // 101.9 / 101.5 / 101.8 ms per step on a faster box): 176 workgroups leave too many CUs without one.
+    const int tiles = p->tiles_co * p->tiles_ci;
     const int maxg = R / 256 > 0 ? R / 256 : 1;
-    int groups = 1;
-    double best_score = -1.0;
-    for (int rounds = 2; rounds <= 5; ++rounds) {
-      int g = slots * rounds / tiles;
-      if (g < 1) g = 1;
-      if (g > maxg) g = maxg;
-      if (g >= 8) g = g / 8 * 8;
-      const double fill = (double)tiles * g / ((double)slots * cdiv(tiles * g, slots));
-      const double score = fill - 0.0025 * g;
-      if (score > best_score + 1e-9) { best_score = score; groups = g; }
-    }
+    static const int small_g = getenv("MX_WGRAD_SPLIT_GROUPS_SMALL") ? atoi(getenv("MX_WGRAD_SPLIT_GROUPS_SMALL")) : 16;
+    int groups = tiles < 40 ? small_g : 8;
+    if (groups > maxg) groups = maxg;
+    static const int forced_split = getenv("MX_WGRAD_SPLIT_GROUPS") ? atoi(getenv("MX_WGRAD_SPLIT_GROUPS")) : 0;
+    if (forced_split > 0) groups = forced_split < maxg ? forced_split : maxg;
     p->rows_per_group = cdiv(cdiv(R, groups), 32) * 32;
     p->groups = cdiv(R, p->rows_per_group);
     return true;

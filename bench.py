@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 from muscle_amd import arch, synth  # noqa: E402
 
 GEMM_CALLS = ("mx_pw_fwd", "mx_pw_fwd_planes", "mx_pw_dgrad_bnbwd_planes", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile",
-              "mx_pw_wgrad_tile_bnbwd")
+              "mx_pw_wgrad_tile_bnbwd", "mx_pw_wgrad_small_bnbwd")
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # same guide, dense bf16 MFMA (no sparsity)
 SPLIT_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0    # split arithmetic: six bf16 products per fp32 product -> 416.7 fp32-equivalent
@@ -85,6 +85,9 @@ class GemmTimer:
             if name == "mx_pw_wgrad_tile_bnbwd":
                 R, Co, Ci = a[5], a[6], a[7]
                 return 2.0 * R * Co * Ci, 2, Co, Ci, R           # split-arithmetic tiled kernel only
+            if name == "mx_pw_wgrad_small_bnbwd":
+                R, Co, Ci = a[5], a[6], a[7]
+                return 2.0 * R * Co * Ci, -1, Co, Ci, R          # exact-fp32 small-output kernel
             if name == "mx_pw_dgrad":
                 M, K, N = a[3], a[4], a[5]
                 return 2.0 * M * K * N, -1, M, N, K             # NN kernel: never split

@@ -100,6 +100,11 @@ int mx_pw_dgrad_bnbwd(const float* G, const float* X, const float* coef, const f
 int mx_pw_dgrad_bnbwd_planes(const float* G, const float* X, const float* coef, const void* WtPlanes, float* dX, int M, int K, int N,
                              int ldg, int ldx, const float* residual, void* stream);
 int mx_pw_wgrad_tile_bnbwd_ok(int R, int Co, int Ci);
+/* the same fold in the small-output weight-gradient kernel (stages 1-2: 192 x 32, 288 x 48; HBM-bound, so dropping the pass that
+ * wrote dZ is a net saving there); scratch = mx_pw_wgrad_small_ws(R,Co,Ci,0) */
+int mx_pw_wgrad_small_bnbwd_ok(int R, int Co, int Ci);
+int mx_pw_wgrad_small_bnbwd(const float* G, const float* G2, const float* coef, const float* X, float* dW, int R, int Co, int Ci,
+                            int ldg, int ldx, void* ws, long ws_bytes, void* stream);
 int mx_pw_wgrad_tile_bnbwd(const float* G, const float* G2, const float* coef, const float* X, float* dW, int R, int Co, int Ci,
                            int ldg, int ldx, void* ws, long ws_bytes, void* stream);
 

@@ -19,10 +19,12 @@ struct WgArgs {
   int rows_per_wg;         // multiple of 16
   int WCO, WCI;            // wave grid over (Co tiles, Ci tiles): WCO * WCI = waves
   int SG, SX;              // LDS row strides (floats), == 16 mod 32: the 4 rows of a fragment fall on disjoint banks
+  const float* G2;         // GBN instantiations: the G operand is c1*G + c2*G2 + c3 per column (BatchNorm backward apply folded
+  const float* gcoef;      //   into the load; gcoef = [3][Co]); G2 shares G's leading dimension
 };
 
 // GI / XI: 16-byte chunks of a G / X row per loader lane (a row is shared by NT/16 lanes); XMODE: operand prologue of X.
-template <int TCO, int TCI, int NW, int GI, int XI, int XMODE>
+template <int TCO, int TCI, int NW, int GI, int XI, int XMODE, bool GBN = false>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void wgrad_small_kernel(WgArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int RB = 16, NT = NW * 64, LPR = NT / RB;       // loader lanes per slab row
@@ -35,7 +37,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void wgrad_small_kernel(W
   const long r_end = min((long)a.R, r_beg + a.rows_per_wg);
   const int lrow = tid / LPR, lc = tid - lrow * LPR;         // this lane's slab row and first chunk
 
-  float4 rg[GI], rx[XI], gt[XMODE == MX_BNACT ? XI : 1];
+  float4 rg[GI], rx[XI], gt[XMODE == MX_BNACT ? XI : 1], rg2[GBN ? GI : 1];
   auto load = [&](long r0) {
     const long r = r0 + lrow;
     const bool rin = r < r_end;
@@ -45,6 +47,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void wgrad_small_kernel(W
     for (int i = 0; i < GI; ++i) {
       const int c = lc + LPR * i;
       rg[i] = (rin && c < gch) ? ld4(pg + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+      if (GBN) rg2[GBN ? i : 0] = (rin && c < gch) ? ld4(a.G2 + r * a.ldg + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -59,7 +62,16 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void wgrad_small_kernel(W
 #pragma unroll
     for (int i = 0; i < GI; ++i) {
       const int c = lc + LPR * i;
-      if (c < gch) st4(buf + lrow * a.SG + 4 * c, rg[i]);
+      if (c < gch) {
+        float4 v = rg[i];
+        if (GBN && rin) {               // dZ = c1*G + c2*G2 + c3 (rows past the range stay zero: they must not add c3)
+          const float4 k1 = ld4(a.gcoef + 4 * c), k2 = ld4(a.gcoef + a.Co + 4 * c), k3 = ld4(a.gcoef + 2 * a.Co + 4 * c);
+          const float4 x = rg2[GBN ? i : 0];
+          v = make_float4(k1.x * v.x + (k2.x * x.x + k3.x), k1.y * v.y + (k2.y * x.y + k3.y), k1.z * v.z + (k2.z * x.z + k3.z),
+                          k1.w * v.w + (k2.w * x.w + k3.w));
+        }
+        st4(buf + lrow * a.SG + 4 * c, v);
+      }
     }
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
@@ -214,15 +226,15 @@ static bool wg_plan(int R, int Co, int Ci, WgPlan* p) {
   return true;
 }
 
-template <int TCO, int TCI, int NW, int GI, int XI, int XMODE>
+template <int TCO, int TCI, int NW, int GI, int XI, int XMODE, bool GBN = false>
 static void wg_launch_one(const WgArgs& a, const WgPlan& p, hipStream_t st) {
   static bool big_lds_ok = false;                      // > 64 KB of dynamic LDS needs the attribute, once per kernel
   if (p.lds_bytes > 64 * 1024 && !big_lds_ok) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_small_kernel<TCO, TCI, NW, GI, XI, XMODE>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_small_kernel<TCO, TCI, NW, GI, XI, XMODE, GBN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     big_lds_ok = true;
   }
-  hipLaunchKernelGGL((wgrad_small_kernel<TCO, TCI, NW, GI, XI, XMODE>), dim3(p.groups), dim3(NW * 64), p.lds_bytes, st, a);
+  hipLaunchKernelGGL((wgrad_small_kernel<TCO, TCI, NW, GI, XI, XMODE, GBN>), dim3(p.groups), dim3(NW * 64), p.lds_bytes, st, a);
 }
 
 // The instantiations that exist: the (Co, Ci, prologue) combinations of EfficientNet-B7's first four stages (project convs
@@ -246,6 +258,17 @@ static bool wg_dispatch(const WgArgs& a, const WgPlan& p, hipStream_t st, bool l
   if (p.tco == TCO && p.tci == TCI && p.nw == NW && gi == GI && xi == XI && a.X.mode == MODE) {        \
     if (launch) wg_launch_one<TCO, TCI, NW, GI, XI, MODE>(a, p, st);                                   \
     return true;                                                                                       \
+  }
+  if (a.G2) {                       // folded BatchNorm backward apply on G: the expand convs of block 4 and of stage 2 (plain X)
+#define WG_TRY_GBN(TCO, TCI, NW, GI, XI)                                                               \
+    if (p.tco == TCO && p.tci == TCI && p.nw == NW && gi == GI && xi == XI && a.X.mode == MX_PLAIN) {  \
+      if (launch) wg_launch_one<TCO, TCI, NW, GI, XI, MX_PLAIN, true>(a, p, st);                       \
+      return true;                                                                                     \
+    }
+    WG_TRY_GBN(3, 2, 4, 3, 1)       /* 192 x 32 */
+    WG_TRY_GBN(5, 3, 4, 5, 1)       /* 288 x 48 */
+#undef WG_TRY_GBN
+    return false;
   }
   WG_TABLE(WG_TRY)
 #undef WG_TRY
@@ -678,6 +701,37 @@ int mx_pw_wgrad_small(const float* G, const float* X, int x_mode, const float* x
   a.rows_per_wg = p.rows_per_wg; a.WCO = p.wco; a.WCI = p.wci; a.SG = p.SG; a.SX = p.SX;
   hipStream_t st = (hipStream_t)stream;
   MX_CHECK_ARG(wg_dispatch(a, p, st, true), "wgrad_small: no kernel for Co=%d Ci=%d mode=%d (ask mx_pw_wgrad_small_ws first)", Co, Ci, x_mode);
+  MX_LAUNCH_CHECK();
+  hipLaunchKernelGGL(wgrad_parts_reduce_kernel, dim3(cdiv((long)Co * Ci, 64)), dim3(256), 0, st, (const float*)ws, p.groups, Co * Ci, dW);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// 1 when mx_pw_wgrad_small_bnbwd takes this shape (a small-output kernel with the folded G operand exists), else 0
+int mx_pw_wgrad_small_bnbwd_ok(int R, int Co, int Ci) {
+  WgPlan p;
+  if (!wg_plan(R, Co, Ci, &p)) return 0;
+  WgArgs a{};
+  a.Co = Co; a.Ci = Ci; a.X.mode = MX_PLAIN; a.G2 = reinterpret_cast<const float*>(16);
+  return wg_dispatch(a, p, nullptr, false) ? 1 : 0;
+}
+
+// dW[Co,Ci] += dZ[R,Co]^T X[R,Ci] with dZ = c1*G + c2*G2 + c3 per column formed in the loader (small outputs, HBM-bound: the fold
+// saves the 2R + 1W pass that materialised dZ); scratch: mx_pw_wgrad_small_ws(R, Co, Ci, 0) bytes
+int mx_pw_wgrad_small_bnbwd(const float* G, const float* G2, const float* coef, const float* X, float* dW, int R, int Co, int Ci,
+                            int ldg, int ldx, void* ws, long ws_bytes, void* stream) {
+  MX_CHECK_ARG(G && G2 && coef && X && dW && ws, "wgrad_small_bnbwd: null pointer");
+  MX_CHECK_ARG((((uintptr_t)dW | (uintptr_t)ws | (uintptr_t)G2 | (uintptr_t)coef) & 15) == 0, "wgrad_small_bnbwd: pointers must be 16-byte aligned");
+  MX_CHECK_ARG(ldg % 4 == 0 && ldx % 4 == 0, "wgrad_small_bnbwd: leading dimensions must be multiples of 4");
+  WgPlan p;
+  MX_CHECK_ARG(wg_plan(R, Co, Ci, &p), "wgrad_small_bnbwd: shape R=%d Co=%d Ci=%d not supported", R, Co, Ci);
+  MX_CHECK_ARG(ws_bytes >= (long)p.groups * Co * Ci * 4, "wgrad_small_bnbwd: workspace too small");
+  WgArgs a{};
+  a.G = G; a.X = MxOperand{X, nullptr, nullptr, nullptr, MX_PLAIN, 1}; a.G2 = G2; a.gcoef = coef;
+  a.part = (float*)ws; a.R = R; a.Co = Co; a.Ci = Ci; a.ldg = ldg; a.ldx = ldx;
+  a.rows_per_wg = p.rows_per_wg; a.WCO = p.wco; a.WCI = p.wci; a.SG = p.SG; a.SX = p.SX;
+  hipStream_t st = (hipStream_t)stream;
+  MX_CHECK_ARG(wg_dispatch(a, p, st, true), "wgrad_small_bnbwd: no kernel for Co=%d Ci=%d (mx_pw_wgrad_small_bnbwd_ok)", Co, Ci);
   MX_LAUNCH_CHECK();
   hipLaunchKernelGGL(wgrad_parts_reduce_kernel, dim3(cdiv((long)Co * Ci, 64)), dim3(256), 0, st, (const float*)ws, p.groups, Co * Ci, dW);
   MX_LAUNCH_CHECK();

@@ -389,6 +389,10 @@ FOLD_BN0_APPLY = os.environ.get("MUSCLE_FOLD_BN0", "0") == "1"
 # lose more (+5.3 ms: 192 registers take the data gradient from 3 to 2 workgroups per CU, 222 the weight gradient from 3 to 2 waves
 # per SIMD) than the pass costs.  Off; MUSCLE_FOLD_BN0_BOTH=1 turns it on (kernels and tests stay: tests/test_gpu_split.py).
 FOLD_BN0_BOTH = os.environ.get("MUSCLE_FOLD_BN0_BOTH", "0") == "1"
+# ... but in stages 1-2 (expand convs 32 -> 192, 48 -> 288 at 0.4-1.6 M rows) both consumers are HBM-bound, and there the same fold
+# (data gradient through the planes kernel, weight gradient through wgrad_small_kernel<..., GBN>) trades a 3-pass kernel for one
+# more operand stream in two kernels that wait on memory anyway.  MUSCLE_FOLD_BN0_EARLY=0 restores the pass.
+FOLD_BN0_EARLY = os.environ.get("MUSCLE_FOLD_BN0_EARLY", "1") == "1"
 # Weight-gradient GEMMs on a second HIP stream (MUSCLE_WGRAD_STREAM=0 turns it off; `engine.WGRAD_SIDE_STREAM` can be
 # flipped at run time).  Nothing in the backward chain consumes them (only the optimizer and the gradient exchange do),
 # they are MFMA-bound, and the chain between two of them (BN backward, SE, depthwise) is HBM-bound.  Measured on
@@ -564,8 +568,8 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
             fold = fused and b.expand and FOLD_BN0_APPLY and ops.DGRAD_AS_FORWARD and b.cexp % 4 == 0
             # round 4: the apply folded into BOTH consumers (dZ never written) where both run in split arithmetic
             wtp = tape.wtp.get(id(m._expand_conv.weight)) if b.expand else None
-            fold2 = (fused and b.expand and FOLD_BN0_BOTH and not fold and wtp is not None and ops.DGRAD_AS_FORWARD
-                     and ops.bnbwd_fold_takes(M, b.cexp, b.cin))
+            kind = ops.bnbwd_fold_takes(M, b.cexp, b.cin) if (fused and b.expand and not fold and wtp is not None and ops.DGRAD_AS_FORWARD) else None
+            fold2 = (kind == "tile" and FOLD_BN0_BOTH) or (kind == "small" and FOLD_BN0_EARLY)
             if fused:
                 c0 = ops.bn_bwd_coeffs(part0, M, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training)
                 if not fold and not fold2:

@@ -239,20 +239,31 @@ def pw_dgrad_bnbwd_planes(G, X, coef, planes, N_in, *, residual=None):
 
 
 def bnbwd_fold_takes(M, K, N):
-    """Can BOTH consumers of dZ [M, K] (data gradient against W^T [N, K], weight gradient dW [K, N]) fold the BatchNorm backward
-    apply in the current arithmetic?"""
+    """Which weight-gradient kernel can fold the BatchNorm backward apply for dZ [M, K] (data gradient against W^T [N, K], weight
+    gradient dW [K, N]) in the current arithmetic, given that the data gradient takes the planes kernel: "small" (the HBM-bound
+    small-output kernel of stages 1-2), "tile" (the split-arithmetic tiled kernel) or None."""
     key = ("fold", get_gemm_mode(), M, K, N)
-    r = _uses_planes.get(key)
-    if r is None:
-        r = _uses_planes[key] = bool(_planes_take(M, K, N) and lib().mx_pw_wgrad_tile_bnbwd_ok(M, K, N)
-                                     and lib().mx_pw_wgrad_small_ws(M, K, N, PLAIN) <= 0)
+    r = _uses_planes.get(key, 0)
+    if r == 0:
+        r = None
+        if _planes_take(M, K, N):
+            if lib().mx_pw_wgrad_small_bnbwd_ok(M, K, N):
+                r = "small"
+            elif lib().mx_pw_wgrad_small_ws(M, K, N, PLAIN) <= 0 and lib().mx_pw_wgrad_tile_bnbwd_ok(M, K, N):
+                r = "tile"
+        _uses_planes[key] = r
     return r
 
 
 def pw_wgrad_bnbwd(G, G2, coef, X, dW):
-    """dW[Co, Ci] += (c1*G + c2*G2 + c3)[R, Co]^T X[R, Ci] (split-arithmetic tiled kernel only: bnbwd_fold_takes)."""
+    """dW[Co, Ci] += (c1*G + c2*G2 + c3)[R, Co]^T X[R, Ci] through the kernel bnbwd_fold_takes names."""
     R, Co = G.shape
     Ci = X.shape[1]
+    if lib().mx_pw_wgrad_small_bnbwd_ok(R, Co, Ci):
+        need = lib().mx_pw_wgrad_small_ws(R, Co, Ci, PLAIN)
+        ws = _wgrad_workspace(G.device, max(need, 16))
+        call("mx_pw_wgrad_small_bnbwd", ptr(G), ptr(G2), ptr(coef), ptr(X), ptr(dW), R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())
+        return
     need = lib().mx_pw_wgrad_tile_ws(R, Co, Ci, PLAIN)
     ws = _wgrad_workspace(G.device, max(need, 16))
     call("mx_pw_wgrad_tile_bnbwd", ptr(G), ptr(G2), ptr(coef), ptr(X), ptr(dW), R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())

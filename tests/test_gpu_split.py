@@ -120,7 +120,8 @@ def test_planes_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, opts):
     assert errs[2] <= 1.5 * errs[1] + 2e-7 * scale_, errs        # ... and as close as the first-generation split kernel
 
 
-@pytest.mark.parametrize("M,K,N,res", [(25088, 960, 160, True), (6272, 2304, 384, False), (3001, 384, 130, True), (700, 1344, 224, False)])
+@pytest.mark.parametrize("M,K,N,res", [(25088, 960, 160, True), (6272, 2304, 384, False), (3001, 384, 130, True), (700, 1344, 224, False),
+                                       (401408, 288, 48, True), (200704, 192, 32, False), (100352 + 37, 288, 48, False)])   # stages 1-2: small-output kernel
 def test_bnbwd_fold_in_both_consumers_matches_fp64(M, K, N, res):
     """The BatchNorm backward apply dZ = c1*G + c2*X + c3 folded into BOTH consumers of dZ (mx_pw_dgrad_bnbwd_planes: the data gradient's
     operand load; mx_pw_wgrad_tile_bnbwd: the weight gradient's G operand) against float64, beside the unfused pair (bn_bwd_apply, then
@@ -142,7 +143,7 @@ def test_bnbwd_fold_in_both_consumers_matches_fp64(M, K, N, res):
     (image,) = plan.run()
     muscle_amd.set_gemm_mode(1)
     try:
-        if not ops.bnbwd_fold_takes(M, K, N):
+        if ops.bnbwd_fold_takes(M, K, N) is None:
             pytest.skip("shape not folded in mode 1")
         dz = ops.bn_bwd_apply_plain(G, X, coef, torch.empty_like(G))
         dx_ref = ops.pw_dgrad(dz, None, N, wt=Wt, planes=image, residual=R)

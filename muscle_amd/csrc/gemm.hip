@@ -999,8 +999,7 @@ template <int TN, int AMODE>
 __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3_kernel(GemmArgs g) {
   constexpr int BM = 128, BN = 16 * TN;
   constexpr int W_PLANE = BN * 64, STAGE = 3 * W_PLANE;
-  constexpr int WPIECES = 3 * BN / 16, WPW = WPIECES / 4;
-  static_assert(WPIECES % 4 == 0, "every wave issues the same number of LDS-DMA loads per stage");
+  constexpr int WPIECES = 3 * BN / 16, WPW = (WPIECES + 3) / 4;   // (uneven shares are fine: every wave waits for all of its own loads)
   static_assert(4 * 2 * BN * 4 <= 2 * STAGE, "statistics staging does not fit");
   __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -1042,7 +1041,8 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
   auto issue_w = [&](int kt) {
     unsigned char* st = smem + (kt & 1) * STAGE;
 #pragma unroll
-    for (int i = 0; i < WPW; ++i) glds16(wsrc[i] + 3 * npad64 * kt, st + wdst[i]);
+    for (int i = 0; i < WPW; ++i)
+      if (WPIECES % 4 == 0 || wave + 4 * i < WPIECES) glds16(wsrc[i] + 3 * npad64 * kt, st + wdst[i]);
   };
   f32x4 raw[2][2];
   f32x4 rawx[AMODE == MX_BNBWD ? 2 : 1][2], cf[AMODE == MX_BNBWD ? 3 : 1][2];
@@ -1196,19 +1196,43 @@ static void launch_nt_split3_t(const GemmArgs& g, int batch, hipStream_t st) {
   else hipLaunchKernelGGL((gemm_nt_split3_kernel<TN, MX_PLAIN>), grid, dim3(256), 0, st, a);
 }
 
-// 128 x 128 or 128 x 64.  Tiles are dealt over 256 CUs: time ~ (tiles per CU + half a tile of tail) x tile width, the 64-wide
-// tile doing 0.85 of the wide tile's work per unit time (measured 0.84-0.96 on the M = 25088 layers); a grid of fewer than
-// ~1.2 wide tiles per CU always takes the narrow tile (M = 6272: 2304 -> 384 108 -> 91 us, M = 12544: 1152 -> 192 61 -> 51).
-static int g_split_nj = getenv("MX_GEMM_SPLIT_NJ") ? atoi(getenv("MX_GEMM_SPLIT_NJ")) : 0;     // 1: force 128 x 64, 2: force 128 x 128
+// Tile width: 128 columns, or 112 / 96 / 80 / 64 where that pads less or balances better.  Tiles are dealt over 256 CUs: time ~
+// (tiles per CU + half a tile of tail) x tile width / efficiency of the width (a narrower tile re-loads and re-splits the same
+// activation rows for fewer columns: 0.85 at 64, measured 0.84-0.96 on the M = 25088 layers); a grid of fewer than ~1.2 wide tiles
+// per CU always takes the 64-wide tile (M = 6272: 2304 -> 384 108 -> 91 us, M = 12544: 1152 -> 192 61 -> 51).  The odd widths are
+// only taken where they divide N (N = 160 = 2 x 80, 224 = 2 x 112, 960 = 10 x 96, 2304 = 24 x 96): no padded columns at all
+// (960 -> 160: 69 us at 64 columns, 55 at 80; 1344 -> 224: 99 at 128, 91 at 112; 480 -> 80 at 100 352 rows: 73 -> 54).
+static int g_split_nj = getenv("MX_GEMM_SPLIT_NJ") ? atoi(getenv("MX_GEMM_SPLIT_NJ")) : 0;     // 1: force 128 x 64, 2: force 128 x 128, 3: 64 / 128 only
 static void launch_nt_split3(const GemmArgs& g, int batch, hipStream_t st) {
   auto cost = [&](int bn, double eff) {
     const double per_cu = (double)cdiv(g.M, 128) * cdiv(g.N, bn) * batch / 256.0;
     return (per_cu + 0.5) * bn / eff;
   };
   const long wide_tiles = (long)cdiv(g.M, 128) * cdiv(g.N, 128) * batch;
-  const bool narrow = g_split_nj ? g_split_nj == 1 : (wide_tiles <= 300 || cost(64, 0.85) < cost(128, 1.0));
-  if (narrow) launch_nt_split3_t<4>(g, batch, st);
-  else launch_nt_split3_t<8>(g, batch, st);
+  int bn = 128;
+  if (g_split_nj >= 16) bn = g_split_nj;                                   // lab: force this width
+  else if (g_split_nj == 1 || (g_split_nj != 2 && wide_tiles <= 300)) bn = 64;
+  else if (g_split_nj != 2) {
+    // short reductions (K <= 512: few K steps per tile, so a tile's fill and epilogue weigh more) reward the widths that run four
+    // workgroups per CU (96 and 80 columns: 112-128 registers, <= 36 KB of LDS): tools/hip/gemm_lab widths,
+    // profiles/r04_gemm_lab_widths.txt - 384 -> 2304: 236 (128) / 216 (96); 224 -> 1344: 97 / 89.5; 160 -> 960: 65 / 57.5
+    const bool shortk = g.K <= 512;
+    const double e64 = shortk ? 0.90 : 0.85, e80 = shortk ? 0.97 : 0.90, e96 = shortk ? 1.03 : 0.94, e112 = 0.97;
+    double best = cost(128, 1.0);
+    if (cost(64, e64) < best) { best = cost(64, e64); bn = 64; }
+    if (g_split_nj != 3) {
+      if (g.N % 112 == 0 && cost(112, e112) < best) { best = cost(112, e112); bn = 112; }
+      if (g.N % 96 == 0 && cost(96, e96) < best) { best = cost(96, e96); bn = 96; }
+      if (g.N % 80 == 0 && cost(80, e80) < best) { best = cost(80, e80); bn = 80; }
+    }
+  }
+  switch (bn) {
+    case 64: launch_nt_split3_t<4>(g, batch, st); break;
+    case 80: launch_nt_split3_t<5>(g, batch, st); break;
+    case 96: launch_nt_split3_t<6>(g, batch, st); break;
+    case 112: launch_nt_split3_t<7>(g, batch, st); break;
+    default: launch_nt_split3_t<8>(g, batch, st); break;
+  }
 }
 
 // tile table of the second-generation NT kernel: {BM, BN}; every entry has 128 rows

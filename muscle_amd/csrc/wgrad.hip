@@ -606,15 +606,15 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     // Row groups of the split kernel.  Standalone, many small work items are fastest (g = 32 at up to ~100 tiles: 1344 x 224 132 ->
     // 118 us; profiles/r04_wgrad_split_groups.txt) - but the weight gradients run on the side stream BESIDE the HBM-bound kernels
     // of the backward chain, and there every extra group is a partial matrix written and read back through the memory system
-    // those kernels live on: in the step g = 8 for every shape is the optimum (B7 / 448 / batch 32, one box: g = 2 / 4 / 6 / 8 /
-    // 16 / 24 / the standalone-best rule: 131.8 / 111.3 / 104.9 / 102.6 / 104.9 / 105.5 / 105.8 ms per step).  Eight = one group
-    // per XCD under the XCD-aware ids.  Shapes with fewer than 40 output tiles (1344 x 224: 22) take 16 (8 / 16 / 24 there:
-    // 101.9 / 101.5 / 101.8 ms per step on a faster box): 176 workgroups leave too many CUs without one.
-    const int tiles = p->tiles_co * p->tiles_ci;
+    // those kernels live on: in the step FEWER groups win (B7 / 448 / batch 32, one box, every shape at g = 2 / 4 / 6 / 8 / 16 / 24 /
+    // the standalone-best rule: 131.8 / 111.3 / 104.9 / 102.6 / 104.9 / 105.5 / 105.8 ms per step).  The floor is set by the
+    // arithmetic, not by speed: a group is ONE fp32 accumulation chain per output element, and the error against fp64 grows with
+    // its length - at g = 8 (3136 rows at R = 25 088, 1568 at 12 544) it is 2.2-2.6x the exact-fp32 tiled kernel's, whose own
+    // groups are short; tests/test_gpu_split.py holds the split kernel to 1.5x.  Sixteen groups (two per XCD under the XCD-aware
+    // ids) keep every tested shape level with the fp32 kernel and are within 0.3 ms per step of g = 8.
     const int maxg = R / 256 > 0 ? R / 256 : 1;
-    static const int small_g = getenv("MX_WGRAD_SPLIT_GROUPS_SMALL") ? atoi(getenv("MX_WGRAD_SPLIT_GROUPS_SMALL")) : 16;
-    int groups = tiles < 40 ? small_g : 8;
-    if (groups > maxg) groups = maxg;
+    int groups = 16;
+    if (groups > maxg) groups = maxg >= 8 ? maxg / 8 * 8 : maxg;
     static const int forced_split = getenv("MX_WGRAD_SPLIT_GROUPS") ? atoi(getenv("MX_WGRAD_SPLIT_GROUPS")) : 0;
     if (forced_split > 0) groups = forced_split < maxg ? forced_split : maxg;
     p->rows_per_group = cdiv(cdiv(R, groups), 32) * 32;

@@ -279,7 +279,39 @@ static void run_chunk(int M, int K, int N) {
   CK(hipFree(planes)); CK(hipFree(table));
 }
 
+// second-generation split kernel: every tile width on one shape (forced through MX_GEMM_SPLIT_NJ's lab values)
+static void run_widths(int M, int K, int N) {
+  float* A = dalloc((long)M * K, 1, 1.f); float* W = dalloc((long)N * K, 2, 0.05f);
+  float* C2 = dalloc((long)M * N, 5, 0.f);
+  float* st2 = dalloc((long)mx_pw_fwd_parts(M, N, K) * 2 * N, 8, 0.f);
+  void* planes; CK(hipMalloc(&planes, mx_pw_planes_bytes(N, K)));
+  long row[5] = {(long)W, (long)planes, N, K, 0};
+  long* table; CK(hipMalloc(&table, sizeof(row))); CK(hipMemcpy(table, row, sizeof(row), hipMemcpyHostToDevice));
+  mx_pw_planes_batch(table, 1, mx_pw_planes_tiles(N, K), nullptr);
+  const int wv[] = {64, 80, 96, 112, 128, 0};
+  float best[6]; for (float& b : best) b = 1e30f;
+  for (int round = 0; round < 3; ++round)
+    for (int i = 0; i < 6; ++i) {
+      if (wv[i] && wv[i] != 64 && wv[i] != 128 && N % wv[i]) continue;
+      g_split_nj = wv[i];
+      best[i] = std::min(best[i], time_us([&] { mx_pw_fwd_planes(A, planes, C2, M, K, N, K, N, nullptr, nullptr, 0, st2, nullptr); }, 5));
+    }
+  g_split_nj = 0;
+  printf("  M=%d K=%d N=%d:", M, K, N);
+  for (int i = 0; i < 6; ++i) if (best[i] < 1e29f) printf("  w%-3d %6.1f", wv[i], best[i]);
+  printf("   (w0 = the library's choice)\n"); fflush(stdout);
+  for (float* p : {A, W, C2, st2}) CK(hipFree(p));
+  CK(hipFree(planes)); CK(hipFree(table));
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "widths")) {
+    static const Shape sh[] = {{25088, 160, 960}, {25088, 960, 160}, {25088, 224, 1344}, {25088, 1344, 224}, {25088, 384, 2304}, {25088, 2304, 384},
+                               {25088, 640, 3840}, {25088, 3840, 640}, {6272, 384, 2304}, {6272, 2304, 384}, {6272, 640, 3840}, {6272, 3840, 640},
+                               {6272, 224, 1344}, {6272, 1344, 224}, {401408, 288, 48}, {100352, 480, 80}, {12544, 192, 1152}, {12544, 1152, 192}};
+    for (const Shape& s : sh) run_widths(s.M, s.K, s.N);
+    return 0;
+  }
   if (argc >= 2 && !strcmp(argv[1], "chunk")) {
     static const Shape sh[] = {{25088, 384, 2304}, {25088, 640, 3840}, {25088, 224, 1344}, {25088, 160, 960}, {25088, 2304, 384}, {25088, 3840, 640}, {6272, 384, 2304}};
     for (const Shape& s : sh) run_chunk(s.M, s.K, s.N);

@@ -435,6 +435,11 @@ __global__ __launch_bounds__(256, (TE * TF >= 16 && XMODE == MX_BNACT) ? 3 : 4) 
 // four 16-byte chunks of a row XOR-ed with (column >> 2) & 3: conflict-free ds_read_b128).  128 x 128 tile, 32-row slabs,
 // one LDS stage (48 KB: 3 workgroups per CU) + register prefetch.  Same (tile, group) decomposition, partial tiles and
 // fixed-order reduce as wgrad_tile_kernel.
+// Round 4 built a second structure in the lab and measured it slower (profiles/r04_wgrad_split2_lab.txt): 16-row slabs, two LDS
+// stages, ONE barrier per slab, a thread owning 8 rows x 2 columns (8-byte loads), the split of slab s + 1 in the same instruction
+// stream as the MFMAs of slab s.  Bit-identical results; at 2 waves per SIMD (175 registers) level with this kernel (317 vs 317 us at
+// 2304 x 384) to 8 % slower (3840 x 640), at 3 waves per SIMD (fragments fetched plane by plane: 144 registers) 10-15 % slower - the
+// barrier now comes every 768 MFMA cycles and the fragment reads sit in front of their MFMAs.  This kernel stays.
 typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
 typedef float wf32x16 __attribute__((ext_vector_type(16)));
 
@@ -583,6 +588,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WtArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
 struct WtPlan { int te, tf, tiles_co, tiles_ci, groups, rows_per_group; };
 
 static int wt_order() {

@@ -601,7 +601,8 @@ extern "C" int mx_get_gemm_mode(void);
 static bool wt_use_split(int Co, int Ci) {
   if (mx_get_gemm_mode() < 1) return false;
   const double eff = ((double)Co / (128.0 * cdiv(Co, 128))) * ((double)Ci / (128.0 * cdiv(Ci, 128)));
-  return mx_get_gemm_mode() == 2 || eff >= 0.8;              // 128 x 128 tiles only: not where they pad much
+  static const double min_eff = getenv("MX_WGRAD_SPLIT_EFF") ? atof(getenv("MX_WGRAD_SPLIT_EFF")) : 0.8;
+  return mx_get_gemm_mode() == 2 || eff >= min_eff;          // 128 x 128 tiles only: not where they pad much
 }
 
 static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
@@ -808,8 +809,11 @@ static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, 
   if (wt_use_split(Co, Ci)) {
     const dim3 grid(8 * cdiv(a.groups, 8) * a.tiles_co * a.tiles_ci);
     a.total = grid.x;
+    // experiment knob: unused dynamic LDS caps the kernel's workgroups per CU (32 KB -> 2 per CU, 64 KB -> 1), leaving wave slots
+    // and registers to the main stream's kernels it runs beside
+    static const int pad = getenv("MX_WGRAD_SPLIT_LDS_PAD") ? atoi(getenv("MX_WGRAD_SPLIT_LDS_PAD")) : 0;
     if (a.G2) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, true>), grid, dim3(256), 0, st, a);
-    else if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, false>), grid, dim3(256), 0, st, a);
+    else if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, false>), grid, dim3(256), pad, st, a);
     else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_split_kernel<MX_BNACT, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_split_kernel<MX_AFFINE, false>), grid, dim3(256), 0, st, a);
   } else if (p.te == 4 && p.tf == 4) wt_launch<4, 4>(a, st);

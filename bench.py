@@ -62,6 +62,7 @@ class GemmTimer:
 
     def __init__(self):
         self.pairs = []       # (event, event, flop of the launch, ran in split arithmetic?)
+        self.shapes = []      # per pair: (entry point, M, N, K) as shape_of() names them
         self.calls = 0        # every mx_* entry point called while the timer is on
         self.dw = []          # (event, event, algorithmic bytes) of the fused depthwise backward: the slowest HBM-bound kernel
         self.on = False
@@ -105,6 +106,7 @@ class GemmTimer:
                 inner(name, *a)
                 e1.record()
                 me.pairs.append((e0, e1, flop, split))
+                me.shapes.append((name, M, N, K))
             elif me.on and name == "mx_dwconv_bwd_fused":
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -132,6 +134,27 @@ class GemmTimer:
             return MFMA_F32_PEAK_TFLOPS, 0.0
         t_ideal = f_split / SPLIT_PEAK_TFLOPS + (f_all - f_split) / MFMA_F32_PEAK_TFLOPS
         return f_all / t_ideal, f_split / f_all
+
+    def table(self, steps):
+        """Per (entry point, shape): launches per step, us per launch, TFLOP/s, and the time the launch's bound allows - the larger of
+        flop / (peak of its pipe) and algorithmic bytes (operands read once, result written once, fp32) / 5 TB/s (what the HBM-bound
+        kernels of this step reach) - so that the ratio names the shapes that are far from THEIR roofline."""
+        agg = {}
+        for (a, b, flop, split), key in zip(self.pairs, self.shapes):
+            e = agg.setdefault(key + (split,), [0, 0.0, flop])
+            e[0] += 1
+            e[1] += a.elapsed_time(b)
+        rows = []
+        for (name, M, N, K, split), (n, ms, flop) in agg.items():
+            by = 4.0 * (M * K + N * K + M * N)
+            t_mfma = flop / ((SPLIT_PEAK_TFLOPS if split else MFMA_F32_PEAK_TFLOPS) * 1e12) * 1e6
+            t_hbm = by / 5e12 * 1e6
+            us = ms * 1e3 / n
+            rows.append({"entry": name, "M": M, "N": N, "K": K, "split": bool(split), "per_step": n / steps, "us": us,
+                         "ms_per_step": ms / steps, "tflops": flop / us / 1e6, "bound": "mfma" if t_mfma > t_hbm else "hbm",
+                         "bound_us": max(t_mfma, t_hbm), "x_bound": us / max(t_mfma, t_hbm)})
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        return rows
 
     def dw_summary(self):
         """Per kernel size of the fused depthwise backward: launches, ms, GB/s of its algorithmic 4 passes."""
@@ -287,6 +310,7 @@ def main():
                     help="GEMM arithmetic of the timed steps (config.arithmetic); the other one is timed as well and reported beside it")
     ap.add_argument("--no-split", "--no-other-arith", dest="no_other", action="store_true",
                     help="skip the extra K steps in the other GEMM arithmetic")
+    ap.add_argument("--gemm-table", default=None, help="write the per-shape table of the pointwise GEMM launches (GemmTimer.table) here")
     ap.add_argument("--no-configs", action="store_true", help="skip the short runs of configs[1] and step-full")
     ap.add_argument("--graph", action="store_true",
                     help="timed steps replay phase 1 from a captured hipGraph (muscle_amd.GraphedStep; one GPU, epoch < 8).  Not "
@@ -398,8 +422,8 @@ def main():
         beside = {"value": a.batch * world * a.steps / dts, "unit": "images/sec", "ms_per_step": dts / a.steps * 1e3,
                   "arithmetic": ARITH_TEXT[other]}
         # the same per-launch events in this arithmetic, so that both roofline fractions are in the line
-        main_pairs, main_dw = timer.pairs, timer.dw
-        timer.pairs, timer.dw = [], []
+        main_pairs, main_dw, main_shapes = timer.pairs, timer.dw, timer.shapes
+        timer.pairs, timer.dw, timer.shapes = [], [], []
         muscle_amd.set_gemm_mode(ARITH_MODE[other])
         engine.WGRAD_SIDE_STREAM = False
         timer.on = (rank == 0)
@@ -418,7 +442,7 @@ def main():
                 beside["roofline"] = {"bound": "mfma", "achieved": o_ach, "peak": o_peak, "unit": "TFLOP/s", "frac": o_ach / o_peak,
                                       "flop_share_split": o_share, "gemm_ms_per_step": o_ms / inst_steps,
                                       "avg_launch_us": o_ms * 1e3 / max(o_n, 1)}
-        timer.pairs, timer.dw = main_pairs, main_dw
+        timer.pairs, timer.dw, timer.shapes = main_pairs, main_dw, main_shapes
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -430,6 +454,19 @@ def main():
 
     imgs = a.batch * world * a.steps
     gemm_ms, gemm_launches = timer.total_ms()
+    if a.gemm_table:
+        rows = timer.table(inst_steps)
+        with open(a.gemm_table, "w") as f:
+            f.write("# pointwise-GEMM launches of one %s step (%s, %dx%d, batch %d), side stream off, HIP events per launch; bound_us = max(flop / "
+                    "pipe peak, fp32 operand + result bytes / 5 TB/s); x_bound = us / bound_us\n" % (a.arith, a.model, a.size, a.size, a.batch))
+            f.write("%-26s %7s %5s %7s %5s %5s %8s %8s %7s %5s %8s %7s\n" % ("entry", "M", "N", "K", "split", "/step", "us", "ms/step", "TFLOP/s",
+                                                                          "bound", "bound_us", "x_bound"))
+            for r in rows:
+                f.write("%-26s %7d %5d %7d %5s %5.1f %8.1f %8.3f %7.1f %5s %8.1f %7.2f\n" % (
+                    r["entry"], r["M"], r["N"], r["K"], "y" if r["split"] else "n", r["per_step"], r["us"], r["ms_per_step"], r["tflops"],
+                    r["bound"], r["bound_us"], r["x_bound"]))
+            f.write("# total %.2f ms/step; at the bounds %.2f ms/step\n" % (sum(r["ms_per_step"] for r in rows),
+                                                                          sum(r["bound_us"] * r["per_step"] for r in rows) / 1e3))
     full = a.epoch >= 12
     flops_img = pointwise_flops_per_image(cfg, a.size)
     if full:

@@ -247,6 +247,13 @@ int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float
               float* dW1, float* db1, float* dW2, float* db2, float* gh, int N, int C,
               int SQ, void* stream);
 
+/* The two halves of mx_se_bwd as separate launches: gh (consumed by mx_bn1_sums_finalize on the data-gradient chain) and the four
+ * parameter gradients (no consumer before the optimizer: the engine queues them beside the weight-gradient GEMMs). */
+int mx_se_bwd_gh(const float* ggate, const float* gate, const float* h, const float* W2, float* gh, int N, int C, int SQ,
+                 void* stream);
+int mx_se_bwd_params(const float* ggate, const float* gate, const float* s, const float* h, const float* gh, float* dW1, float* db1,
+                     float* dW2, float* db2, int N, int C, int SQ, void* stream);
+
 /* out[(n,oy,ox), ci*9+ky*3+kx] = img[n,ci,oy*2-pad+ky,ox*2-pad+kx] (NCHW image), rows of 28 floats (27 + 0) */
 int mx_stem_im2col(const float* img, float* out, int N, int H, int W, int Ho, int Wo, int pad_lo, void* stream);
 

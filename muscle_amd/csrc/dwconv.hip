@@ -430,6 +430,16 @@ struct DwFusedArgs {
 //   14 x 28, PX 7 - four passes of groups per thread; 72 KB for 5x5 (2 workgroups per CU).  B7's stride-1 layers are 224 / 112 / 56 /
 //                   28 pixels wide: 28 = 2 x 14 rows x 1 x 28 columns EXACTLY, where 8 x 16 tiles cover 32 x 32 (1.31x the pixels) and stage
 //                   8 x 240 elements for 784 outputs (2.45x); 14 x 28 stages 2 x 576 (1.47x): -40 % staging work and dA / D reads.
+#ifndef MX_DW_STAGE_MAX
+#define MX_DW_STAGE_MAX 4
+#endif
+// float4 pairs (dA, d) a thread has in flight per staging chunk: the largest divisor of its share of the tile up to MX_DW_STAGE_MAX
+constexpr int dw_stage_depth(int per, int th) {
+  int best = 1;
+  for (int c = 2; c <= (th == 8 ? 4 : MX_DW_STAGE_MAX); ++c) if (per % c == 0) best = c;   // (8 x 16 at 3 waves per SIMD spills above 4)
+  return best;
+}
+
 template <int K, int TH, int TW, int PX>
 __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused_kernel(DwFusedArgs a) {
   // Only dd is staged with its halo.  The weight gradient is taken over INPUT pixels,
@@ -439,7 +449,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
   // factor and the BN0 sums of the epilogue, and the dW and dX loops walk the SAME shifted dd rows, so every LDS read
   // feeds both.  One staged array instead of two (round 1 PMC: the two-array kernel sat at SQ_WAIT_ANY 45-60 %, 1.5-1.9 TB/s).
   constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256;
-  constexpr int CH = (PER % 4 == 0) ? 4 : (PER % 3 == 0) ? 3 : 2;
+  constexpr int CH = dw_stage_depth(PER, TH);
   static_assert(PER % CH == 0, "staging chunks");
   __shared__ float4 td[TOT];     // dd with halo; at the end the per-wave partial rows of dW and of the BN0 sums
   static_assert(TOT * 4 >= 4 * K * K * CB, "the per-wave partial rows reuse the staged tile");

@@ -955,7 +955,7 @@ static __device__ __forceinline__ void glds16(const void* src, void* lds_wave_ba
                                    (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
-// pre-split image of a weight matrix W[N][K] (K % 32 == 0): planes[((kt * 3 + p) * Npad + n) * 64 + c' * 16 + 2 e] =
+// pre-split image of a weight matrix W[N][K] (K % 32 == 0 or 16: a half K step at the end is filled with zeros): planes[((kt * 3 + p) * Npad + n) * 64 + c' * 16 + 2 e] =
 // bf16 term p of W[n][32 kt + 4 c + (e < 4 ? e : 12 + e)] with c = c' ^ swz_w(n) (chunk c = k 4c..4c+3 and 16+4c..16+4c+3 of
 // the K step: the order gemm_nt_split3_kernel's lanes load the activations in); rows n >= N zero; Npad = N rounded up to 128
 // table: rows of 5 longs {src, dst, N, K, first_tile}; a tile = (K step, group of 64 rows) -> Npad/64 * K/32 tiles per matrix
@@ -977,7 +977,7 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const long* __restric
   unsigned h[4] = {0, 0, 0, 0}, m[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0};
   if (n < N) {
     const float* s = src + (long)n * K + 32 * kt + 4 * c;
-    const float4 x0 = ld4(s), x1 = ld4(s + 16);
+    const float4 x0 = ld4(s), x1 = (32 * kt + 16 < K) ? ld4(s + 16) : make_float4(0.f, 0.f, 0.f, 0.f);
     split3_pair(x0.x, x0.y, h[0], m[0], l[0]);
     split3_pair(x0.z, x0.w, h[1], m[1], l[1]);
     split3_pair(x1.x, x1.y, h[2], m[2], l[2]);
@@ -1021,7 +1021,8 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
   const float* A = g.a.p + zb * g.sa;
   const unsigned char* WP = reinterpret_cast<const unsigned char*>(g.b.p);
   float* C = g.c + zb * g.sc;
-  const int nk = g.K >> 5;
+  const int nk = (g.K + 31) >> 5;
+  const bool ktail = (g.K & 31) != 0;        // K % 32 == 16: the last step's second half is zero in the image and is not loaded here
   const long npad64 = (long)g.ldb * 64;
 
   const float* ap[2];
@@ -1048,10 +1049,11 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
   f32x4 rawx[AMODE == MX_BNBWD ? 2 : 1][2], cf[AMODE == MX_BNBWD ? 3 : 1][2];
   const long xoff = AMODE == MX_BNBWD ? (g.a.rowp + zb * g.sa) - A : 0;      // X[r][k] sits xoff floats from G[r][k]
   auto load_a = [&](int kt) {
+    const bool half = AMODE != MX_BNBWD && ktail && kt == nk - 1;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       raw[i][0] = *reinterpret_cast<const f32x4*>(ap[i] + 32 * kt);
-      raw[i][1] = *reinterpret_cast<const f32x4*>(ap[i] + 32 * kt + 16);
+      raw[i][1] = half ? f32x4{0.f, 0.f, 0.f, 0.f} : *reinterpret_cast<const f32x4*>(ap[i] + 32 * kt + 16);
       if (AMODE == MX_BNBWD) {
         rawx[AMODE == MX_BNBWD ? i : 0][0] = *reinterpret_cast<const f32x4*>(ap[i] + xoff + 32 * kt);
         rawx[AMODE == MX_BNBWD ? i : 0][1] = *reinterpret_cast<const f32x4*>(ap[i] + xoff + 32 * kt + 16);
@@ -1430,16 +1432,16 @@ int mx_transpose(const float* src, float* dst, int rows, int cols, void* stream)
 }
 
 // ---- pre-split weight planes --------------------------------------------------------------------------------------
-// bytes of the image mx_pw_planes writes for a weight W[N][K]; MX_EARG when the shape has none (K % 32 != 0)
+// bytes of the image mx_pw_planes writes for a weight W[N][K]; MX_EARG when the shape has none (K % 32 is neither 0 nor 16)
 long mx_pw_planes_bytes(int N, int K) {
-  if (N <= 0 || K <= 0 || K % 32) return MX_EARG;
-  return (long)((N + 127) & ~127) * K * 6;
+  if (N <= 0 || K <= 0 || K % 16) return MX_EARG;
+  return (long)((N + 127) & ~127) * ((K + 31) & ~31) * 6;
 }
 
 // number of workgroups (tiles) mx_pw_planes_batch needs for one matrix
 int mx_pw_planes_tiles(int N, int K) {
-  if (N <= 0 || K <= 0 || K % 32) return MX_EARG;
-  return (((N + 127) & ~127) / 64) * (K / 32);
+  if (N <= 0 || K <= 0 || K % 16) return MX_EARG;
+  return (((N + 127) & ~127) / 64) * ((K + 31) / 32);
 }
 
 // n weight matrices in one launch.  table: DEVICE array of n rows of 5 longs {src W[N][K] fp32, dst image, N, K, first_tile};
@@ -1455,7 +1457,11 @@ int mx_pw_planes_batch(const long* table, int n, int total_tiles, void* stream) 
 int mx_pw_fwd_uses_planes(int M, int K, int N) {
   static const int on = getenv("MX_SPLIT2") ? atoi(getenv("MX_SPLIT2")) : 1;
   static const int early = getenv("MX_SPLIT3_EARLY") ? atoi(getenv("MX_SPLIT3_EARLY")) : 1;
-  if (!on || M <= 0 || K % 32) return 0;
+  static const int tail = getenv("MX_SPLIT3_KTAIL") ? atoi(getenv("MX_SPLIT3_KTAIL")) : 1;
+  if (!on || M <= 0 || K % 16) return 0;
+  // K = 48 / 80 (the expand convolutions of stages 2-3 and the project data gradients beside them, 0.1-0.4 M rows): HBM-bound, and
+  // the second-generation kernel's register-direct activation stream wins there as well; the half K step it pads costs MFMA time only
+  if (K % 32) return (g_gemm_mode != 0 && tail && K >= 48 && N >= 96) ? 1 : 0;
   if (nt_uses_split(N, K)) return 1;
   // the HBM-bound data gradients of stages 2-3 (K = 288 -> 48 at 401 408 rows, 480 -> 80 at 100 352): the second-generation
   // kernel streams their long operand straight into registers and beats the exact-fp32 kernel there too (137 -> 127 us,
@@ -1468,7 +1474,7 @@ int mx_pw_fwd_uses_planes(int M, int K, int N) {
 int mx_pw_fwd_planes(const float* A, const void* Wplanes, float* C, int M, int K, int N, int lda, int ldc,
                      const float* bias, const float* residual, int relu, float* stats, void* stream) {
   MX_CHECK_ARG(A && Wplanes && C, "pw_fwd_planes: null pointer");
-  MX_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 32 == 0, "pw_fwd_planes: bad extents M=%d N=%d K=%d (K must be a multiple of 32)", M, N, K);
+  MX_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 16 == 0, "pw_fwd_planes: bad extents M=%d N=%d K=%d (K must be a multiple of 16)", M, N, K);
   MX_CHECK_ARG(lda % 4 == 0 && lda >= K && ldc >= N, "pw_fwd_planes: bad leading dimensions lda=%d ldc=%d", lda, ldc);
   MX_CHECK_ARG((((uintptr_t)A | (uintptr_t)Wplanes | (uintptr_t)C) & 15) == 0, "pw_fwd_planes: pointers must be 16-byte aligned");
   GemmArgs g{};

@@ -183,23 +183,38 @@ int mx_se_fwd(const float* pooled_sum, float inv_hw, const float* W1, const floa
   return MX_OK;
 }
 
-int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W2,
-              float* dW1, float* db1, float* dW2, float* db2, float* gh, int N, int C,
-              int SQ, void* stream) {
-  MX_CHECK_ARG(ggate && gate && s && h && W2 && dW1 && db1 && dW2 && db2, "se_bwd: null pointer");
-  MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd: bad extents N=%d C=%d SQ=%d", N, C, SQ);
-  MX_CHECK_ARG(gh != nullptr, "se_bwd: gh [N*SQ] required");
-
-  size_t shb = (size_t)2 * N * SE_JB * sizeof(float);
-  MX_CHECK_ARG(shb <= 48 * 1024, "se_bwd: N=%d too large for LDS staging", N);
+int mx_se_bwd_gh(const float* ggate, const float* gate, const float* h, const float* W2, float* gh, int N, int C, int SQ,
+                 void* stream) {
+  MX_CHECK_ARG(ggate && gate && h && W2 && gh, "se_bwd_gh: null pointer");
+  MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd_gh: bad extents N=%d C=%d SQ=%d", N, C, SQ);
   if (SQ % 4 == 0 && ((uintptr_t)W2 & 15) == 0)
     hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 16)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh, C, SQ);
   else
     hipLaunchKernelGGL(se_bwd_a1_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh, C, SQ);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+int mx_se_bwd_params(const float* ggate, const float* gate, const float* s, const float* h, const float* gh, float* dW1, float* db1,
+                     float* dW2, float* db2, int N, int C, int SQ, void* stream) {
+  MX_CHECK_ARG(ggate && gate && s && h && gh && dW1 && db1 && dW2 && db2, "se_bwd_params: null pointer");
+  MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd_params: bad extents N=%d C=%d SQ=%d", N, C, SQ);
+  size_t shb = (size_t)2 * N * SE_JB * sizeof(float);
+  MX_CHECK_ARG(shb <= 48 * 1024, "se_bwd_params: N=%d too large for LDS staging", N);
   hipLaunchKernelGGL(se_bwd_b_kernel, dim3(cdiv(C, 256), cdiv(SQ, SE_JB)), dim3(256), shb, (hipStream_t)stream, ggate, gate, s, h, gh,
                      dW1, db1, dW2, db2, N, C, SQ);
   MX_LAUNCH_CHECK();
   return MX_OK;
+}
+
+int mx_se_bwd(const float* ggate, const float* gate, const float* s, const float* h, const float* W2,
+              float* dW1, float* db1, float* dW2, float* db2, float* gh, int N, int C,
+              int SQ, void* stream) {
+  MX_CHECK_ARG(dW1 && db1 && dW2 && db2 && s, "se_bwd: null pointer");
+  MX_CHECK_ARG(N > 0 && (size_t)2 * N * SE_JB * sizeof(float) <= 48 * 1024, "se_bwd: N=%d too large for LDS staging", N);
+  int rc = mx_se_bwd_gh(ggate, gate, h, W2, gh, N, C, SQ, stream);
+  if (rc != MX_OK) return rc;
+  return mx_se_bwd_params(ggate, gate, s, h, gh, dW1, db1, dW2, db2, N, C, SQ, stream);
 }
 
 int mx_stem_im2col(const float* img, float* out, int N, int H, int W, int Ho, int Wo, int pad_lo, void* stream) {

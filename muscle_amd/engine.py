@@ -22,6 +22,7 @@ With save=False (no backward will follow) every tensor only backward would read 
 """
 from __future__ import annotations
 
+import functools
 import os
 
 from dataclasses import dataclass, field
@@ -429,6 +430,23 @@ def _masked_stream(device, n_cus: int):
 # otherwise take wave slots on every CU and the small latency-bound kernels of the main chain queue behind them
 # (profiles/r02_b_timeline.txt: se_bwd_b 134.9 us instead of 25.7 under overlap).
 WGRAD_CUS = int(os.environ.get("MUSCLE_WGRAD_CUS", "0"))
+# SE excitation parameter gradients (se_bwd_b) on the side stream instead of the data-gradient chain
+SE_PARAMS_ASIDE = os.environ.get("MUSCLE_SE_PARAMS_ASIDE", "0") != "0"     # measured 0.6 ms per step SLOWER (profiles/r04_knob_sweep.txt)
+# Priority of the weight-gradient side stream: 0 = as the main stream, -1 = higher, 1 = LOWER (a raw HIP stream: torch only offers -1 / 0)
+WGRAD_PRIO = int(os.environ.get("MUSCLE_WGRAD_PRIO", "0"))
+
+
+def _low_priority_stream(device, prio: int):
+    """A HIP stream of priority `prio` > 0 (LOWER than the default streams; torch.cuda.Stream clamps to [-1, 0]), wrapped for torch.
+    hipDeviceGetStreamPriorityRange on MI355X: least = 1, greatest = -1."""
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipStreamCreateWithPriority(ctypes.byref(handle), ctypes.c_uint(1), ctypes.c_int(int(prio)))      # hipStreamNonBlocking
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipStreamCreateWithPriority failed (hipError {rc})")
+    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 class _WgradLane:
@@ -441,8 +459,10 @@ class _WgradLane:
             if key not in _side_streams:
                 if WGRAD_CUS > 0:
                     _side_streams[key] = _masked_stream(device, WGRAD_CUS)
+                elif WGRAD_PRIO > 0:
+                    _side_streams[key] = _low_priority_stream(device, WGRAD_PRIO)
                 else:
-                    _side_streams[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MUSCLE_WGRAD_PRIO", "0")))
+                    _side_streams[key] = torch.cuda.Stream(device=device, priority=WGRAD_PRIO)
             self.s = _side_streams[key]
 
     def wgrad_bnbwd(self, G, G2, coef, X, dW):
@@ -456,6 +476,12 @@ class _WgradLane:
         if self.s is None:
             return ops.dw_parts_reduce(scratch, dW)
         self.pending.append((scratch, None, dW, {"_dwreduce": True}))
+
+    def defer(self, fn, *tensors):
+        """Queue any launch whose results nothing reads before the optimizer (`tensors` = its operands, kept alive until join())."""
+        if self.s is None:
+            return fn()
+        self.pending.append((tensors, None, None, {"_fn": fn}))
 
     def wgrad(self, G, X, dW, **kw):
         """Queue dW += G^T X'.  It is launched by the next flush(), i.e. right after the data-gradient GEMM of the same
@@ -471,7 +497,9 @@ class _WgradLane:
         self.s.wait_stream(torch.cuda.current_stream())     # operands ready, the data-gradient GEMM done
         with torch.cuda.stream(self.s):
             for G, X, dW, kw in self.pending:
-                if "_dwreduce" in kw:
+                if "_fn" in kw:
+                    kw["_fn"]()
+                elif "_dwreduce" in kw:
                     ops.dw_parts_reduce(G, dW)
                 elif "_bnbwd" in kw:
                     ops.pw_wgrad_bnbwd(G, kw["_bnbwd"][0], kw["_bnbwd"][1], X, dW)
@@ -537,9 +565,18 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         # sums; the excitation backward then gives the pooled-path term `add`, and the BN1 sums follow without
         # touching the big tensors again.
         pooled5 = ops.se_bn1_pool(ga, d2, t.bn1, hw)
-        gh = ops.se_bwd(pooled5[0], t.gate, t.s, t.h, m._se_expand.weight.view(b.cexp, b.se),
-                        sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
-                        sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias))
+        W2 = m._se_expand.weight.view(b.cexp, b.se)
+        if SE_PARAMS_ASIDE:
+            # the excitation's parameter gradients have no consumer on this chain: beside the weight-gradient GEMMs
+            gh = ops.se_bwd_gh(pooled5[0], t.gate, t.h, W2)
+            lane.defer(functools.partial(ops.se_bwd_params, pooled5[0], t.gate, t.s, t.h, gh,
+                                         sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
+                                         sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias)),
+                       pooled5, t.gate, t.s, t.h, gh)
+        else:
+            gh = ops.se_bwd(pooled5[0], t.gate, t.s, t.h, W2,
+                            sink.of(m._se_reduce.weight).view(b.se, b.cexp), sink.of(m._se_reduce.bias),
+                            sink.of(m._se_expand.weight).view(b.cexp, b.se), sink.of(m._se_expand.bias))
         # pooled-path gradient `add`, the BN1 backward sums and their finalisation: one launch, no second pass over the tensors
         c1, add = ops.bn1_coeffs(pooled5, t.gate, gh, m._se_reduce.weight.view(b.se, b.cexp), 1.0 / hw, Mo, m._bn1, t.bn1,
                                  sink.of(m._bn1.weight), sink.of(m._bn1.bias), training)

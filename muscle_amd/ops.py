@@ -562,6 +562,21 @@ def se_bwd(ggate, gate, s, h, W2, dW1, db1, dW2, db2):
     return gh
 
 
+def se_bwd_gh(ggate, gate, h, W2):
+    """First half of se_bwd: gh alone (the data-gradient chain needs nothing else of the excitation backward)."""
+    N, C = ggate.shape
+    gh = torch.empty_like(h)
+    call("mx_se_bwd_gh", ptr(ggate), ptr(gate), ptr(h), ptr(W2), ptr(gh), N, C, W2.shape[1], stream())
+    return gh
+
+
+def se_bwd_params(ggate, gate, s, h, gh, dW1, db1, dW2, db2):
+    """Second half of se_bwd: the parameter gradients (+=), which nothing reads before the optimizer."""
+    N, C = ggate.shape
+    call("mx_se_bwd_params", ptr(ggate), ptr(gate), ptr(s), ptr(h), ptr(gh), ptr(dW1), ptr(db1), ptr(dW2), ptr(db2), N, C,
+         h.shape[1], stream())
+
+
 def stem_im2col(img, Ho, Wo, pad_lo):
     N, _, H, W = img.shape
     out = _f32(N * Ho * Wo, 28, device=img.device)

@@ -78,7 +78,8 @@ def test_split_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, mode, opts):
 
 @pytest.mark.parametrize("M,K,N,opts", [
     (25088, 384, 2304, "stats"), (6272, 2304, 384, "stats+res"), (777, 640, 21, "bias+relu"), (3001, 64, 48, "res"),
-    (12544, 224, 1344, "stats"), (4096, 1344, 224, "res+stats"), (130, 160, 200, ""), (128, 32, 128, "stats"), (1, 96, 130, "bias")])
+    (12544, 224, 1344, "stats"), (4096, 1344, 224, "res+stats"), (130, 160, 200, ""), (128, 32, 128, "stats"), (1, 96, 130, "bias"),
+    (50176, 48, 288, "stats"), (25088 + 5, 80, 480, "stats+res"), (1000, 48, 96, "bias"), (401408, 48, 288, "")])     # K % 32 == 16: half a K step of zeros
 def test_planes_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, opts):
     """Second-generation split kernel (mx_pw_fwd_planes: weight planes split once, LDS-DMA, activations straight to registers,
     16x16x32 MFMA) against fp64, beside the exact-fp32 kernel and the first-generation split kernel on the same inputs; ragged

@@ -430,6 +430,13 @@ struct DwFusedArgs {
 //   14 x 28, PX 7 - four passes of groups per thread; 72 KB for 5x5 (2 workgroups per CU).  B7's stride-1 layers are 224 / 112 / 56 /
 //                   28 pixels wide: 28 = 2 x 14 rows x 1 x 28 columns EXACTLY, where 8 x 16 tiles cover 32 x 32 (1.31x the pixels) and stage
 //                   8 x 240 elements for 784 outputs (2.45x); 14 x 28 stages 2 x 576 (1.47x): -40 % staging work and dA / D reads.
+// an optimisation barrier on one float2 (kept as a 64-bit register pair, so v_pk_* survives): the value is materialised HERE
+__device__ __forceinline__ void pin2(float2& v) {
+  double d = __builtin_bit_cast(double, v);
+  asm volatile("" : "+v"(d));
+  v = __builtin_bit_cast(float2, d);
+}
+
 #ifndef MX_DW_STAGE_MAX
 #define MX_DW_STAGE_MAX 4
 #endif
@@ -448,10 +455,14 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
   // straight into registers (1.0x instead of the halo's 1.9x, no LDS), reuses the raw values for the swish'(bn0(x))
   // factor and the BN0 sums of the epilogue, and the dW and dX loops walk the SAME shifted dd rows, so every LDS read
   // feeds both.  One staged array instead of two (round 1 PMC: the two-array kernel sat at SQ_WAIT_ANY 45-60 %, 1.5-1.9 TB/s).
-  constexpr int IH = TH + K - 1, IW = TW + K - 1, TOT = IH * IW * C4B, PER = (TOT + 255) / 256;
+  // ROWS (28-pixel-wide tiles): the staged rows are pitched at 32 pixels, so that the 256 threads' float4s of one staging pass are
+  // exactly one tile row - row index wave-uniform (scalar address part, scalar bounds), column fixed per thread for the whole tile
+  constexpr bool ROWS = (TW == 28);
+  constexpr int IH = TH + K - 1, IW = TW + K - 1, IWP = ROWS ? 32 : IW, TOT = IH * IWP * C4B, PER = (TOT + 255) / 256;
+  static_assert(!ROWS || (IW <= 32 && PER == IH && 256 / C4B == 32), "one padded tile row per staging pass");
   constexpr int CH = dw_stage_depth(PER, TH);
   static_assert(PER % CH == 0, "staging chunks");
-  __shared__ float4 td[TOT];     // dd with halo; at the end the per-wave partial rows of dW and of the BN0 sums
+  __shared__ float4 td[TOT + C4B];     // dd with halo (+ one pixel of zeros: the masked eighth slot of an odd PX reads past the last row); at the end the per-wave partial rows of dW and of the BN0 sums
   static_assert(TOT * 4 >= 4 * K * K * CB, "the per-wave partial rows reuse the staged tile");
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
   __shared__ __attribute__((aligned(16))) float cst[9 * CB];   // a1 b1 c1 c2 c3 a0 b0 | gate add (per tile)
@@ -484,6 +495,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
   const int cc2 = c0 + 2 * c2;
   const bool cok2 = cc2 < a.C;
   const bool has_bn0 = a.a0 != nullptr;
+  if (tid < C4B) td[TOT + tid] = make_float4(0.f, 0.f, 0.f, 0.f);
   // weights wl[tap][CB]
   for (int i = tid; i < K * K * CB; i += 256) {
     int cc = i % CB, tap = i / CB;
@@ -499,13 +511,16 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
 #pragma unroll
   for (int t = 0; t < K * K; ++t) part[t] = make_float2(0, 0);
   float2 s0 = make_float2(0, 0), s1 = s0;
-  // this thread's centre pixels of X (raw) for one group: clamped addresses, masked at use
+  // this thread's centre pixels of X (raw) for one group: clamped addresses, masked at use.  One 64-bit row base; the pixel
+  // offsets are 32-bit (a row of one sample is far below 2^31 floats) and advance by C with a clamp at the last column
   auto load_x = [&](float2 (&xr)[PX], int n, int oy, int oxb) {
-    const int oyc = min(oy, a.H - 1);
+    const float* row = a.x + (((long)n * a.H + min(oy, a.H - 1)) * a.W) * a.C + (cok2 ? cc2 : 0);
+    const int last = (a.W - 1) * a.C;
+    int off = min(oxb, a.W - 1) * a.C;
 #pragma unroll
     for (int o = 0; o < PX; ++o) {
-      const int oxc = min(oxb + o, a.W - 1);
-      xr[o] = *reinterpret_cast<const float2*>(a.x + (((long)n * a.H + oyc) * a.W + oxc) * a.C + (cok2 ? cc2 : 0));
+      xr[o] = *reinterpret_cast<const float2*>(row + off);
+      off = min(off + a.C, last);
     }
   };
   for (long t = t_beg; t < t_end; ++t) {
@@ -522,46 +537,80 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
     float2 xr[PX];
     load_x(xr, n, oy0 + pq / GX, ox0 + (pq % GX) * PX);
     __syncthreads();
-    // stage dd, CH float4 pairs in flight per thread
-#pragma unroll 1
-    for (int k0 = 0; k0 < PER; k0 += CH) {
-      asm volatile("" ::: "memory");   // keep the constant reloads inside the loop
-      float4 vg[CH], vd[CH];
-      unsigned okm = 0;
-      // branch-free: out-of-image / out-of-range elements read a clamped (valid) address and are multiplied by 0
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        int i = min(tid + 256 * (k0 + k), TOT - 1), pix = i / C4B;
-        int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
-        okm |= (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cok) ? (1u << k) : 0u;
-        iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1);
-        const long off = (((long)n * a.H + iy) * a.W + ix) * a.C + (cok ? c : 0);
-        vg[k] = ld4(a.dA + off); vd[k] = ld4(a.d + off);
-      }
-      const float4 A1 = ld4(cst + 4 * c4), B1 = ld4(cst + CB + 4 * c4), C1 = ld4(cst + 2 * CB + 4 * c4),
-                   C2 = ld4(cst + 3 * CB + 4 * c4), C3 = ld4(cst + 4 * CB + 4 * c4),
-                   G = ld4(cst + 7 * CB + 4 * c4), AD = ld4(cst + 8 * CB + 4 * c4);
-#pragma unroll
-      for (int k = 0; k < CH; ++k) {
-        const int i = min(tid + 256 * (k0 + k), TOT - 1);   // duplicates of the last element rewrite the same value
-        float4 dd;
-        const float okf = ((okm >> k) & 1u) ? 1.f : 0.f;
+    // stage dd, CH float4 pairs in flight per thread; out-of-image / out-of-range elements read a clamped (valid) address and
+    // are multiplied by 0
 #define DD1(f) dd.f = okf * (C1.f * ((vg[k].f * G.f + AD.f) * swish_gradf_(A1.f * vd[k].f + B1.f)) + C2.f * vd[k].f + C3.f);
-        DD1(x) DD1(y) DD1(z) DD1(w)
-#undef DD1
-        td[i] = dd;
+    if constexpr (ROWS) {
+      const int col = tid / C4B, ix = ix0 + col;
+      const float colf = (col < IW && ix >= 0 && ix < a.W && cok) ? 1.f : 0.f;     // (columns IW..31 of the pitch are stored as zeros)
+      const int voff = min(max(ix, 0), a.W - 1) * a.C + (cok ? c : 0);
+#pragma unroll 1
+      for (int r0 = 0; r0 < IH; r0 += CH) {
+        asm volatile("" ::: "memory");   // keep the constant reloads inside the loop
+        float4 vg[CH], vd[CH];
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const long rb = (((long)n * a.H + min(max(iy0 + r0 + k, 0), a.H - 1)) * a.W) * a.C;     // wave-uniform
+          vg[k] = ld4(a.dA + rb + voff); vd[k] = ld4(a.d + rb + voff);
+        }
+        const float4 A1 = ld4(cst + 4 * c4), B1 = ld4(cst + CB + 4 * c4), C1 = ld4(cst + 2 * CB + 4 * c4),
+                     C2 = ld4(cst + 3 * CB + 4 * c4), C3 = ld4(cst + 4 * CB + 4 * c4),
+                     G = ld4(cst + 7 * CB + 4 * c4), AD = ld4(cst + 8 * CB + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int iy = iy0 + r0 + k;
+          const float okf = (iy >= 0 && iy < a.H) ? colf : 0.f;
+          float4 dd;
+          DD1(x) DD1(y) DD1(z) DD1(w)
+          td[(r0 + k) * 256 + tid] = dd;
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int k0 = 0; k0 < PER; k0 += CH) {
+        asm volatile("" ::: "memory");   // keep the constant reloads inside the loop
+        float4 vg[CH], vd[CH];
+        unsigned okm = 0;
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          int i = min(tid + 256 * (k0 + k), TOT - 1), pix = i / C4B;
+          int iy = iy0 + pix / IW, ix = ix0 + pix % IW;
+          okm |= (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W && cok) ? (1u << k) : 0u;
+          iy = min(max(iy, 0), a.H - 1); ix = min(max(ix, 0), a.W - 1);
+          const long off = (((long)n * a.H + iy) * a.W + ix) * a.C + (cok ? c : 0);
+          vg[k] = ld4(a.dA + off); vd[k] = ld4(a.d + off);
+        }
+        const float4 A1 = ld4(cst + 4 * c4), B1 = ld4(cst + CB + 4 * c4), C1 = ld4(cst + 2 * CB + 4 * c4),
+                     C2 = ld4(cst + 3 * CB + 4 * c4), C3 = ld4(cst + 4 * CB + 4 * c4),
+                     G = ld4(cst + 7 * CB + 4 * c4), AD = ld4(cst + 8 * CB + 4 * c4);
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+          const int i = min(tid + 256 * (k0 + k), TOT - 1);   // duplicates of the last element rewrite the same value
+          float4 dd;
+          const float okf = ((okm >> k) & 1u) ? 1.f : 0.f;
+          DD1(x) DD1(y) DD1(z) DD1(w)
+          td[i] = dd;
+        }
       }
     }
+#undef DD1
     __syncthreads();
     // Compute: a thread owns 2 channels x PX consecutive pixels of one tile row per pass (4 channels x 4 pixels needs 100
     // accumulator VGPRs for K=5 and the allocator then spills; 2 x 8 needs 50 and keeps v_pk_fma_f32 over the channel pair).
     // Row ky of the kernel pairs this pixel row with dd row pyl + K-1-ky of the halo tile, for the weight gradient
-    // (times act(X) of the centre pixel) and for the data gradient (times the flipped weight) alike.  The pixel loop is
-    // a real loop over halves (QX pixels each): fully unrolled, the scheduler hoists every LDS read to the top and the
-    // kernel drops below its occupancy target or spills.
+    // (times act(X) of the centre pixel) and for the data gradient (times the flipped weight) alike.  The pixels go in two
+    // halves of QX (each half: taps, then its own epilogue and stores - no accumulator survives a half), both unrolled, so
+    // every register index and every LDS offset is a constant and the odd PX's eighth slot is never computed; scheduling
+    // barriers keep the halves and the kernel rows apart (hoisted together their LDS reads spill).
     const float2* td2 = reinterpret_cast<const float2*>(td);
     const float2 A0 = *reinterpret_cast<const float2*>(cst + 5 * CB + 2 * c2), B0 = *reinterpret_cast<const float2*>(cst + 6 * CB + 2 * c2);
-    constexpr int QX = (PX + 1) / 2;               // pixels per half; an odd PX leaves the last slot of the second half masked
+#ifndef MX_DW_NH
+#define MX_DW_NH 1
+#endif
+    constexpr int NH = MX_DW_NH;                   // the PX pixels go in NH parts of QX
+    constexpr int QX = (PX + NH - 1) / NH;
+    constexpr bool UNROLL_H = true;
+    constexpr int HU = NH;
 #pragma unroll 1
     for (int gi = 0; gi < NG; ++gi) {
       const int grp = pq + 16 * gi;
@@ -573,79 +622,107 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
         const int g2 = min(grp + 16, NGRP - 1);
         load_x(xn, n, oy0 + g2 / GX, ox0 + (g2 % GX) * PX);
       }
-      // sig: sigma(bn0(x)) of the centre pixels, evaluated ONCE (act and swish' both use it) where the register budget has
-      // room for it (2 waves per SIMD); the 3-wave 3x3 / 8 x 16 variant re-evaluates it in the epilogue instead of spilling
-      constexpr bool KEEP_SIG = (K == 5 || TH != 8);
-      float2 acc[PX], sig[KEEP_SIG ? PX : 1];
-#pragma unroll 1
-      for (int h = 0; h < 2; ++h) {
-        const int px = pxl + h * QX;
-        const float* wlh = wl + 2 * c2;            // opaque per half: the 25 weight pairs are loop-invariant and would
-        asm volatile("" : "+v"(wlh));              // otherwise be hoisted out of this loop as 50 live registers
+      const bool rok = gok && cok2 && oy < a.H;
+      const float2* tdg = td2 + (pyl * IWP + pxl) * C2B + c2;
+      const long rowoff = (((long)n * a.H + min(oy, a.H - 1)) * a.W + ox0 + pxl) * a.C + cc2;
+      float2 cur[QX];                              // the centre pixels of the current half
+#pragma unroll
+      for (int o = 0; o < QX; ++o) cur[o] = xr[o];
+#pragma unroll HU
+      for (int h = 0; h < NH; ++h) {
+        __builtin_amdgcn_sched_barrier(0);
+        const int pxh = h * QX;
+        int wlh = c2;                              // opaque per half: the K*K weight pairs are loop-invariant and would otherwise be
+        asm volatile("" : "+v"(wlh));              // hoisted out of the loops as 2 K*K live registers (an index: ds_read, not flat_load)
+        const float2* tdh = tdg + pxh * C2B;
         float2 xa[QX], ah[QX], sg[QX];
+        bool img[QX];
 #pragma unroll
         for (int o = 0; o < QX; ++o) {
-          const int oo = h * QX + o;
-          float2 r = make_float2(0.f, 0.f);
-#pragma unroll
-          for (int q = 0; q < PX; ++q) if (q == oo) r = xr[q];          // (register select: oo is uniform, PX <= 8)
-          const bool in_img = gok && cok2 && oo < PX && oy < a.H && ox0 + px + o < a.W;
+          if (UNROLL_H && pxh + o >= PX) continue;
+          const float2 r = cur[o];
+          img[o] = rok && pxh + o < PX && ox0 + pxl + pxh + o < a.W;
           float2 v = r, sv = make_float2(0.f, 0.f);
           if (has_bn0) {
             const float zx = A0.x * r.x + B0.x, zy = A0.y * r.y + B0.y;
             sv.x = sigmoidf_(zx); sv.y = sigmoidf_(zy);
             v.x = zx * sv.x; v.y = zy * sv.y;
           }
-          xa[o] = in_img ? v : make_float2(0.f, 0.f);
+          xa[o] = img[o] ? v : make_float2(0.f, 0.f);
           sg[o] = sv;
           ah[o] = make_float2(0.f, 0.f);
         }
+        // the tile row of kernel row ky + 1 is requested before the products of row ky: two rows of reads live, never more
+        // (not in the 3-workgroups-per-CU variant: 168 registers)
+#ifndef MX_DW_PIPE
+#define MX_DW_PIPE 1
+#endif
+        constexpr bool PIPE = MX_DW_PIPE && (K == 5 || TH != 8);
+        float2 inb[PIPE ? 2 : 1][QX - 1 + K];
+#pragma unroll
+        for (int j = 0; j < QX - 1 + K; ++j) {
+          if (!PIPE || (UNROLL_H && pxh + j - (K - 1) >= PX)) continue;  // (a slot past PX feeds the left-out pixel only)
+          inb[0][j] = tdh[((K - 1) * IWP + j) * C2B];
+        }
 #pragma unroll
         for (int ky = 0; ky < K; ++ky) {
-          __builtin_amdgcn_sched_barrier(0);       // one kernel row's LDS reads at a time (hoisted together they spill)
-          float2 in[QX - 1 + K];
+          __builtin_amdgcn_sched_barrier(0);       // one kernel row at a time (hoisted together the reads spill)
+          if (PIPE ? ky + 1 < K : true) {
+            const int kr = PIPE ? ky + 1 : ky;
 #pragma unroll
-          for (int j = 0; j < QX - 1 + K; ++j) in[j] = td2[((pyl + K - 1 - ky) * IW + min(px + j, IW - 1)) * C2B + c2];
+            for (int j = 0; j < QX - 1 + K; ++j) {
+              if (UNROLL_H && pxh + j - (K - 1) >= PX) continue;
+              inb[PIPE ? (ky + 1) & 1 : 0][j] = tdh[((K - 1 - kr) * IWP + j) * C2B];
+            }
+          }
+          float2 (&in)[QX - 1 + K] = inb[PIPE ? ky & 1 : 0];
 #pragma unroll
           for (int kx = 0; kx < K; ++kx) {
-            const float2 w = *reinterpret_cast<const float2*>(wlh + (ky * K + kx) * CB);
+            const float2 w = reinterpret_cast<const float2*>(wl)[wlh + (ky * K + kx) * C2B];
             float2& p = part[ky * K + kx];
 #pragma unroll
             for (int o = 0; o < QX; ++o) {
+              if (UNROLL_H && pxh + o >= PX) continue;
               const float2 v = in[o + K - 1 - kx];
               ah[o].x += w.x * v.x; ah[o].y += w.y * v.y;
               p.x += xa[o].x * v.x; p.y += xa[o].y * v.y;
             }
           }
+          // (this row's weight-gradient sums are pinned too: left free, the optimiser moves all K*K*PX of them to the end of the
+          // pass and keeps every tile value it has read alive until then)
+#pragma unroll
+          for (int kx = 0; kx < K; ++kx) pin2(part[ky * K + kx]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // this part's epilogue and stores: no accumulator survives a part.  (The data gradient is pinned here: its only use is
+        // under `if (img)`, and the optimiser otherwise sinks its K*K products into that branch, after ALL the tile reads.)
+#pragma unroll
+        for (int o = 0; o < QX; ++o) {
+          if (UNROLL_H && pxh + o >= PX) continue;
+          pin2(ah[o]);
         }
 #pragma unroll
         for (int o = 0; o < QX; ++o) {
-          const int oo = h * QX + o;
-#pragma unroll
-          for (int q = 0; q < PX; ++q) if (q == oo) { acc[q] = ah[o]; if (KEEP_SIG) sig[q] = sg[o]; }
-        }
-      }
-      if (gok && cok2 && oy < a.H) {
-#pragma unroll
-        for (int o = 0; o < PX; ++o) {
-          int ox = ox0 + pxl + o;
-          if (ox < a.W) {
-            const long off = (((long)n * a.H + oy) * a.W + ox) * a.C + cc2;
-            float2 v = acc[o];
+          if (UNROLL_H && pxh + o >= PX) continue;
+          if (img[o]) {
+            const long off = rowoff + (long)(pxh + o) * a.C;
+            float2 v = ah[o];
             if (has_bn0) {
-              const float2 r = xr[o];
+              const float2 r = cur[o];
               const float zx = A0.x * r.x + B0.x, zy = A0.y * r.y + B0.y;
-              const float2 sv = KEEP_SIG ? sig[o] : make_float2(sigmoidf_(zx), sigmoidf_(zy));
+              const float2 sv = sg[o];
               v.x *= sv.x * (1.0f + zx * (1.0f - sv.x)); v.y *= sv.y * (1.0f + zy * (1.0f - sv.y));   // swish'(z) from the same sigma
               s0.x += v.x; s0.y += v.y;
               s1.x += v.x * r.x; s1.y += v.y * r.y;
             } else if (a.res) {
-              float2 r = *reinterpret_cast<const float2*>(a.res + off);
+              const float2 r = *reinterpret_cast<const float2*>(a.res + off);
               v.x += r.x; v.y += r.y;
             }
             *reinterpret_cast<float2*>(a.gx + off) = v;
           }
         }
+#pragma unroll
+        for (int o = 0; o < QX; ++o) cur[o] = ((h + 1) * QX + o < PX) ? xr[(h + 1) * QX + o] : make_float2(0.f, 0.f);   // (the next part's pixels)
       }
       if (gi + 1 < NG) {
 #pragma unroll

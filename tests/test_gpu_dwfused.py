@@ -1,0 +1,71 @@
+"""The fused stride-1 depthwise backward (mx_dwconv_bwd_fused: BN1 data gradient formed while the tile is staged, weight + data
+gradients from the one staged tile, swish'(bn0) and the BN0 backward sums in the epilogue; reference model.py:76-90 backward)
+against float64 autograd of the same chain, on every tile shape the kernel has (14 x 28 and 8 x 16, 3x3 and 5x5), ragged images,
+channel counts that are not a multiple of the 32-channel chunk, with and without BN0 / residual."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _swish_grad(z):
+    s = torch.sigmoid(z)
+    return s * (1 + z * (1 - s))
+
+
+def _reference(dA, D, gate, add, st1, c1, X, st0, W, K, residual):
+    d = lambda t: t.double()
+    dA, D, gate, add, X, W, c1 = map(d, (dA, D, gate, add, X, W, c1))
+    a1, b1 = d(st1.scale), d(st1.shift)
+    dd = c1[0] * ((dA * gate[:, None, None, :] + add[:, None, None, :]) * _swish_grad(a1 * D + b1)) + c1[1] * D + c1[2]
+    x = X.clone().requires_grad_()
+    w = W.clone().requires_grad_()
+    act = F.silu(d(st0.scale) * x + d(st0.shift)) if st0 is not None else x
+    y = F.conv2d(act.permute(0, 3, 1, 2), w, padding=(K - 1) // 2, groups=X.shape[3])
+    (y * dd.permute(0, 3, 1, 2)).sum().backward()
+    gX = x.grad
+    part = None
+    if st0 is not None:
+        gX = gX / d(st0.scale)       # the kernel returns dL/d(a0*x + b0): the BatchNorm-0 backward that follows carries the scale
+        part = torch.stack([gX.sum((0, 1, 2)), (gX * X).sum((0, 1, 2))])
+    elif residual is not None:
+        gX = gX + residual.double()
+    return gX, w.grad, part
+
+
+@pytest.mark.parametrize("N,H,W,C,K,bn0,res", [
+    (2, 28, 28, 64, 5, True, False), (2, 28, 28, 40, 3, True, False),       # 14 x 28 tiles (B7's 28 x 28 stages), ragged channels
+    (3, 56, 56, 36, 5, True, False), (2, 56, 56, 32, 3, False, True),       # several tiles per plane; the plain-input (stage 1) form
+    (2, 14, 28, 32, 5, True, False), (1, 42, 84, 16, 3, True, False),
+    (2, 20, 37, 48, 5, True, False), (2, 20, 37, 20, 3, True, False),       # 8 x 16 tiles, image not a multiple of the tile
+    (3, 9, 9, 32, 5, False, True), (2, 16, 16, 64, 3, False, False),
+    (4, 112, 112, 32, 3, True, False), (2, 112, 112, 24, 5, True, False)])
+def test_fused_depthwise_backward_matches_float64(N, H, W, C, K, bn0, res):
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(N * 1000 + H * 10 + C + K)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    dA, D, X = rn(N, H, W, C), rn(N, H, W, C), rn(N, H, W, C)
+    gate, add = torch.sigmoid(rn(N, C)), rn(N, C) * 0.1
+    mk = lambda: ops.BNState(torch.rand(C, device=DEV, generator=g) + 0.5, rn(C) * 0.1, rn(C) * 0.1, torch.rand(C, device=DEV, generator=g) + 0.5)
+    st1, st0 = mk(), (mk() if bn0 else None)
+    c1 = rn(3, C) * 0.3
+    Wt = rn(C, 1, K, K) * 0.3
+    residual = rn(N, H, W, C) if res else None
+    want_gx, want_dw, want_part = _reference(dA, D, gate, add, st1, c1, X, st0, Wt, K, residual)
+    outs = []
+    for _ in range(2):
+        dW = torch.zeros_like(Wt)
+        gX, part = ops.dwconv_bwd_fused(dA, D, gate, add, st1, c1, X, st0, Wt, dW, K, (K - 1) // 2, residual=residual)
+        outs.append((gX, dW, part))
+    (gX, dW, part), (gX2, dW2, part2) = outs
+    assert torch.equal(gX, gX2) and torch.equal(dW, dW2)                    # same bits every run (ordered partial rows, no atomics)
+    assert float((gX.double() - want_gx).abs().max()) <= 2e-5 * float(want_gx.abs().max()) + 1e-6
+    assert float((dW.double() - want_dw).abs().max()) <= 5e-5 * float(want_dw.abs().max()) + 1e-5
+    if bn0:
+        assert torch.equal(part, part2)
+        got = part.double().sum(0)
+        assert float((got - want_part).abs().max()) <= 5e-5 * float(want_part.abs().max()) + 1e-5
+    else:
+        assert part is None

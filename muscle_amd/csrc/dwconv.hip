@@ -437,6 +437,19 @@ __device__ __forceinline__ void pin2(float2& v) {
   v = __builtin_bit_cast(float2, d);
 }
 
+#ifdef MX_DW_STAMPS
+// diagnostic build only (-DMX_DW_STAMPS, never shipped): wall-clock stamps (s_memrealtime, 10 ns) of thread 0 of the first 64 workgroups
+// around the phases of each tile: [wg][tile][4] = tile start, staging issued+transformed, compute start (after the barrier), compute end
+__device__ unsigned long long mx_dw_stamps[64 * 32 * 4];
+extern "C" int mx_dw_stamps_read(unsigned long long* host) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(mx_dw_stamps), sizeof(mx_dw_stamps));
+}
+#define DW_STAMP(k) do { if (tid == 0 && blockIdx.x < 64 && blockIdx.y == 0 && (t - t_beg) < 32) \
+    mx_dw_stamps[(blockIdx.x * 32 + (int)(t - t_beg)) * 4 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define DW_STAMP(k) do {} while (0)
+#endif
+
 #ifndef MX_DW_STAGE_MAX
 #define MX_DW_STAGE_MAX 4
 #endif
@@ -448,7 +461,7 @@ constexpr int dw_stage_depth(int per, int th) {
 }
 
 template <int K, int TH, int TW, int PX>
-__global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused_kernel(DwFusedArgs a) {
+__global__ __launch_bounds__(256, (TH == 7) ? 3 : (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused_kernel(DwFusedArgs a) {
   // Only dd is staged with its halo.  The weight gradient is taken over INPUT pixels,
   //     dW[ky,kx] = sum_q act(X)[q] * dd[q - (ky,kx) + pad],
   // so the activated input is needed at the tile's centre pixels only: each thread reads its 2 channels x PX pixels of X
@@ -460,8 +473,8 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
   constexpr bool ROWS = (TW == 28);
   constexpr int IH = TH + K - 1, IW = TW + K - 1, IWP = ROWS ? 32 : IW, TOT = IH * IWP * C4B, PER = (TOT + 255) / 256;
   static_assert(!ROWS || (IW <= 32 && PER == IH && 256 / C4B == 32), "one padded tile row per staging pass");
-  constexpr int CH = dw_stage_depth(PER, TH);
-  static_assert(PER % CH == 0, "staging chunks");
+  constexpr int CH = (ROWS && TH == 7) ? 4 : dw_stage_depth(PER, TH);     // (7-row tiles: 11 or 9 staged rows in chunks of 4, the last one short)
+  static_assert(ROWS || PER % CH == 0, "staging chunks");
   __shared__ float4 td[TOT + C4B];     // dd with halo (+ one pixel of zeros: the masked eighth slot of an odd PX reads past the last row); at the end the per-wave partial rows of dW and of the BN0 sums
   static_assert(TOT * 4 >= 4 * K * K * CB, "the per-wave partial rows reuse the staged tile");
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
@@ -513,7 +526,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
   float2 s0 = make_float2(0, 0), s1 = s0;
   // this thread's centre pixels of X (raw) for one group: clamped addresses, masked at use.  One 64-bit row base; the pixel
   // offsets are 32-bit (a row of one sample is far below 2^31 floats) and advance by C with a clamp at the last column
-  auto load_x = [&](float2 (&xr)[PX], int n, int oy, int oxb) {
+  auto load_x = [&](auto& xr, int n, int oy, int oxb) {
     const float* row = a.x + (((long)n * a.H + min(oy, a.H - 1)) * a.W) * a.C + (cok2 ? cc2 : 0);
     const int last = (a.W - 1) * a.C;
     int off = min(oxb, a.W - 1) * a.C;
@@ -528,6 +541,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
     const int rem = (int)(t % (a.tiles_x * a.tiles_y));
     const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
     const int iy0 = oy0 - a.pad, ix0 = ox0 - a.pad;
+    DW_STAMP(0);
     __syncthreads();
     if (tid < 2 * CB) {
       int cc = tid % CB;
@@ -550,7 +564,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
         float4 vg[CH], vd[CH];
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
-          const long rb = (((long)n * a.H + min(max(iy0 + r0 + k, 0), a.H - 1)) * a.W) * a.C;     // wave-uniform
+          const long rb = (((long)n * a.H + min(max(iy0 + min(r0 + k, IH - 1), 0), a.H - 1)) * a.W) * a.C;     // wave-uniform
           vg[k] = ld4(a.dA + rb + voff); vd[k] = ld4(a.d + rb + voff);
         }
         const float4 A1 = ld4(cst + 4 * c4), B1 = ld4(cst + CB + 4 * c4), C1 = ld4(cst + 2 * CB + 4 * c4),
@@ -562,7 +576,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
           const float okf = (iy >= 0 && iy < a.H) ? colf : 0.f;
           float4 dd;
           DD1(x) DD1(y) DD1(z) DD1(w)
-          td[(r0 + k) * 256 + tid] = dd;
+          if (IH % CH == 0 || r0 + k < IH) td[(r0 + k) * 256 + tid] = dd;
         }
       }
     } else {
@@ -594,7 +608,9 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
       }
     }
 #undef DD1
+    DW_STAMP(1);
     __syncthreads();
+    DW_STAMP(2);
     // Compute: a thread owns 2 channels x PX consecutive pixels of one tile row per pass (4 channels x 4 pixels needs 100
     // accumulator VGPRs for K=5 and the allocator then spills; 2 x 8 needs 50 and keeps v_pk_fma_f32 over the channel pair).
     // Row ky of the kernel pairs this pixel row with dd row pyl + K-1-ky of the halo tile, for the weight gradient
@@ -617,11 +633,13 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
       const bool gok = grp < NGRP;                 // (NGRP is a multiple of 16 for the 8 x 16 shape; 56 of 64 for 14 x 28)
       const int pyl = min(grp, NGRP - 1) / GX, pxl = (min(grp, NGRP - 1) % GX) * PX;
       const int oy = oy0 + pyl;
-      float2 xn[PX];                               // the next pass's centre pixels, in flight under this pass's arithmetic
-      if (gi + 1 < NG) {
+      constexpr bool XAHEAD = (TH != 7);           // (the 3-workgroup 7-row variant has no registers for it, and a third wave to wait behind)
+      float2 xn[XAHEAD ? PX : 1];                  // the next pass's centre pixels, in flight under this pass's arithmetic
+      if (XAHEAD && gi + 1 < NG) {
         const int g2 = min(grp + 16, NGRP - 1);
         load_x(xn, n, oy0 + g2 / GX, ox0 + (g2 % GX) * PX);
       }
+      if (!XAHEAD && gi > 0) load_x(xr, n, oy, ox0 + pxl);
       const bool rok = gok && cok2 && oy < a.H;
       const float2* tdg = td2 + (pyl * IWP + pxl) * C2B + c2;
       const long rowoff = (((long)n * a.H + min(oy, a.H - 1)) * a.W + ox0 + pxl) * a.C + cc2;
@@ -657,7 +675,7 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
 #ifndef MX_DW_PIPE
 #define MX_DW_PIPE 1
 #endif
-        constexpr bool PIPE = MX_DW_PIPE && (K == 5 || TH != 8);
+        constexpr bool PIPE = MX_DW_PIPE && TH != 7 && (K == 5 || TH != 8);
         float2 inb[PIPE ? 2 : 1][QX - 1 + K];
 #pragma unroll
         for (int j = 0; j < QX - 1 + K; ++j) {
@@ -724,11 +742,12 @@ __global__ __launch_bounds__(256, (K == 5 || TH != 8) ? 2 : 3) void dw_bwd_fused
 #pragma unroll
         for (int o = 0; o < QX; ++o) cur[o] = ((h + 1) * QX + o < PX) ? xr[(h + 1) * QX + o] : make_float2(0.f, 0.f);   // (the next part's pixels)
       }
-      if (gi + 1 < NG) {
+      if (XAHEAD && gi + 1 < NG) {
 #pragma unroll
-        for (int o = 0; o < PX; ++o) xr[o] = xn[o];
+        for (int o = 0; o < PX; ++o) xr[o] = xn[XAHEAD ? o : 0];
       }
     }
+    DW_STAMP(3);
   }
   // leave: dW and the BN0 sums as this workgroup's partial rows (global atomics here would have every workgroup of a
   // channel chunk contend on the same K*K*32 addresses: measured ~20 us per workgroup).  Inside the workgroup each wave
@@ -803,7 +822,7 @@ static void launch_dw_parts_reduce(const float* part, int P, int n, float* dW, h
 // fewer staged elements per valid output (its halo factor is lower, its quantisation coarser); MX_DW_FUSED_TILE forces one.
 static int dw_fused_shape(int H, int Wd, int K) {
   static const int forced = getenv("MX_DW_FUSED_TILE") ? atoi(getenv("MX_DW_FUSED_TILE")) : -1;
-  if (forced == 0 || forced == 1) return forced;
+  if (forced == 0 || forced == 1 || forced == 2) return forced;
   // measured on MI355X (tools/microbench.py dwfused, profiles/r03_dwfused_tiles.txt): 5x5 gains 13-19 % on every B7 layer
   // (2.3-2.6 -> 2.8-2.9 TB/s); 3x3, which ran 3 workgroups per CU on the small tile, loses 9-15 % at 112 / 224 pixels and is
   // level at 28: the large tile is taken for 5x5 only
@@ -817,7 +836,7 @@ static int dw_fused_shape(int H, int Wd, int K) {
 // not straddle samples, all on one XCD); gpp = 0: plain 2-D grid, a group is tpb consecutive tiles of the (sample, tile) sequence
 static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int* tiles_y, int* tpb, int* groups, int* gpp) {
   const int shape = dw_fused_shape(H, Wd, K);
-  *tiles_x = cdiv(Wd, shape ? 28 : 16); *tiles_y = cdiv(H, shape ? 14 : 8);
+  *tiles_x = cdiv(Wd, shape ? 28 : 16); *tiles_y = cdiv(H, shape == 2 ? 7 : shape ? 14 : 8);
   const int ntile = (*tiles_x) * (*tiles_y);
   long ntiles = (long)N * ntile;
   int chunks = cdiv(C, CB);
@@ -825,7 +844,8 @@ static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int*
   // per-workgroup prologue / partial-row epilogue) wants few long-lived workgroups: 11.0 -> 9.8 ms per step at 1024
   // instead of 4096; the 3x3 kernel (3 per CU) wants the opposite: 6.8 ms at 4096, 8.0 ms at 1024.
   static const long override_target = getenv("MX_DW_GROUPS") ? atol(getenv("MX_DW_GROUPS")) : 0;
-  const long group_target = override_target > 0 ? override_target : ((K == 5 || shape) ? 1024 : 4096);
+  // (round 4, rewritten kernel: the 14 x 28 / 5x5 form is level or 2-5 % faster at 512 - one workgroup per slot of its 2 per CU)
+  const long group_target = override_target > 0 ? override_target : (shape == 2 ? 768 : shape ? 512 : K == 5 ? 1024 : 4096);
   long g = group_target / chunks;
   if (g < 1) g = 1;
   if (g > ntiles) g = ntiles;
@@ -1024,7 +1044,10 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
     grid = dim3((unsigned)(cdiv((long)a.chunks * N, 8) * 8 * a.gpp), 1, 1);
   }
   const int shape = dw_fused_shape(H, Wd, K);
-  if (shape) {
+  if (shape == 2) {
+    if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 7, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 7, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (shape) {
     static bool big_lds = false;                         // 14 x 28 tiles: 72 KB (5x5) / 60 KB (3x3) of static LDS
     (void)big_lds;
     if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 14, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);

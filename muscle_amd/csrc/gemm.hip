@@ -456,6 +456,42 @@ static __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, float* C, 
   f32x4 cs[TN], cq[TN];
 #pragma unroll
   for (int j = 0; j < TN; ++j) cs[j] = cq[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Interior tiles without bias / ReLU (every expand, project and data-gradient GEMM of the backbone) take a lean path: one base
+  // offset per lane, constant strides, packed statistics, no per-element bounds.  The general loop below is ~40 instructions per
+  // 16 x 16 sub-tile; beside two other workgroups' MFMA streams on the same SIMDs it took 19 000 cycles per 128 x 128 tile
+  // (tools/hip/gemm_lab stamps, profiles/r04_planes_epilogue.txt), a quarter of the workgroup's life at K = 640.
+  const bool lean = vec && !g.bias && !g.relu && m0 + WM * TM * 16 <= g.M && n0 + BN <= g.N;
+  if (lean) {
+    const long idx0 = (long)(m0 + wm * TM * 16 + l15) * g.ldc + n0 + wn * TN * 16 + 4 * q;
+    float* cp = C + idx0;
+    const long istep = 16L * g.ldc;
+    if (g.residual) {
+      const float* rp = g.residual + idx0;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const f32x4 v = acc[i][j] + *reinterpret_cast<const f32x4*>(rp + i * istep + 16 * j);
+          cs[j] += v; cq[j] += v * v;
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(cp + i * istep + 16 * j));
+        }
+    } else if (g.stats) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const f32x4 v = acc[i][j];
+          cs[j] += v; cq[j] += v * v;
+          __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(cp + i * istep + 16 * j));
+        }
+    } else {
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+          __builtin_nontemporal_store(acc[i][j], reinterpret_cast<f32x4*>(cp + i * istep + 16 * j));
+    }
+  } else
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = n0 + wn * TN * 16 + 16 * j + 4 * q;
@@ -498,6 +534,7 @@ static __device__ __forceinline__ void nt_epilogue(const GemmArgs& g, float* C, 
       }
     }
   }
+  MX_GEMM_STAMP(g, 7);
   if (g.stats) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -1075,8 +1112,10 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
     for (int j = 0; j < TN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int woff = l15 * 64 + ((q ^ swz_w(l15)) << 4);
 
+  MX_GEMM_STAMP(g, 0);
   issue_w(0);
   load_a(0);
+  MX_GEMM_STAMP(g, 1);
   for (int kt = 0; kt < nk; ++kt) {
     // this wave's loads of step kt (weight pieces by LDS-DMA, its own activation rows) are done; split before the barrier
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1117,8 +1156,10 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
           acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[PW[t]], af[i][PX[t]], acc[i][j], 0, 0, 0);
     }
   }
+  MX_GEMM_STAMP(g, 2);
   __syncthreads();
   nt_epilogue<4, 1, 2, TN>(g, C, tile_m, m0, n0, acc, reinterpret_cast<float*>(smem), tid);
+  MX_GEMM_STAMP(g, 3);
 }
 
 // 0 = exact-fp32 MFMA everywhere; 1 (default since round 3) = split arithmetic for the MFMA-bound forward / data-gradient /
@@ -1482,6 +1523,7 @@ int mx_pw_fwd_planes(const float* A, const void* Wplanes, float* C, int M, int K
   g.b = MxOperand{reinterpret_cast<const float*>(Wplanes), nullptr, nullptr, nullptr, MX_PLAIN, 1};
   g.c = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = (N + 127) & ~127; g.ldc = ldc;
   g.bias = bias; g.residual = residual; g.relu = relu; g.stats = stats;
+  g.stamps = mx_gemm_stamps;
   launch_nt_split3(g, 1, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;

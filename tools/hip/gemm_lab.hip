@@ -98,8 +98,19 @@ static void run_stamps(int M, int K, int N, int which) {
   float* st = dalloc((long)parts * 2 * N, 7, 0.f);
   const long maxwg = 1 << 20;
   unsigned long long* stamps; CK(hipMalloc(&stamps, maxwg * 8 * sizeof(unsigned long long)));
+  void* planes = nullptr;
+  if (which == 3) {                       // the second-generation split kernel on the pre-split image of W
+    const long pb = mx_pw_planes_bytes(N, K);
+    if (pb <= 0) { printf("planes M=%d K=%d N=%d: no image for this shape\n", M, K, N); return; }
+    CK(hipMalloc(&planes, pb));
+    long row[5] = {(long)W, (long)planes, N, K, 0};
+    long* table; CK(hipMalloc(&table, sizeof(row))); CK(hipMemcpy(table, row, sizeof(row), hipMemcpyHostToDevice));
+    mx_pw_planes_batch(table, 1, mx_pw_planes_tiles(N, K), nullptr);
+    CK(hipDeviceSynchronize());
+  }
   auto call = [&] {
-    if (which == 0) mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C, M, K, N, K, N, nullptr, nullptr, 0, st, nullptr);
+    if (which == 3) mx_pw_fwd_planes(A, planes, C, M, K, N, K, N, nullptr, nullptr, 0, st, nullptr);
+    else if (which == 0) mx_pw_fwd(A, 0, nullptr, nullptr, nullptr, 1, W, C, M, K, N, K, N, nullptr, nullptr, 0, st, nullptr);
     else if (which == 1) mx_pw_dgrad(G, W, dX, M, N, K, N, K, nullptr, nullptr);
     else mx_pw_wgrad(G, A, 0, nullptr, nullptr, nullptr, 1, dW, M, N, K, N, K, ws, ws_bytes, nullptr);
   };
@@ -108,6 +119,9 @@ static void run_stamps(int M, int K, int N, int which) {
   CK(hipMemset(stamps, 0, maxwg * 8 * sizeof(unsigned long long)));
   mx_gemm_stamps = stamps;
   float t_st = time_us(call, 3);
+  // the clock the chip HOLDS under this kernel: ~1.5 s of back-to-back launches before the launch whose stamps are read
+  for (int i = 0, n = (int)(1.5e6f / t_st) + 1; i < n; ++i) call();
+  CK(hipDeviceSynchronize());
   CK(hipMemset(stamps, 0, maxwg * 8 * sizeof(unsigned long long)));
   call();
   CK(hipDeviceSynchronize());
@@ -115,7 +129,7 @@ static void run_stamps(int M, int K, int N, int which) {
   std::vector<unsigned long long> h(maxwg * 8);
   CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
   long nwg = 0;
-  double pro = 0, loop = 0, epi = 0, clk = 0;
+  double pro = 0, loop = 0, epi = 0, clk = 0, epi_store = 0;
   unsigned long long t0 = ~0ull, t1 = 0;
   std::vector<double> starts, ends;
   for (long w = 0; w < maxwg; ++w) {
@@ -123,16 +137,18 @@ static void run_stamps(int M, int K, int N, int which) {
     if (!s[0] || !s[3]) continue;
     ++nwg;
     pro += (double)(s[1] - s[0]); loop += (double)(s[2] - s[1]); epi += (double)(s[3] - s[2]);
+    if (s[7] > s[2]) epi_store += (double)(s[7] - s[2]);
     if (s[5] > s[4]) clk += (double)(s[3] - s[0]) / (double)(s[5] - s[4]) * 100.0;   // MHz (memrealtime = 100 MHz)
     t0 = std::min(t0, s[4]); t1 = std::max(t1, s[5]);
     starts.push_back((double)s[4]); ends.push_back((double)s[5]);
   }
-  const char* nm[] = {"fwd", "dgrad", "wgrad"};
+  const char* nm[] = {"fwd", "dgrad", "wgrad", "fwd (planes kernel)"};
   printf("%s M=%d K=%d N=%d: %.1f us plain, %.1f us stamped; %ld workgroups stamped\n", nm[which], M, K, N, t_plain, t_st, nwg);
   if (nwg) {
     const double tot = pro + loop + epi;
     printf("  per-workgroup cycles: prologue %.0f (%.1f%%)  main loop %.0f (%.1f%%)  epilogue %.0f (%.1f%%)  total %.0f; in-kernel clock %.0f MHz\n",
            pro / nwg, 100 * pro / tot, loop / nwg, 100 * loop / tot, epi / nwg, 100 * epi / tot, tot / nwg, clk / nwg);
+    if (epi_store > 0) printf("  epilogue: %.0f cycles up to the last C store issued, %.0f for the statistics after it\n", epi_store / nwg, (epi - epi_store) / nwg);
     printf("  first start -> last end (realtime): %.1f us\n", (double)(t1 - t0) / 100.0);
     // concurrency histogram: how many workgroups are alive over time (20 buckets)
     const int NB = 20;
@@ -143,6 +159,25 @@ static void run_stamps(int M, int K, int N, int which) {
       printf("%s%ld", b ? " " : "  alive: ", alive);
     }
     printf("\n");
+    if (which == 3) {
+      // the workgroups of ONE compute unit (XCC 0, the CU / SE bits of the first stamped workgroup), in start order: are their phases locked?
+      struct Ev { double s, l, e; long w; };
+      std::vector<Ev> ev;
+      unsigned long long key0 = ~0ull;
+      for (long w = 0; w < maxwg; ++w) {
+        const unsigned long long* s = &h[w * 8];
+        if (!s[0] || !s[3]) continue;
+        const unsigned long long key = ((s[6] >> 8) & 0xff) | (((s[6] >> 32) & 0xf) << 8);
+        if (key0 == ~0ull) key0 = key;
+        if (key != key0) continue;
+        const double cyc2us = (double)(s[5] - s[4]) / 100.0 / (double)(s[3] - s[0]);
+        ev.push_back({(double)(s[4] - t0) / 100.0, (double)(s[4] - t0) / 100.0 + (double)(s[2] - s[0]) * cyc2us, (double)(s[5] - t0) / 100.0, w});
+      }
+      std::sort(ev.begin(), ev.end(), [](const Ev& a, const Ev& b) { return a.s < b.s; });
+      printf("  one CU (key %llx), %zu workgroups: [id start -> loop end -> end] us:", key0, ev.size());
+      for (const Ev& e : ev) printf(" [%ld %.0f>%.0f>%.0f]", e.w, e.s, e.l, e.e);
+      printf("\n");
+    }
     // start-time rounds: sort starts, print deciles in us
     std::sort(starts.begin(), starts.end());
     printf("  start deciles (us):");
@@ -337,7 +372,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (argc >= 5 && !strcmp(argv[1], "stamps")) {
-    for (int which = 0; which < 3; ++which) run_stamps(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), which);
+    for (int which = (argc >= 6 ? atoi(argv[5]) : 0); which < (argc >= 6 ? atoi(argv[5]) + 1 : 3); ++which) run_stamps(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]), which);
     return 0;
   }
   printf("usage: gemm_lab time | stamps M K N\n");

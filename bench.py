@@ -25,7 +25,7 @@ sys.path.insert(0, ROOT)
 
 from muscle_amd import arch, synth  # noqa: E402
 
-GEMM_CALLS = ("mx_pw_fwd", "mx_pw_fwd_planes", "mx_pw_dgrad_bnbwd_planes", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile",
+GEMM_CALLS = ("mx_pw_fwd", "mx_pw_fwd_planes", "mx_pw_fwd_planes_act", "mx_pw_dgrad_bnbwd_planes", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile",
               "mx_pw_wgrad_tile_bnbwd", "mx_pw_wgrad_small_bnbwd")
 MFMA_F32_PEAK_TFLOPS = 157.3          # /opt/skills/guides/MI355X_MICROARCH.md, dense fp32 MFMA
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # same guide, dense bf16 MFMA (no sparsity)
@@ -80,6 +80,9 @@ class GemmTimer:
             if name == "mx_pw_fwd_planes":
                 M, K, N = a[3], a[4], a[5]
                 return 2.0 * M * K * N, 2, M, N, K              # second-generation split kernel: always split
+            if name == "mx_pw_fwd_planes_act":
+                M, K, N = a[7], a[8], a[9]
+                return 2.0 * M * K * N, 2, M, N, K
             if name == "mx_pw_dgrad_bnbwd_planes":
                 M, K, N = a[5], a[6], a[7]
                 return 2.0 * M * K * N, 2, M, N, K

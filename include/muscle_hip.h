@@ -92,6 +92,13 @@ int mx_pw_dgrad(const float* G, const float* W, float* dX, int M, int K, int N, 
 int mx_pw_dgrad_bnbwd(const float* G, const float* X, const float* coef, const float* Wt, float* dX, float* dZ, int M, int K, int N,
                       int ldg, int ldx, const float* residual, void* stream);
 
+/* The project convolution's forward GEMM (model.py:83-86) with its operand prologue in the second-generation split kernel:
+ * C[M,N] = (swish(scale[k]*A[m,k] + shift[k]) * gate[m / rows_per_sample, k]) * W[N,K]^T, W given as its pre-split image; statistics as
+ * mx_pw_fwd.  K % 32 == 0.  mx_pw_fwd_act_uses_planes: 1 where the engine should take it (narrow outputs of the HBM-bound stages). */
+int mx_pw_fwd_act_uses_planes(int M, int K, int N);
+int mx_pw_fwd_planes_act(const float* A, const float* scale, const float* shift, const float* gate, int rows_per_sample,
+                         const void* Wplanes, float* C, int M, int K, int N, int lda, int ldc, float* stats, void* stream);
+
 /* The BatchNorm-0 backward apply dZ = c1*G + c2*X + c3 (model.py:45 backward; coef = [3][K] as mx_bn_bwd_finalize leaves it) folded into
  * BOTH consumers of dZ in split arithmetic, so that dZ is never written (round 4):
  *   mx_pw_dgrad_bnbwd_planes: dX[M,N] = dZ[M,K] * Wt[N,K]^T (+residual), Wt given as its pre-split image (mx_pw_planes_batch);

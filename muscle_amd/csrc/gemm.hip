@@ -1083,8 +1083,19 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
       if (WPIECES % 4 == 0 || wave + 4 * i < WPIECES) glds16(wsrc[i] + 3 * npad64 * kt, st + wdst[i]);
   };
   f32x4 raw[2][2];
-  f32x4 rawx[AMODE == MX_BNBWD ? 2 : 1][2], cf[AMODE == MX_BNBWD ? 3 : 1][2];
+  f32x4 rawx[(AMODE == MX_BNBWD || AMODE == MX_BNACT) ? 2 : 1][2], cf[AMODE == MX_BNBWD ? 3 : AMODE == MX_BNACT ? 2 : 1][2];
   const long xoff = AMODE == MX_BNBWD ? (g.a.rowp + zb * g.sa) - A : 0;      // X[r][k] sits xoff floats from G[r][k]
+  // AMODE = MX_BNACT (the project convolution of stages 1-3, model.py:86 on swish(bn1(d_raw)) * gate): the lane applies scale / shift per
+  // channel k, SiLU and the SE gate of its row's sample to the fragments it loaded, in registers; rawx holds the gate values, cf the
+  // scale and shift.  16 sigmoids per lane and K step: only for the narrow outputs of the HBM-bound stages (the launcher keeps TN <= 6)
+  const float* gp[AMODE == MX_BNACT ? 2 : 1];
+  if (AMODE == MX_BNACT) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int gr = min(m0 + 32 * wave + 16 * i + l15, g.M - 1);
+      gp[AMODE == MX_BNACT ? i : 0] = g.a.rowp + (long)(gr / g.a.rps) * g.K + 4 * q;
+    }
+  }
   auto load_a = [&](int kt) {
     const bool half = AMODE != MX_BNBWD && ktail && kt == nk - 1;
 #pragma unroll
@@ -1095,6 +1106,16 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
         rawx[AMODE == MX_BNBWD ? i : 0][0] = *reinterpret_cast<const f32x4*>(ap[i] + xoff + 32 * kt);
         rawx[AMODE == MX_BNBWD ? i : 0][1] = *reinterpret_cast<const f32x4*>(ap[i] + xoff + 32 * kt + 16);
       }
+      if (AMODE == MX_BNACT) {
+        rawx[AMODE == MX_BNACT ? i : 0][0] = *reinterpret_cast<const f32x4*>(gp[AMODE == MX_BNACT ? i : 0] + 32 * kt);
+        rawx[AMODE == MX_BNACT ? i : 0][1] = *reinterpret_cast<const f32x4*>(gp[AMODE == MX_BNACT ? i : 0] + 32 * kt + 16);
+      }
+    }
+    if (AMODE == MX_BNACT) {
+      cf[0][0] = *reinterpret_cast<const f32x4*>(g.a.c1 + 32 * kt + 4 * q);
+      cf[0][1] = *reinterpret_cast<const f32x4*>(g.a.c1 + 32 * kt + 4 * q + 16);
+      cf[AMODE == MX_BNACT ? 1 : 0][0] = *reinterpret_cast<const f32x4*>(g.a.c2 + 32 * kt + 4 * q);
+      cf[AMODE == MX_BNACT ? 1 : 0][1] = *reinterpret_cast<const f32x4*>(g.a.c2 + 32 * kt + 4 * q + 16);
     }
     if (AMODE == MX_BNBWD) {
 #pragma unroll
@@ -1129,6 +1150,13 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
           for (int e = 0; e < 4; ++e)
             raw[i][u][e] = cf[0][u][e] * raw[i][u][e] + (cf[AMODE == MX_BNBWD ? 1 : 0][u][e] * rawx[AMODE == MX_BNBWD ? i : 0][u][e] +
                                                          cf[AMODE == MX_BNBWD ? 2 : 0][u][e]);
+      }
+      if (AMODE == MX_BNACT) {
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            raw[i][u][e] = swishf_(cf[0][u][e] * raw[i][u][e] + cf[AMODE == MX_BNACT ? 1 : 0][u][e]) * rawx[AMODE == MX_BNACT ? i : 0][u][e];
       }
       unsigned h[4], m[4], l[4];
       split3_pair(raw[i][0][0], raw[i][0][1], h[0], m[0], l[0]);
@@ -1236,7 +1264,9 @@ static void launch_nt_split3_t(const GemmArgs& g, int batch, hipStream_t st) {
     grid = dim3(chunks * 8 * cdiv(mt, 8) * a.xcd_nt, 1, batch);
   }
   if (g.a.mode == MX_BNBWD) hipLaunchKernelGGL((gemm_nt_split3_kernel<TN, MX_BNBWD>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gemm_nt_split3_kernel<TN, MX_PLAIN>), grid, dim3(256), 0, st, a);
+  else if (g.a.mode == MX_BNACT) {
+    if constexpr (TN <= 6) hipLaunchKernelGGL((gemm_nt_split3_kernel<TN, MX_BNACT>), grid, dim3(256), 0, st, a);     // (launch_nt_split3 keeps the activated form at <= 96 columns)
+  } else hipLaunchKernelGGL((gemm_nt_split3_kernel<TN, MX_PLAIN>), grid, dim3(256), 0, st, a);
 }
 
 // Tile width: 128 columns, or 112 / 96 / 80 / 64 where that pads less or balances better.  Tiles are dealt over 256 CUs: time ~
@@ -1269,6 +1299,7 @@ static void launch_nt_split3(const GemmArgs& g, int batch, hipStream_t st) {
       if (g.N % 80 == 0 && cost(80, e80) < best) { best = cost(80, e80); bn = 80; }
     }
   }
+  if (g.a.mode == MX_BNACT && bn > 96) bn = (g.N % 96 == 0) ? 96 : 64;     // (the activated form exists up to 96 columns)
   switch (bn) {
     case 64: launch_nt_split3_t<4>(g, batch, st); break;
     case 80: launch_nt_split3_t<5>(g, batch, st); break;
@@ -1524,6 +1555,34 @@ int mx_pw_fwd_planes(const float* A, const void* Wplanes, float* C, int M, int K
   g.c = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = (N + 127) & ~127; g.ldc = ldc;
   g.bias = bias; g.residual = residual; g.relu = relu; g.stats = stats;
   g.stamps = mx_gemm_stamps;
+  launch_nt_split3(g, 1, (hipStream_t)stream);
+  MX_LAUNCH_CHECK();
+  return MX_OK;
+}
+
+// 1 when, in the current mode, the project convolution's forward GEMM on swish(scale*A + shift) * gate should go through
+// mx_pw_fwd_planes_act: the narrow outputs of stages 2-3 (K = 192 / 288 -> 48, 288 / 480 -> 80 at 0.1-0.4 M rows), HBM-bound - the
+// register-direct activation stream beats the exact-fp32 kernel's LDS slabs there as it does for the plain form (MX_SPLIT3_ACT=0: off)
+int mx_pw_fwd_act_uses_planes(int M, int K, int N) {
+  static const int on = getenv("MX_SPLIT3_ACT") ? atoi(getenv("MX_SPLIT3_ACT")) : 1;
+  static const int split2 = getenv("MX_SPLIT2") ? atoi(getenv("MX_SPLIT2")) : 1;
+  return (on && split2 && g_gemm_mode != 0 && M >= 65536 && K % 32 == 0 && K >= 192 && N >= 48 && N <= 128) ? 1 : 0;
+}
+
+// C[M,N] = (swish(scale[k]*A[m,k] + shift[k]) * gate[m / rows_per_sample, k]) * W[N,K]^T with W as its pre-split image: the operand
+// prologue of mx_pw_fwd's a_mode 1 (model.py:83-86) in the second-generation split kernel's register loads.  K % 32 == 0.
+int mx_pw_fwd_planes_act(const float* A, const float* scale, const float* shift, const float* gate, int rows_per_sample,
+                         const void* Wplanes, float* C, int M, int K, int N, int lda, int ldc, float* stats, void* stream) {
+  MX_CHECK_ARG(A && scale && shift && gate && Wplanes && C, "pw_fwd_planes_act: null pointer");
+  MX_CHECK_ARG(M > 0 && N > 0 && K > 0 && K % 32 == 0 && rows_per_sample > 0, "pw_fwd_planes_act: bad extents M=%d N=%d K=%d rows_per_sample=%d", M, N, K, rows_per_sample);
+  MX_CHECK_ARG(lda % 4 == 0 && lda >= K && ldc >= N, "pw_fwd_planes_act: bad leading dimensions lda=%d ldc=%d", lda, ldc);
+  MX_CHECK_ARG((((uintptr_t)A | (uintptr_t)scale | (uintptr_t)shift | (uintptr_t)gate | (uintptr_t)Wplanes | (uintptr_t)C) & 15) == 0,
+               "pw_fwd_planes_act: pointers must be 16-byte aligned");
+  GemmArgs g{};
+  g.a = MxOperand{A, scale, shift, gate, MX_BNACT, rows_per_sample};
+  g.b = MxOperand{reinterpret_cast<const float*>(Wplanes), nullptr, nullptr, nullptr, MX_PLAIN, 1};
+  g.c = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = (N + 127) & ~127; g.ldc = ldc;
+  g.stats = stats;
   launch_nt_split3(g, 1, (hipStream_t)stream);
   MX_LAUNCH_CHECK();
   return MX_OK;

@@ -335,7 +335,7 @@ def backbone_forward(backbone, cfg: NetCfg, img: torch.Tensor, training: bool,
         else:
             t.p_raw = ops.pw_fwd(d2, m._project_conv.weight.view(b.cout, b.cexp), b.cout, a_mode=ops.BNACT,
                                  a_scale=t.bn1.scale, a_shift=t.bn1.shift, a_gate=t.gate, rows_per_sample=ho * wo,
-                                 want_stats=training)
+                                 want_stats=training, planes=tape.wp.get(id(m._project_conv.weight)))
         if training:
             t.p_raw, st2 = t.p_raw
         t.bn2 = ops.bn_finalize(st2, Mo, m._bn2, training)

@@ -75,6 +75,15 @@ def _planes_take(M, K, N_out):
     return r
 
 
+def _planes_act_take(M, K, N_out):
+    """The same question for the project convolution's activated-input form (mx_pw_fwd_planes_act)."""
+    key = ("act", get_gemm_mode(), M, K, N_out)
+    r = _uses_planes.get(key)
+    if r is None:
+        r = _uses_planes[key] = bool(lib().mx_pw_fwd_act_uses_planes(M, K, N_out))
+    return r
+
+
 def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None, rows_per_sample=1,
            bias=None, residual=None, relu=False, want_stats=False, out=None, ldc=None, planes=None):
     """A: [M, K]; W: [N_out, K] -> [M, N_out] (and, if want_stats, the partial BN statistics [P, 2, N_out]).
@@ -89,6 +98,10 @@ def pw_fwd(A, W, N_out, *, a_mode=PLAIN, a_scale=None, a_shift=None, a_gate=None
     if planes is not None and a_mode == PLAIN and _planes_take(M, K, N_out):
         call("mx_pw_fwd_planes", ptr(A), planes, ptr(out), M, K, N_out, A.stride(0), ldc, ptr(bias), ptr(residual), int(relu),
              ptr(stats), stream())
+    elif (planes is not None and a_mode == BNACT and a_gate is not None and bias is None and residual is None and not relu
+          and _planes_act_take(M, K, N_out)):
+        call("mx_pw_fwd_planes_act", ptr(A), ptr(a_scale), ptr(a_shift), ptr(a_gate), rows_per_sample, planes, ptr(out), M, K, N_out,
+             A.stride(0), ldc, ptr(stats), stream())
     else:
         call("mx_pw_fwd", ptr(A), a_mode, ptr(a_scale), ptr(a_shift), ptr(a_gate), rows_per_sample, ptr(W), ptr(out),
              M, K, N_out, A.stride(0), ldc, ptr(bias), ptr(residual), int(relu), ptr(stats), stream())

@@ -121,6 +121,42 @@ def test_planes_gemm_matches_fp64_as_well_as_fp32_mfma(M, K, N, opts):
     assert errs[2] <= 1.5 * errs[1] + 2e-7 * scale_, errs        # ... and as close as the first-generation split kernel
 
 
+@pytest.mark.parametrize("M,K,N,rps", [(100352, 288, 48, 3136), (65536 + 77, 480, 80, 784), (131072, 192, 48, 12544), (70000, 288, 96, 1)])
+def test_planes_gemm_with_activated_input_matches_fp64(M, K, N, rps):
+    """mx_pw_fwd_planes_act: the project convolution's operand prologue (BN1 scale / shift, SiLU, the SE gate of the row's sample,
+    model.py:83-86) in the second-generation split kernel's register loads, against float64 and beside the exact-fp32 kernel with the
+    same prologue; ragged row counts, the statistics, bit-identical from run to run."""
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + K + N)
+    A = torch.randn(M, K, device=DEV, generator=g)
+    W = torch.randn(N, K, device=DEV, generator=g) * (K ** -0.5)
+    scale = torch.rand(K, device=DEV, generator=g) + 0.5
+    shift = torch.randn(K, device=DEV, generator=g) * 0.3
+    gate = torch.rand((M + rps - 1) // rps, K, device=DEV, generator=g)
+    want = _ref(A, W, scale, shift, gate, rps, None, None, False, 1)
+    plan = ops.PlanesPlan([W])
+    (image,) = plan.run()
+    kw = dict(a_mode=ops.BNACT, a_scale=scale, a_shift=shift, a_gate=gate, rows_per_sample=rps, want_stats=True)
+    outs = []
+    for gm, planes in ((0, None), (1, image), (1, image)):
+        muscle_amd.set_gemm_mode(gm)
+        try:
+            assert planes is None or ops._planes_act_take(M, K, N)
+            outs.append(ops.pw_fwd(A, W, N, planes=planes, **kw))
+        finally:
+            muscle_amd.set_gemm_mode(0)
+    assert torch.equal(outs[1][0], outs[2][0]) and torch.equal(outs[1][1], outs[2][1])
+    for _, st in outs:
+        ssum = st.double().sum(0)
+        assert float((ssum[0] - want.sum(0)).abs().max() / want.sum(0).abs().max()) <= 1e-5
+        assert float((ssum[1] - (want * want).sum(0)).abs().max() / (want * want).sum(0).abs().max()) <= 1e-5
+    errs = [float((o.double() - want).abs().max()) for o, _ in outs[:2]]
+    scale_ = float(want.abs().max())
+    assert errs[0] <= 2e-6 * scale_ + 1e-6, errs                 # the exact-fp32 kernel itself
+    assert errs[1] <= 1.5 * errs[0] + 2e-7 * scale_, errs        # the planes kernel is as close to fp64
+
+
 @pytest.mark.parametrize("M,K,N,res", [(25088, 960, 160, True), (6272, 2304, 384, False), (3001, 384, 130, True), (700, 1344, 224, False),
                                        (401408, 288, 48, True), (200704, 192, 32, False), (100352 + 37, 288, 48, False)])   # stages 1-2: small-output kernel
 def test_bnbwd_fold_in_both_consumers_matches_fp64(M, K, N, res):

@@ -122,11 +122,17 @@ __device__ __forceinline__ void dw_stage_input(const DwArgs& a, float4* tile, in
 #ifndef DW_FWD_PREFETCH
 #define DW_FWD_PREFETCH 0
 #endif
+// ROWS (28-wide stride-1 tiles, round 4): as in dw_bwd_fused_kernel the staged rows are pitched at 32 pixels, so one staging pass of
+// the 256 threads is one tile row - the row's address, clamp and bounds are scalar, the thread's column is fixed for the tile - and a
+// thread computes 7 pixels x 4 channels (11 tile reads per kernel row for 70 packed FMAs; 8 for 40 at 4 pixels).  The 16-wide form
+// spent ~75 instructions per output element against ~26 here, on a kernel whose VALU is 80 % busy at four waves per SIMD (PMC).
 template <int K, int S, int TH, int TW, int OX>
-__global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
-  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+__global__ __launch_bounds__(256, (TW == 28) ? 3 : 1) void dw_fwd_kernel(DwArgs a) {
+  constexpr bool ROWS = (TW == 28 && S == 1);
+  constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K, IWP = ROWS ? 32 : IW;
   static_assert(TH * (TW / OX) * C4B == 256, "thread mapping");
-  __shared__ float4 tile[IH * IW * C4B];
+  static_assert(!ROWS || (IW <= 32 && 256 / C4B == 32), "one padded tile row per staging pass");
+  __shared__ float4 tile[IH * IWP * C4B];
   __shared__ __attribute__((aligned(16))) float wl[K * K * CB];
   __shared__ __attribute__((aligned(16))) float red[4][2 * CB];     // one row per wave: the four waves are added in wave order (LDS atomics gave sums
   __shared__ unsigned last_flag;       // whose last bit depended on which wave came first)
@@ -160,10 +166,37 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
   for (long t = t_beg; t < t_end; ++t) {
     const int n = (int)(t / ntile), rem = (int)(t % ntile);
     const int oy0 = (rem / a.tiles_x) * TH, ox0 = (rem % a.tiles_x) * TW;
+    if constexpr (ROWS) {
+      const int col = tid / C4B, ix = ox0 - a.pad + col;
+      const bool colok = col < IW && ix >= 0 && ix < a.W && c < a.C;
+      const int voff = min(max(ix, 0), a.W - 1) * a.C + (c < a.C ? c : 0);
+      float4 sv = make_float4(0, 0, 0, 0), tv = sv;
+      if (a.sc && c < a.C) { sv = ld4(a.sc + c); tv = ld4(a.sh + c); }
+      float4 v[IH];
+#pragma unroll
+      for (int r = 0; r < IH; ++r) {
+        const int iy = oy0 - a.pad + r;                                  // wave-uniform
+        v[r] = ld4(a.x + (((long)n * a.H + min(max(iy, 0), a.H - 1)) * a.W) * a.C + voff);
+      }
+      __syncthreads();                             // the previous tile's readers are done (first pass: the weights are staged)
+#pragma unroll
+      for (int r = 0; r < IH; ++r) {
+        const int iy = oy0 - a.pad + r;
+        float4 x = v[r];
+        if (a.sc) {
+          x.x = swishf_(sv.x * x.x + tv.x); x.y = swishf_(sv.y * x.y + tv.y);
+          x.z = swishf_(sv.z * x.z + tv.z); x.w = swishf_(sv.w * x.w + tv.w);
+        }
+        const bool ok = colok && iy >= 0 && iy < a.H;                    // the convolution pads the ACTIVATED tensor with zeros
+        tile[r * 256 + tid] = ok ? x : make_float4(0, 0, 0, 0);
+      }
+      __syncthreads();
+    } else {
     if (!DW_FWD_PREFETCH) stg.load(a, n, oy0, ox0, c0, tid);
     __syncthreads();                               // the previous tile's readers are done (first pass: the weights are staged)
     stg.store(a, tile, c0, tid);
     __syncthreads();
+    }
     if (DW_FWD_PREFETCH && t + 1 < t_end) {
       const int rem1 = (int)((t + 1) % ntile);
       stg.load(a, (int)((t + 1) / ntile), (rem1 / a.tiles_x) * TH, (rem1 % a.tiles_x) * TW, c0, tid);
@@ -176,7 +209,7 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     for (int ky = 0; ky < K; ++ky) {
       float4 in[(OX - 1) * S + K];
 #pragma unroll
-      for (int j = 0; j < (OX - 1) * S + K; ++j) in[j] = tile[((oyl * S + ky) * IW + oxl * S + j) * C4B + c4];
+      for (int j = 0; j < (OX - 1) * S + K; ++j) in[j] = tile[((oyl * S + ky) * IWP + oxl * S + j) * C4B + c4];
 #pragma unroll
       for (int kx = 0; kx < K; ++kx) {
         float4 w = ld4(wl + (ky * K + kx) * CB + 4 * c4);
@@ -189,11 +222,12 @@ __global__ __launch_bounds__(256) void dw_fwd_kernel(DwArgs a) {
     }
     const int oy = oy0 + oyl;
     if (c < a.C && oy < a.Ho) {
+      float* yrow = a.y + (((long)n * a.Ho + oy) * a.Wo + ox0 + oxl) * a.C + c;     // one 64-bit base, the pixels C floats apart
 #pragma unroll
       for (int o = 0; o < OX; ++o) {
         int ox = ox0 + oxl + o;
         if (ox < a.Wo) {
-          st4(a.y + (((long)n * a.Ho + oy) * a.Wo + ox) * a.C + c, acc[o]);
+          st4(yrow + o * a.C, acc[o]);
           if (a.pooled) {
             // Inference (eval-mode BatchNorm: its affine is known before the batch is seen): the squeeze of the SE block,
             // sum over the image of swish(bn1(y)), leaves with the tiles instead of costing a second pass over d (model.py:81-82)
@@ -818,15 +852,18 @@ static void launch_dw_parts_reduce(const float* part, int P, int n, float* dW, h
   hipLaunchKernelGGL(dw_parts_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, part, P, n, dW);
 }
 
-// tile shape of the fused backward: 1 = 14 x 28 (PX 7), 0 = 8 x 16 (PX 8).  The large tile wherever it covers the image with
+// tile shape of the fused backward: 1 = 14 x 28 (PX 7), 0 = 8 x 16 (PX 8), 3 = 8 x 28 (3x3 only), 2 = 7 x 28 (a knob: MX_DW_FUSED_TILE=2).  The large tile wherever it covers the image with
 // fewer staged elements per valid output (its halo factor is lower, its quantisation coarser); MX_DW_FUSED_TILE forces one.
 static int dw_fused_shape(int H, int Wd, int K) {
   static const int forced = getenv("MX_DW_FUSED_TILE") ? atoi(getenv("MX_DW_FUSED_TILE")) : -1;
-  if (forced == 0 || forced == 1 || forced == 2) return forced;
+  if (forced == 0 || forced == 1 || forced == 2 || (forced == 3 && K == 3)) return forced;
   // measured on MI355X (tools/microbench.py dwfused, profiles/r03_dwfused_tiles.txt): 5x5 gains 13-19 % on every B7 layer
   // (2.3-2.6 -> 2.8-2.9 TB/s); 3x3, which ran 3 workgroups per CU on the small tile, loses 9-15 % at 112 / 224 pixels and is
   // level at 28: the large tile is taken for 5x5 only
-  if (K != 5) return 0;
+  // (round 4, after the rewrite: 3x3 takes 8 x 28 row-staged tiles - three workgroups per CU like the small tile, 1.71x instead of 1.41x
+  // staged pixels per output but scalar row addressing and 7-pixel threads - where the image is a multiple of 28 wide: 3840 x 28 x 28
+  // 368 -> 346 us, 960 x 28 x 28 108 -> 99, level at 112 / 224; profiles/r04_knob_sweep.txt)
+  if (K != 5) return (Wd % 28 == 0) ? 3 : 0;
   const double small = (double)cdiv(H, 8) * cdiv(Wd, 16) * (8 + K - 1) * (16 + K - 1);
   const double large = (double)cdiv(H, 14) * cdiv(Wd, 28) * (14 + K - 1) * (28 + K - 1);
   return large < 0.9 * small ? 1 : 0;
@@ -836,7 +873,7 @@ static int dw_fused_shape(int H, int Wd, int K) {
 // not straddle samples, all on one XCD); gpp = 0: plain 2-D grid, a group is tpb consecutive tiles of the (sample, tile) sequence
 static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int* tiles_y, int* tpb, int* groups, int* gpp) {
   const int shape = dw_fused_shape(H, Wd, K);
-  *tiles_x = cdiv(Wd, shape ? 28 : 16); *tiles_y = cdiv(H, shape == 2 ? 7 : shape ? 14 : 8);
+  *tiles_x = cdiv(Wd, shape ? 28 : 16); *tiles_y = cdiv(H, shape == 2 ? 7 : shape == 3 ? 8 : shape ? 14 : 8);
   const int ntile = (*tiles_x) * (*tiles_y);
   long ntiles = (long)N * ntile;
   int chunks = cdiv(C, CB);
@@ -845,7 +882,7 @@ static void dw_fused_geom(int N, int H, int Wd, int C, int K, int* tiles_x, int*
   // instead of 4096; the 3x3 kernel (3 per CU) wants the opposite: 6.8 ms at 4096, 8.0 ms at 1024.
   static const long override_target = getenv("MX_DW_GROUPS") ? atol(getenv("MX_DW_GROUPS")) : 0;
   // (round 4, rewritten kernel: the 14 x 28 / 5x5 form is level or 2-5 % faster at 512 - one workgroup per slot of its 2 per CU)
-  const long group_target = override_target > 0 ? override_target : (shape == 2 ? 768 : shape ? 512 : K == 5 ? 1024 : 4096);
+  const long group_target = override_target > 0 ? override_target : (shape == 3 ? 4096 : shape == 2 ? 768 : shape ? 512 : K == 5 ? 1024 : 4096);
   long g = group_target / chunks;
   if (g < 1) g = 1;
   if (g > ntiles) g = ntiles;
@@ -881,6 +918,7 @@ static int dw_check(const DwArgs& a, int K, int S, const char* who) {
   } while (0)
 
 #define FWD_S1(k) dw_fwd_kernel<k, 1, 8, 16, 4>
+#define FWD_S1W(k) dw_fwd_kernel<k, 1, 8, 28, 7>
 #define FWD_S2(k) dw_fwd_kernel<k, 2, 8, 8, 2>
 #define BWW_S1(k) dw_bwd_weight_kernel<k, 1, 8, 16, 4>
 #define BWW_S2(k) dw_bwd_weight_kernel<k, 2, 8, 8, 2>
@@ -890,8 +928,14 @@ static int dw_check(const DwArgs& a, int K, int S, const char* who) {
 extern "C" {
 
 // tile groups of the forward: ~MX_DWF_GROUPS workgroups per launch (default 4096), each walking tpb consecutive tiles
+// 1: the stride-1 forward takes its 8 x 28 tiles (images a multiple of 28 pixels wide: 224 / 112 / 56 / 28 of B7 at 448; MX_DWF_WIDE=0: never)
+static int dw_fwd_wide(int Wo, int S) {
+  static const int on = getenv("MX_DWF_WIDE") ? atoi(getenv("MX_DWF_WIDE")) : 1;
+  return (on && S == 1 && Wo % 28 == 0) ? 1 : 0;
+}
+
 static void dw_fwd_geom(int N, int Ho, int Wo, int C, int S, bool pooled, int* tiles_x, int* tiles_y, int* tpb, int* groups, int* gpp) {
-  *tiles_x = cdiv(Wo, S == 1 ? 16 : 8); *tiles_y = cdiv(Ho, 8);
+  *tiles_x = cdiv(Wo, dw_fwd_wide(Wo, S) ? 28 : S == 1 ? 16 : 8); *tiles_y = cdiv(Ho, 8);
   const int ntile = (*tiles_x) * (*tiles_y);
   const long ntiles = (long)N * ntile;
   const int chunks = cdiv(C, CB);
@@ -953,7 +997,8 @@ int mx_dwconv_fwd(const float* X, const float* scale, const float* shift, const 
     a.counters = reinterpret_cast<unsigned*>(ws);
     a.poolpart = reinterpret_cast<float*>((char*)ws + MX_WS_COUNTER_BYTES);
   }
-  DW_DISPATCH(FWD_S1, FWD_S2, K, S, grid, (hipStream_t)stream, a);
+  if (dw_fwd_wide(Wo, S)) DW_DISPATCH(FWD_S1W, FWD_S2, K, S, grid, (hipStream_t)stream, a);
+  else DW_DISPATCH(FWD_S1, FWD_S2, K, S, grid, (hipStream_t)stream, a);
   MX_LAUNCH_CHECK();
   return MX_OK;
 }
@@ -1044,7 +1089,9 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
     grid = dim3((unsigned)(cdiv((long)a.chunks * N, 8) * 8 * a.gpp), 1, 1);
   }
   const int shape = dw_fused_shape(H, Wd, K);
-  if (shape == 2) {
+  if (shape == 3) {
+    hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 8, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);
+  } else if (shape == 2) {
     if (K == 3) hipLaunchKernelGGL((dw_bwd_fused_kernel<3, 7, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL((dw_bwd_fused_kernel<5, 7, 28, 7>), grid, dim3(256), 0, (hipStream_t)stream, a);
   } else if (shape) {

@@ -69,3 +69,41 @@ def test_fused_depthwise_backward_matches_float64(N, H, W, C, K, bn0, res):
         assert float((got - want_part).abs().max()) <= 5e-5 * float(want_part.abs().max()) + 1e-5
     else:
         assert part is None
+
+
+@pytest.mark.parametrize("N,H,W,C,K,S,act", [
+    (2, 28, 28, 64, 5, 1, True), (2, 28, 28, 40, 3, 1, True), (3, 56, 56, 36, 5, 1, True), (2, 112, 112, 32, 3, 1, False),     # 8 x 28 row-staged tiles
+    (1, 30, 84, 16, 5, 1, True), (2, 12, 28, 32, 3, 1, True),                                                                  # ... ragged rows
+    (2, 20, 37, 48, 5, 1, True), (2, 16, 16, 20, 3, 1, False),                                                                 # 8 x 16 tiles
+    (2, 56, 56, 32, 3, 2, True), (2, 28, 28, 24, 5, 2, True)])                                                                 # stride 2 (TF 'same' padding)
+def test_depthwise_forward_matches_float64(N, H, W, C, K, S, act):
+    """mx_dwconv_fwd (model.py:76-79: BN0 + SiLU of the expand output applied while the tile is staged, depthwise convolution with
+    TensorFlow 'same' padding, the BatchNorm-1 statistics as partial rows; eval mode: the SE squeeze sums instead) against float64, on
+    both stride-1 tile shapes, stride 2, ragged images and channel counts."""
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(N * 1000 + H * 10 + C + K + S)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=g)
+    X = rn(N, H, W, C)
+    Wt = rn(C, 1, K, K) * 0.3
+    st = ops.BNState(torch.rand(C, device=DEV, generator=g) + 0.5, rn(C) * 0.1, rn(C) * 0.1, torch.rand(C, device=DEV, generator=g) + 0.5) if act else None
+    Ho, Wo = (H + S - 1) // S, (W + S - 1) // S
+    pt_h, pt_w = max((Ho - 1) * S + K - H, 0), max((Wo - 1) * S + K - W, 0)
+    x64 = X.double()
+    if act:
+        x64 = F.silu(st.scale.double() * x64 + st.shift.double())
+    xp = F.pad(x64.permute(0, 3, 1, 2), (pt_w // 2, pt_w - pt_w // 2, pt_h // 2, pt_h - pt_h // 2))
+    want = F.conv2d(xp, Wt.double(), stride=S, groups=C).permute(0, 2, 3, 1)
+    assert pt_h // 2 == pt_w // 2
+    outs = [ops.dwconv_fwd(X, Wt, K, S, pt_h // 2, Ho, Wo, st=st, want_stats=True) for _ in range(2)]
+    (Y, stats), (Y2, stats2) = outs
+    assert torch.equal(Y, Y2) and torch.equal(stats, stats2)
+    assert float((Y.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
+    ssum = stats.double().sum(0)
+    assert float((ssum[0] - want.sum((0, 1, 2))).abs().max()) <= 2e-5 * float(want.abs().sum((0, 1, 2)).max()) + 1e-5
+    assert float((ssum[1] - (want * want).sum((0, 1, 2))).abs().max()) <= 2e-5 * float((want * want).sum((0, 1, 2)).max()) + 1e-5
+    # inference form: no statistics, the squeeze sums of swish(ps * y + pb) per sample instead
+    ps, pb = torch.rand(C, device=DEV, generator=g) + 0.5, rn(C) * 0.1
+    Yp, pooled = ops.dwconv_fwd(X, Wt, K, S, pt_h // 2, Ho, Wo, st=st, pool=(ps, pb))
+    assert float((Yp.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-6
+    want_pool = F.silu(ps.double() * want + pb.double()).sum((1, 2))
+    assert float((pooled.double() - want_pool).abs().max()) <= 2e-5 * float(want_pool.abs().max()) + 1e-5

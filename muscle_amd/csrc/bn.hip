@@ -206,12 +206,15 @@ struct GEff {
   const float* a; const float* b;
   int C, rps;
   __device__ __forceinline__ void get(long r, int c, float4& g, float4& x) const {
+    get_n(r, (int)((unsigned)r / (unsigned)rps), c, g, x);   // (32-bit: a 64-bit division is ~60 instructions per float4; rows < 2^31)
+  }
+  // the same with the row's sample index n = r / rps supplied (the streaming kernels carry it along instead of dividing)
+  __device__ __forceinline__ void get_n(long r, int n, int c, float4& g, float4& x) const {
     g = ld4(G + r * C + c);
     x = ld4(X + r * C + c);
-    const long n = r / rps;
     if (rs) { float s = rs[n]; g.x *= s; g.y *= s; g.z *= s; g.w *= s; }
     if (gate) {
-      float4 gt = ld4(gate + n * C + c), ad = ld4(add + n * C + c);
+      float4 gt = ld4(gate + (long)n * C + c), ad = ld4(add + (long)n * C + c);
       g.x = g.x * gt.x + ad.x; g.y = g.y * gt.y + ad.y; g.z = g.z * gt.z + ad.z; g.w = g.w * gt.w + ad.w;
     }
     if (a) {
@@ -557,21 +560,40 @@ __global__ __launch_bounds__(64 * B1_NL) void bn1_sums_finalize_kernel(const flo
 
 // ---------------------------------------------------------------------------
 // streaming elementwise kernels
+// Index walk of the grid-stride streaming kernels over [rows][C / 4] float4s: (row, float4 column, sample) are carried from one
+// element to the next by additions and one compare each - the 64-bit divisions i / c4n and r / rps cost ~100 instructions per float4,
+// more than the rest of the loop body, and these kernels run beside the VALU-bound weight-gradient GEMMs of the side stream.
+struct RowWalk {
+  long r; int c4, n, rem;                 // row, float4 column, sample, row within the sample
+  int dr, dc, dn, drem, c4n, rps;
+  __device__ __forceinline__ RowWalk(long i0, long stride, int c4n_, int rps_) : c4n(c4n_), rps(rps_) {
+    r = i0 / c4n; c4 = (int)(i0 - r * c4n);
+    n = (int)(r / rps); rem = (int)(r - (long)n * rps);
+    const long sr = stride / c4n;
+    dr = (int)sr; dc = (int)(stride - sr * c4n);
+    dn = dr / rps; drem = dr - dn * rps;
+  }
+  __device__ __forceinline__ void next() {
+    c4 += dc; r += dr; n += dn; rem += drem;
+    if (c4 >= c4n) { c4 -= c4n; ++r; ++rem; }
+    if (rem >= rps) { rem -= rps; ++n; }
+  }
+};
+
 // ---------------------------------------------------------------------------
 // out = (sc[c]*P + sh[c]) [swish] [* gate[n,c]] [* rs[n]] [+ R]
 __global__ __launch_bounds__(256) void bn_apply_kernel(const float* P, const float* sc, const float* sh, const float* rs,
                                                        const float* R, const float* gate, float* out, long total4, int C,
                                                        int rps, int act) {
-  const int c4n = C / 4;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-    long r = i / c4n;
-    int c = (int)(i - r * c4n) * 4;
+  RowWalk w(blockIdx.x * 256L + threadIdx.x, (long)gridDim.x * 256, C / 4, rps);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256, w.next()) {
+    const int c = w.c4 * 4;
     float4 v = ld4(P + i * 4);
     float4 a = ld4(sc + c), b = ld4(sh + c);
     v.x = a.x * v.x + b.x; v.y = a.y * v.y + b.y; v.z = a.z * v.z + b.z; v.w = a.w * v.w + b.w;
     if (act) { v.x = swishf_(v.x); v.y = swishf_(v.y); v.z = swishf_(v.z); v.w = swishf_(v.w); }
-    if (gate) { float4 g = ld4(gate + (r / rps) * C + c); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
-    if (rs) { float s = rs[r / rps]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
+    if (gate) { float4 g = ld4(gate + (long)w.n * C + c); v.x *= g.x; v.y *= g.y; v.z *= g.z; v.w *= g.w; }
+    if (rs) { float s = rs[w.n]; v.x *= s; v.y *= s; v.z *= s; v.w *= s; }
     if (R) { float4 q = ld4(R + i * 4); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
     st4(out + i * 4, v);
   }
@@ -580,12 +602,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* P, const flo
 // out = c1[c]*g_eff + c2[c]*X + c3[c]   (BatchNorm backward, data gradient)
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(GEff e, const float* c1, const float* c2, const float* c3,
                                                            float* out, long total4) {
-  const int c4n = e.C / 4;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256) {
-    long r = i / c4n;
-    int c = (int)(i - r * c4n) * 4;
+  RowWalk w(blockIdx.x * 256L + threadIdx.x, (long)gridDim.x * 256, e.C / 4, e.rps);
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total4; i += (long)gridDim.x * 256, w.next()) {
+    const int c = w.c4 * 4;
     float4 g, x;
-    e.get(r, c, g, x);
+    e.get_n(w.r, w.n, c, g, x);
     float4 k1 = ld4(c1 + c), k2 = ld4(c2 + c), k3 = ld4(c3 + c);
     float4 o;
     o.x = k1.x * g.x + k2.x * x.x + k3.x; o.y = k1.y * g.y + k2.y * x.y + k3.y;

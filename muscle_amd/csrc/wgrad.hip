@@ -54,7 +54,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 3 : 4) void wgrad_small_kernel(W
       const int c = lc + LPR * i;
       rx[i] = (rin && c < xch) ? ld4(px + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
       if (XMODE == MX_BNACT)
-        gt[i] = (rin && c < xch && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+        gt[i] = (rin && c < xch && a.X.rowp) ? ld4(a.X.rowp + (long)((unsigned)r / (unsigned)a.X.rps) * a.Ci + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
   };
   auto store = [&](float* buf, long r0) {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256, (TE * TF >= 16 && XMODE == MX_BNACT) ? 3 : 4) 
       const long r = r0 + row;
       const bool ok = idx < 16 * TCI / 4 && r < r_end && ci0 + 4 * c < a.Ci;
       rx[i] = ok ? ld4(a.X.p + r * a.ldx + ci0 + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (XMODE == MX_BNACT) gt[i] = (ok && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + ci0 + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (XMODE == MX_BNACT) gt[i] = (ok && a.X.rowp) ? ld4(a.X.rowp + (long)((unsigned)r / (unsigned)a.X.rps) * a.Ci + ci0 + 4 * c) : make_float4(1.f, 1.f, 1.f, 1.f);
     }
   };
   auto store = [&](float* buf, long r0) {
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WtArgs a) {
       const long r = r0 + 8 * rg + i;
       const bool ok = colok && r < r_end;
       rv[i] = ok ? ld4(base + r * ld + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
-      if (XMODE == MX_BNACT && (!GBN || isx)) gt[i] = (ok && isx && a.X.rowp) ? ld4(a.X.rowp + (r / a.X.rps) * (long)a.Ci + col0) : make_float4(1.f, 1.f, 1.f, 1.f);
+      if (XMODE == MX_BNACT && (!GBN || isx)) gt[i] = (ok && isx && a.X.rowp) ? ld4(a.X.rowp + (long)((unsigned)r / (unsigned)a.X.rps) * a.Ci + col0) : make_float4(1.f, 1.f, 1.f, 1.f);
       if (GBN && !isx) gt[i] = ok ? ld4(a.G2 + r * ld + col0) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };

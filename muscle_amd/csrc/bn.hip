@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
     long r = r0 + tr;
     const long st = g.rpp;
     float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, c0 = b0, c1 = b0, d0 = b0, d1 = b0;
-    if (NOUT == 1) {
+    if (NOUT == 1) {        // (eight rows for the two-tensor reductions as well: measured 0.1-0.2 ms per step slower, profiles/r04_knob_sweep.txt)
       for (; r + 7 * st < r1; r += 8 * st) {     // one-tensor reductions (pooling): eight independent rows in flight
         f.eval(r, 4 * c4, a0, a1);
         f.eval(r + st, 4 * c4, b0, b1);

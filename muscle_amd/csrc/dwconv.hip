@@ -680,8 +680,11 @@ __global__ __launch_bounds__(256, (TH == 7) ? 3 : (K == 5 || TH != 8) ? 2 : 3) v
       float2 cur[QX];                              // the centre pixels of the current half
 #pragma unroll
       for (int o = 0; o < QX; ++o) cur[o] = xr[o];
+      // a wave none of whose lanes has a pixel group in this pass (14 x 28: 56 groups in passes of 16 - waves 2 and 3 of the fourth) leaves
+      // its issue slots to the other workgroup's waves instead of running 500 masked instructions
+      const bool wave_has_work = __builtin_amdgcn_ballot_w64(rok) != 0;
 #pragma unroll HU
-      for (int h = 0; h < NH; ++h) {
+      for (int h = 0; h < (wave_has_work ? NH : 0); ++h) {
         __builtin_amdgcn_sched_barrier(0);
         const int pxh = h * QX;
         int wlh = c2;                              // opaque per half: the K*K weight pairs are loop-invariant and would otherwise be

@@ -601,8 +601,11 @@ extern "C" int mx_get_gemm_mode(void);
 static bool wt_use_split(int Co, int Ci) {
   if (mx_get_gemm_mode() < 1) return false;
   const double eff = ((double)Co / (128.0 * cdiv(Co, 128))) * ((double)Ci / (128.0 * cdiv(Ci, 128)));
-  static const double min_eff = getenv("MX_WGRAD_SPLIT_EFF") ? atof(getenv("MX_WGRAD_SPLIT_EFF")) : 0.8;
-  return mx_get_gemm_mode() == 2 || eff >= min_eff;          // 128 x 128 tiles only: not where they pad much
+  // 128 x 128 tiles only.  0.8 until late round 4 (not where they pad much); with the row groups filling the chip for few-tile outputs
+  // (wt_plan) the padded shapes win as well - 960 x 160 and 480 x 80 (0.59 of their tiles used): 105 -> 76 us and 136 -> 77 us, and the
+  // step 96.9 -> 95.15 ms on one box (profiles/r04_knob_sweep.txt)
+  static const double min_eff = getenv("MX_WGRAD_SPLIT_EFF") ? atof(getenv("MX_WGRAD_SPLIT_EFF")) : 0.55;
+  return mx_get_gemm_mode() == 2 || eff >= min_eff;
 }
 
 static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
@@ -621,6 +624,17 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     // ids) keep every tested shape level with the fp32 kernel and are within 0.3 ms per step of g = 8.
     const int maxg = R / 256 > 0 ? R / 256 : 1;
     int groups = 16;
+    // few output tiles (960 x 160: 16, 480 x 80: 4 - taken by this kernel when MX_WGRAD_SPLIT_EFF admits their padding): their partial
+    // matrices are small, so the groups are what fills the chip - ~768 workgroups, at most 128 groups of at least 512 rows
+    static const int fill = getenv("MX_WGRAD_SPLIT_FILL") ? atoi(getenv("MX_WGRAD_SPLIT_FILL")) : 1;
+    const int tiles = p->tiles_co * p->tiles_ci;
+    if (fill && tiles < 48) {
+      int want = (cdiv(768, tiles) + 7) / 8 * 8;
+      const int cap = R / 512 >= 8 ? R / 512 / 8 * 8 : 8;
+      if (want > 128) want = 128;
+      if (want > cap) want = cap;
+      if (want > groups) groups = want;
+    }
     if (groups > maxg) groups = maxg >= 8 ? maxg / 8 * 8 : maxg;
     static const int forced_split = getenv("MX_WGRAD_SPLIT_GROUPS") ? atoi(getenv("MX_WGRAD_SPLIT_GROUPS")) : 0;
     if (forced_split > 0) groups = forced_split < maxg ? forced_split : maxg;

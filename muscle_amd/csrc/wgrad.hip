@@ -760,8 +760,9 @@ int mx_pw_wgrad_small_bnbwd(const float* G, const float* G2, const float* coef, 
 }
 
 bool mx_wgrad_uses_split(int R, int Co, int Ci) {
-  WgPlan sp;
-  if (wg_plan(R, Co, Ci, &sp)) return false;          // the small-output kernel is tried first (ops.pw_wgrad) and stays fp32
+  // the small-output kernel is tried first (ops.pw_wgrad) and stays fp32 - where it has an instantiation for the shape (any prologue):
+  // 480 x 80 has a plan but no kernel, and goes to the tiled kernels
+  if (mx_pw_wgrad_small_ws(R, Co, Ci, MX_PLAIN) > 0 || mx_pw_wgrad_small_ws(R, Co, Ci, MX_BNACT) > 0) return false;
   WtPlan p;
   return wt_plan(R, Co, Ci, MX_PLAIN, &p) && wt_use_split(Co, Ci);
 }

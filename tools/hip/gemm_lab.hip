@@ -319,7 +319,7 @@ static void run_widths(int M, int K, int N) {
   float* A = dalloc((long)M * K, 1, 1.f); float* W = dalloc((long)N * K, 2, 0.05f);
   float* C2 = dalloc((long)M * N, 5, 0.f);
   float* st2 = dalloc((long)mx_pw_fwd_parts(M, N, K) * 2 * N, 8, 0.f);
-  void* planes; CK(hipMalloc(&planes, mx_pw_planes_bytes(N, K)));
+  void* planes; CK(hipMalloc(&planes, mx_pw_planes_bytes(N, K) + 8192));      // (slack: a padded last tile reads up to 16 rows past the image)
   long row[5] = {(long)W, (long)planes, N, K, 0};
   long* table; CK(hipMalloc(&table, sizeof(row))); CK(hipMemcpy(table, row, sizeof(row), hipMemcpyHostToDevice));
   mx_pw_planes_batch(table, 1, mx_pw_planes_tiles(N, K), nullptr);
@@ -327,7 +327,8 @@ static void run_widths(int M, int K, int N) {
   float best[6]; for (float& b : best) b = 1e30f;
   for (int round = 0; round < 3; ++round)
     for (int i = 0; i < 6; ++i) {
-      if (wv[i] && wv[i] != 64 && wv[i] != 128 && N % wv[i]) continue;
+      // odd widths: where they divide N, or pad it by at most 16 columns that stay inside the image's 128-row padding + slack
+      if (wv[i] && wv[i] != 64 && wv[i] != 128 && N % wv[i] && ((N + wv[i] - 1) / wv[i] * wv[i] - ((N + 127) & ~127) > 16 || (N + wv[i] - 1) / wv[i] * wv[i] - N > N / 16)) continue;
       g_split_nj = wv[i];
       best[i] = std::min(best[i], time_us([&] { mx_pw_fwd_planes(A, planes, C2, M, K, N, K, N, nullptr, nullptr, 0, st2, nullptr); }, 5));
     }
@@ -341,6 +342,7 @@ static void run_widths(int M, int K, int N) {
 
 int main(int argc, char** argv) {
   if (argc >= 2 && !strcmp(argv[1], "widths")) {
+    if (argc >= 5) { run_widths(atoi(argv[2]), atoi(argv[3]), atoi(argv[4])); return 0; }
     static const Shape sh[] = {{25088, 160, 960}, {25088, 960, 160}, {25088, 224, 1344}, {25088, 1344, 224}, {25088, 384, 2304}, {25088, 2304, 384},
                                {25088, 640, 3840}, {25088, 3840, 640}, {6272, 384, 2304}, {6272, 2304, 384}, {6272, 640, 3840}, {6272, 3840, 640},
                                {6272, 224, 1344}, {6272, 1344, 224}, {401408, 288, 48}, {100352, 480, 80}, {12544, 192, 1152}, {12544, 1152, 192}};

@@ -240,6 +240,16 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
                         const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,
                         int Wd, int C, int K, int pad_lo, void* stream);
 
+/* mx_dwconv_bwd_fused with the BatchNorm-0 backward statistics FINISHED in the kernel (a0 / b0 / part required): the last workgroup of
+ * every 32-channel chunk adds the partial rows in mx_bn_bwd_finalize's order and writes dgamma / dbeta (+=) and the coefficients o1 o2 o3
+ * of dX = o1*g + o2*X + o3 - bit for bit what mx_bn_bwd_finalize(part, ...) would have left, without its launch.  ws: zeroed scratch
+ * whose first 64 KB are arrival counters (left zero by the call), 16-byte aligned. */
+int mx_dwconv_bwd_fused_bn0(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
+                            const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
+                            const float* W, float* gX, float* dW, float* dw_scratch, float* part, int N, int H, int Wd, int C, int K,
+                            int pad_lo, void* ws, long ws_bytes, double count, const float* gamma, const float* mean, const float* rstd,
+                            int training, float* dgamma, float* dbeta, float* o1, float* o2, float* o3, void* stream);
+
 int mx_dw_parts_reduce(const float* part, int P, int n, float* dW, void* stream);
 
 /* ---- SE excitation (model.py:83-84) and stem patches (model.py:131,175) -------------------------------- */

@@ -389,10 +389,6 @@ struct BnFwdFin {
   double count; const float* gamma; const float* beta; float* rmean; float* rvar; float momentum, eps; int training;
   float* scale; float* shift; float* mean_out; float* rstd_out;
 };
-struct BnBwdFin {
-  double count; const float* gamma; const float* mean; const float* rstd; int training;
-  float* dgamma; float* dbeta; float* c1; float* c2; float* c3;
-};
 
 __device__ __forceinline__ void bn_fwd_finalize_one(int c, double st0, double st1, double count, const float* gamma,
                                                     const float* beta, float* rmean, float* rvar, float momentum, float eps,
@@ -444,24 +440,6 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* acc, int
   bn_fwd_finalize_one(c, st0, st1, count, gamma, beta, rmean, rvar, momentum, eps, training, scale, shift, mean_out, rstd_out);
 }
 
-__device__ __forceinline__ void bn_bwd_finalize_one(int c, double sg, double sgx, double count, const float* gamma,
-                                                    const float* mean, const float* rstd, int training, float* dgamma,
-                                                    float* dbeta, float* c1, float* c2, float* c3) {
-  double m = mean[c], r = rstd[c], gm = gamma[c];
-  double dg = r * (sgx - m * sg);
-  dgamma[c] += (float)dg;
-  dbeta[c] += (float)sg;
-  if (training) {
-    double k = gm * r * r * (dg / count);
-    c1[c] = (float)(gm * r);
-    c2[c] = (float)(-k);
-    c3[c] = (float)(-gm * r * (sg / count) + k * m);
-  } else {
-    c1[c] = (float)(gm * r);
-    c2[c] = 0.f;
-    c3[c] = 0.f;
-  }
-}
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const double* acc, int slices, int C, double count, const float* gamma,
                                        const float* mean, const float* rstd, int training, float* dgamma, float* dbeta,

@@ -100,6 +100,58 @@ __device__ __forceinline__ bool mx_last_arriver(unsigned* counter, unsigned tota
   return *lds_flag != 0u;
 }
 
+// BatchNorm backward finalisation of one channel from its two sums (shared by bn.hip and by the producers that finish their own
+// statistics, dwconv.hip): dgamma / dbeta (+=) and the coefficients of dX = c1*g + c2*X + c3.
+struct BnBwdFin {
+  double count; const float* gamma; const float* mean; const float* rstd; int training;
+  float* dgamma; float* dbeta; float* c1; float* c2; float* c3;
+};
+
+__device__ __forceinline__ void bn_bwd_finalize_one(int c, double sg, double sgx, double count, const float* gamma,
+                                                    const float* mean, const float* rstd, int training, float* dgamma,
+                                                    float* dbeta, float* c1, float* c2, float* c3) {
+  double m = mean[c], r = rstd[c], gm = gamma[c];
+  double dg = r * (sgx - m * sg);
+  dgamma[c] += (float)dg;
+  dbeta[c] += (float)sg;
+  if (training) {
+    double k = gm * r * r * (dg / count);
+    c1[c] = (float)(gm * r);
+    c2[c] = (float)(-k);
+    c3[c] = (float)(-gm * r * (sg / count) + k * m);
+  } else {
+    c1[c] = (float)(gm * r);
+    c2[c] = 0.f;
+    c3[c] = 0.f;
+  }
+}
+
+// The reduction of bn_reduce_finalize_kernel<true> (bn.hip) for 32 channels starting at c0, by ONE workgroup of 256 threads: 8 row
+// lanes walk the P partial rows part[P][2][C] in the same order and association, so a producer that finishes its own statistics
+// (the last workgroup to arrive) leaves the same bits as the separate launch did.  `sh` = 2 x 8 x 32 doubles of LDS.
+__device__ __forceinline__ void bn_bwd_reduce_finalize_32(const float* part, int P, int C, int c0, const BnBwdFin& b, double* sh) {
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = c0 + cl;
+  double s0 = 0.0, s1 = 0.0;
+  if (c < C) {
+    int p = rl;
+    for (; p + 24 < P; p += 32) {
+      float a0 = part[(long)p * 2 * C + c], b0 = part[(long)p * 2 * C + C + c];
+      float a1 = part[(long)(p + 8) * 2 * C + c], b1 = part[(long)(p + 8) * 2 * C + C + c];
+      float a2 = part[(long)(p + 16) * 2 * C + c], b2 = part[(long)(p + 16) * 2 * C + C + c];
+      float a3 = part[(long)(p + 24) * 2 * C + c], b3 = part[(long)(p + 24) * 2 * C + C + c];
+      s0 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
+      s1 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
+    }
+    for (; p < P; p += 8) { s0 += (double)part[(long)p * 2 * C + c]; s1 += (double)part[(long)p * 2 * C + C + c]; }
+  }
+  sh[rl * 32 + cl] = s0; sh[256 + rl * 32 + cl] = s1;
+  __syncthreads();
+  if (rl != 0 || c >= C) return;
+  for (int i = 1; i < 8; ++i) { s0 += sh[i * 32 + cl]; s1 += sh[256 + i * 32 + cl]; }
+  bn_bwd_finalize_one(c, s0, s1, b.count, b.gamma, b.mean, b.rstd, b.training, b.dgamma, b.dbeta, b.c1, b.c2, b.c3);
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 

@@ -457,6 +457,8 @@ struct DwFusedArgs {
   float* gx; float* dwpart; float* part;              // outputs: gX (or g*swish'), dW partial rows [groups][C*K*K], BN0 partial sums [groups][2][C]
   int N, H, W, C, pad, tiles_x, tiles_y, tiles_per_block;
   int xcd, gpp, chunks;    // xcd = 1: 1-D grid, the gpp tile groups of one (sample, channel chunk) plane run on ONE XCD (dw_fwd_kernel)
+  unsigned* fin_counters;  // non-null: the last workgroup of a channel chunk to arrive finishes the BatchNorm-0 backward statistics itself
+  BnBwdFin fin;            //   (dgamma / dbeta +=, c1 c2 c3) from the partial rows - the separate bn_reduce_finalize launch is gone
 };
 
 // Tile shapes (TH x TW output pixels per staged tile, PX consecutive pixels per thread "group", 16 groups per pass):
@@ -820,9 +822,17 @@ __global__ __launch_bounds__(256, (TH == 7) ? 3 : (K == 5 || TH != 8) ? 2 : 3) v
     __syncthreads();
     if (tid < 2 * CB) {
       const int cc = tid % CB;
-      if (c0 + cc < a.C)
-        a.part[(long)grp_id * 2 * a.C + (tid / CB) * a.C + c0 + cc] =
-            ((slots[tid] + slots[2 * CB + tid]) + slots[4 * CB + tid]) + slots[6 * CB + tid];
+      if (c0 + cc < a.C) {
+        const float v = ((slots[tid] + slots[2 * CB + tid]) + slots[4 * CB + tid]) + slots[6 * CB + tid];
+        float* dst = a.part + (long)grp_id * 2 * a.C + (tid / CB) * a.C + c0 + cc;
+        if (a.fin_counters) mx_st_wt(dst, v); else *dst = v;
+      }
+    }
+    if (a.fin_counters) {
+      // every group of this channel chunk has left its row: the last one to arrive adds them in bn_reduce_finalize_kernel's order
+      __shared__ unsigned fin_flag;
+      if (mx_last_arriver(a.fin_counters + chunk_id, gridDim.x, &fin_flag))
+        bn_bwd_reduce_finalize_32(a.part, (int)gridDim.x, a.C, c0, a.fin, reinterpret_cast<double*>(td));
     }
   }
 }
@@ -1070,10 +1080,42 @@ int mx_dwconv_bwd_fused_parts(int N, int H, int Wd, int C, int K) {
 
 // Stride-1 backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> SE gate fused (see dw_bwd_fused_kernel):
 //   gX = dwconv^T(dd) [* swish'(a0*X+b0)] [+ residual];  dW += sum dd*act(X);  part = BN0 backward partial sums (a0 != NULL)
+static int dw_bwd_fused_impl(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
+                            const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
+                            const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,
+                            int Wd, int C, int K, int pad_lo, void* stream, unsigned* fin_counters, const BnBwdFin* fin);
+
 int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
                         const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
                         const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,
                         int Wd, int C, int K, int pad_lo, void* stream) {
+  return dw_bwd_fused_impl(dA, D, gate, add, a1, b1, c1, c2, c3, X, a0, b0, W, residual, gX, dW, dw_scratch, part, N, H, Wd, C, K, pad_lo,
+                           stream, nullptr, nullptr);
+}
+
+// The same with the BatchNorm-0 backward statistics FINISHED in the kernel (a0 / b0 / part required): the last workgroup of every
+// 32-channel chunk adds the partial rows in mx_bn_bwd_finalize's order and writes dgamma / dbeta (+=) and the coefficients o1 o2 o3 of
+// dX = o1*g + o2*X + o3 - what a separate mx_bn_bwd_finalize(part, ...) launch would have left, bit for bit.  ws: zeroed scratch whose
+// first 64 KB are arrival counters (left zero), as for mx_pool_sum.  Returns MX_EARG for geometries it does not take (the XCD-grouped
+// grid): call mx_dwconv_bwd_fused + mx_bn_bwd_finalize then.
+int mx_dwconv_bwd_fused_bn0(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
+                            const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
+                            const float* W, float* gX, float* dW, float* dw_scratch, float* part, int N, int H, int Wd, int C, int K,
+                            int pad_lo, void* ws, long ws_bytes, double count, const float* gamma, const float* mean, const float* rstd,
+                            int training, float* dgamma, float* dbeta, float* o1, float* o2, float* o3, void* stream) {
+  MX_CHECK_ARG(a0 && b0 && part, "dwconv_bwd_fused_bn0: the BatchNorm-0 form only (a0, b0, part)");
+  MX_CHECK_ARG(ws && ws_bytes >= MX_WS_COUNTER_BYTES && ((uintptr_t)ws & 15) == 0, "dwconv_bwd_fused_bn0: scratch with %d bytes of counters required", MX_WS_COUNTER_BYTES);
+  MX_CHECK_ARG(gamma && mean && rstd && dgamma && dbeta && o1 && o2 && o3 && count > 0, "dwconv_bwd_fused_bn0: null pointer");
+  MX_CHECK_ARG(cdiv(C, CB) <= MX_WS_COUNTERS, "dwconv_bwd_fused_bn0: too many channel chunks");
+  BnBwdFin fin{count, gamma, mean, rstd, training, dgamma, dbeta, o1, o2, o3};
+  return dw_bwd_fused_impl(dA, D, gate, add, a1, b1, c1, c2, c3, X, a0, b0, W, nullptr, gX, dW, dw_scratch, part, N, H, Wd, C, K, pad_lo,
+                           stream, reinterpret_cast<unsigned*>(ws), &fin);
+}
+
+static int dw_bwd_fused_impl(const float* dA, const float* D, const float* gate, const float* add, const float* a1, const float* b1,
+                            const float* c1, const float* c2, const float* c3, const float* X, const float* a0, const float* b0,
+                            const float* W, const float* residual, float* gX, float* dW, float* dw_scratch, float* part, int N, int H,
+                            int Wd, int C, int K, int pad_lo, void* stream, unsigned* fin_counters, const BnBwdFin* fin) {
   MX_CHECK_ARG(dA && D && gate && add && a1 && b1 && c1 && c2 && c3 && X && W && gX && dw_scratch, "dwconv_bwd_fused: null pointer");
   MX_CHECK_ARG((a0 == nullptr) == (b0 == nullptr), "dwconv_bwd_fused: a0/b0 come together");
   MX_CHECK_ARG(!a0 || part, "dwconv_bwd_fused: BN0 present -> part required");
@@ -1090,6 +1132,10 @@ int mx_dwconv_bwd_fused(const float* dA, const float* D, const float* gate, cons
   if (a.gpp > 0) {
     a.xcd = 1;
     grid = dim3((unsigned)(cdiv((long)a.chunks * N, 8) * 8 * a.gpp), 1, 1);
+  }
+  if (fin_counters) {
+    MX_CHECK_ARG(!a.xcd, "dwconv_bwd_fused_bn0: not with the XCD-grouped grid (MX_DW_XCD)");
+    a.fin_counters = fin_counters; a.fin = *fin;
   }
   const int shape = dw_fused_shape(H, Wd, K);
   if (shape == 3) {

@@ -430,6 +430,11 @@ def _masked_stream(device, n_cus: int):
 # otherwise take wave slots on every CU and the small latency-bound kernels of the main chain queue behind them
 # (profiles/r02_b_timeline.txt: se_bwd_b 134.9 us instead of 25.7 under overlap).
 WGRAD_CUS = int(os.environ.get("MUSCLE_WGRAD_CUS", "0"))
+# MUSCLE_FUSED_BN0_FINALIZE=1: the fused depthwise backward finishes the BatchNorm-0 backward statistics itself (its last workgroup per
+# channel chunk; mx_dwconv_bwd_fused_bn0, same bits) instead of a bn_reduce_finalize launch between it and the BN0 apply / the folded
+# GEMMs: 51 launches fewer per step and no time gained (alternating on one box 96.15 / 96.21, 96.74 / 96.60, 96.47 / 96.17 ms) - the
+# backward is bound by the sum of its kernels' work, not by the chain's launches.  Off; built and tested (tests/test_gpu_dwfused.py).
+FUSED_BN0_FINALIZE = os.environ.get("MUSCLE_FUSED_BN0_FINALIZE", "0") != "0"
 # SE excitation parameter gradients (se_bwd_b) on the side stream instead of the data-gradient chain
 SE_PARAMS_ASIDE = os.environ.get("MUSCLE_SE_PARAMS_ASIDE", "0") != "0"     # measured 0.6 ms per step SLOWER (profiles/r04_knob_sweep.txt)
 # Priority of the weight-gradient side stream: 0 = as the main stream, -1 = higher, 1 = LOWER (a raw HIP stream: torch only offers -1 / 0)
@@ -585,9 +590,12 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
         fused = FUSED_DW_BACKWARD and b.stride == 1 and b.pad_lo == (b.kernel - 1) // 2
         if fused:
             # stride 1: BN1 data gradient, depthwise weight + data gradients and the BN0 backward sums in one kernel
-            gx, part0 = ops.dwconv_bwd_fused(ga.view(N, t.Ho, t.Wo, b.cexp), t.d_raw, t.gate, add, t.bn1, c1, dw_in, dw_st,
-                                             m._depthwise_conv.weight, sink.of(m._depthwise_conv.weight), b.kernel, b.pad_lo,
-                                             residual=None if dw_st is not None else skip_res, defer=lane.dw_reduce)
+            bn_mod0 = m._bn0 if b.expand else backbone._bn0
+            fin0 = (bn_mod0, sink.of(bn_mod0.weight), sink.of(bn_mod0.bias), training) if (FUSED_BN0_FINALIZE and dw_st is not None) else None
+            res = ops.dwconv_bwd_fused(ga.view(N, t.Ho, t.Wo, b.cexp), t.d_raw, t.gate, add, t.bn1, c1, dw_in, dw_st,
+                                       m._depthwise_conv.weight, sink.of(m._depthwise_conv.weight), b.kernel, b.pad_lo,
+                                       residual=None if dw_st is not None else skip_res, defer=lane.dw_reduce, bn0=fin0)
+            gx, part0, c0_fin = res if fin0 is not None else (res[0], res[1], None)
             del ga
         else:
             # BN1 backward with g = (ga*gate + add) * swish'(bn1(d_raw)), in place over ga
@@ -608,7 +616,7 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
             kind = ops.bnbwd_fold_takes(M, b.cexp, b.cin) if (fused and b.expand and not fold and wtp is not None and ops.DGRAD_AS_FORWARD) else None
             fold2 = (kind == "tile" and FOLD_BN0_BOTH) or (kind == "small" and FOLD_BN0_EARLY)
             if fused:
-                c0 = ops.bn_bwd_coeffs(part0, M, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training)
+                c0 = c0_fin if c0_fin is not None else ops.bn_bwd_coeffs(part0, M, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training)
                 if not fold and not fold2:
                     dz = ops.bn_bwd_apply_plain(gx2, raw2, c0, gx2)
             else:

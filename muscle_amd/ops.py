@@ -473,22 +473,37 @@ def dw_parts_reduce(scratch, dW):
     call("mx_dw_parts_reduce", ptr(scratch), P, n, ptr(dW), stream())
 
 
-def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNState], W, dW, K, pad_lo, *, residual=None, defer=None):
+def dwconv_bwd_fused(dA, D, gate, add, st1: BNState, c1, X, st0: Optional[BNState], W, dW, K, pad_lo, *, residual=None, defer=None,
+                     bn0=None):
     """Stride-1 fused backward of [BN0+SiLU] -> dwconv -> BN1 -> SiLU -> gate; returns (gX, BN0 partial sums or None).
     defer: a callable taking (scratch, dW) - the addition of the weight gradient's partial rows is handed to it (e.g. queued for
-    the side stream) instead of being launched behind the kernel."""
+    the side stream) instead of being launched behind the kernel.
+    bn0 = (bn module, dgamma, dbeta, training): the kernel finishes the BatchNorm-0 backward statistics itself (its last workgroup per
+    channel chunk; mx_dwconv_bwd_fused_bn0) and a third value is returned: the [3, C] coefficients bn_bwd_coeffs would have made."""
     N, H, Wd, C = X.shape
     gX = _f32(N, H, Wd, C, device=X.device)
     P = lib().mx_dwconv_bwd_fused_parts(N, H, Wd, C, K)
     part = _f32(P, 2, C, device=X.device) if st0 is not None else None
     scratch = _f32(P, C * K * K, device=X.device)
     cb, cs = c1.data_ptr(), 4 * c1.shape[1]
+    if bn0 is not None and st0 is not None and residual is None:
+        bn, dgamma, dbeta, training = bn0
+        co = _f32(3, C, device=X.device)
+        ob = co.data_ptr()
+        ws, wsn = _scratch(X.device, 65536)
+        _call_ws("mx_dwconv_bwd_fused_bn0", ptr(dA), ptr(D), ptr(gate), ptr(add), ptr(st1.scale), ptr(st1.shift), cb, cb + cs, cb + 2 * cs,
+                 ptr(X), ptr(st0.scale), ptr(st0.shift), ptr(W), ptr(gX), None if defer is not None else ptr(dW), ptr(scratch), ptr(part),
+                 N, H, Wd, C, K, pad_lo, ws, wsn, float(N * H * Wd), ptr(bn.weight), ptr(st0.mean), ptr(st0.rstd), int(training),
+                 ptr(dgamma), ptr(dbeta), ob, ob + 4 * C, ob + 8 * C, stream())
+        if defer is not None:
+            defer(scratch, dW)
+        return gX, part, co
     call("mx_dwconv_bwd_fused", ptr(dA), ptr(D), ptr(gate), ptr(add), ptr(st1.scale), ptr(st1.shift), cb, cb + cs,
          cb + 2 * cs, ptr(X), ptr(st0.scale) if st0 else None, ptr(st0.shift) if st0 else None, ptr(W), ptr(residual), ptr(gX),
          None if defer is not None else ptr(dW), ptr(scratch), ptr(part), N, H, Wd, C, K, pad_lo, stream())
     if defer is not None:
         defer(scratch, dW)
-    return gX, part
+    return (gX, part, None) if bn0 is not None else (gX, part)
 
 
 def se_bn1_pool(dA2d, X2d, st: BNState, rows_per_sample):

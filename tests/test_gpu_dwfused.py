@@ -67,6 +67,23 @@ def test_fused_depthwise_backward_matches_float64(N, H, W, C, K, bn0, res):
         assert torch.equal(part, part2)
         got = part.double().sum(0)
         assert float((got - want_part).abs().max()) <= 5e-5 * float(want_part.abs().max()) + 1e-5
+        # the same kernel finishing the BatchNorm-0 backward statistics itself (mx_dwconv_bwd_fused_bn0): what the separate
+        # mx_bn_bwd_finalize launch leaves - bit for bit while both add the partial rows in one pass (<= 1024 rows), run twice
+        bn = torch.nn.BatchNorm2d(C).to(DEV)
+        with torch.no_grad():
+            bn.weight.copy_(torch.rand(C, device=DEV, generator=g) + 0.5)
+        rows = N * H * W
+        dg_a, db_a = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+        c_sep = ops.bn_bwd_coeffs(part, rows, bn, st0, dg_a, db_a, True)
+        for _ in range(2):
+            dg_b, db_b = torch.zeros(C, device=DEV), torch.zeros(C, device=DEV)
+            dW3 = torch.zeros_like(Wt)
+            gX3, part3, c_fin = ops.dwconv_bwd_fused(dA, D, gate, add, st1, c1, X, st0, Wt, dW3, K, (K - 1) // 2, bn0=(bn, dg_b, db_b, True))
+            assert torch.equal(gX3, gX) and torch.equal(part3, part) and torch.equal(dW3, dW)
+            if part.shape[0] <= 1024:
+                assert torch.equal(c_fin, c_sep) and torch.equal(dg_b, dg_a) and torch.equal(db_b, db_a)
+            else:
+                assert torch.allclose(c_fin, c_sep, rtol=1e-5, atol=1e-6) and torch.allclose(dg_b, dg_a, rtol=1e-5, atol=1e-5)
     else:
         assert part is None
 

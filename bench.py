@@ -511,6 +511,9 @@ def main():
                                 f"pipe (peak {MFMA_BF16_PEAK_TFLOPS:.0f} / 6 = {SPLIT_PEAK_TFLOPS:.1f} TFLOP/s fp32-equivalent), the rest on "
                                 f"exact-fp32 MFMA (peak {MFMA_F32_PEAK_TFLOPS})",
                      "flop_share_split": split_share,
+                     # not measured by this run: the in-kernel clock of the split forward / data-gradient kernel after 1.5 s of back-to-back
+                     # launches (tools/hip/gemm_lab stamps M K N 3, profiles/r04_planes_stamps.txt); `peak` above is quoted at 2.4 GHz
+                     "clock_held_under_load_GHz": [1.84, 2.01],
                      "measured_over": f"{inst_steps} eager steps right after the timed region (HIP events per launch, weight-gradient "
                                       f"side stream off; {inst_dt / inst_steps * 1e3:.1f} ms/step in that mode)",
                      "launches_per_step": gemm_launches // max(inst_steps, 1),

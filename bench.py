@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from muscle_amd import arch, synth  # noqa: E402
+from muscle_amd._host import cpu_share  # noqa: E402
 
 GEMM_CALLS = ("mx_pw_fwd", "mx_pw_fwd_planes", "mx_pw_fwd_planes_act", "mx_pw_dgrad_bnbwd_planes", "mx_pw_dgrad", "mx_pw_wgrad", "mx_pw_wgrad_small", "mx_pw_wgrad_tile",
               "mx_pw_wgrad_tile_bnbwd", "mx_pw_wgrad_small_bnbwd")
@@ -201,7 +202,7 @@ def _cpu_steps(model_name, size, view, ep, n, warm, timed_n, seconds_budget):
 def cpu_baseline(model_name, size, view, ep, seconds_budget=25.0):
     """The oracle (a CPU port of the reference's loop body) on this host's cores; bounded sample: 2 warm-up + up to 5
     timed steps of the headline model at batch 2, and BASELINE.json configs[0] (EfficientNet-B0, 2 images, 224x224)."""
-    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))     # the GPU box's CPU share for one GPU
+    torch.set_num_threads(max(1, min(16, cpu_share())))     # the GPU box's CPU share for one GPU (cgroup quota, not os.cpu_count())
     n = 2
     sec, cnt = _cpu_steps(model_name, size, view, ep, n, 2, 5, seconds_budget)
     sec0, cnt0 = _cpu_steps("efficientnet-b0", 224, 112, ep, n, 2, 5, 10.0)

@@ -13,7 +13,9 @@ from typing import Dict, Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmuscle_hip.so")
+# MUSCLE_HIP_LIB names another build of the SAME ABI (lab A/B runs, tools/dbg/lib_ab.sh): nothing is ever copied over the
+# in-tree library, and the override announces itself on stderr so a lab build cannot pass for the product silently.
+LIB_PATH = os.environ.get("MUSCLE_HIP_LIB") or os.path.join(_HERE, "libmuscle_hip.so")
 
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "muscle_hip.h")
 
@@ -57,6 +59,9 @@ def lib() -> ctypes.CDLL:
             raise MuscleHipError(
                 f"{LIB_PATH} not found: build it with `python -m muscle_amd._build` "
                 "(or __graft_entry__.build()); there is no fallback path")
+        if os.environ.get("MUSCLE_HIP_LIB"):
+            import sys
+            print(f"[muscle_amd] MUSCLE_HIP_LIB: loading {LIB_PATH} instead of the in-tree library", file=sys.stderr)
         L = ctypes.CDLL(LIB_PATH)
         L.mx_last_error.restype = ctypes.c_char_p
         L.mx_version.restype = ctypes.c_int

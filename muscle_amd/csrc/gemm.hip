@@ -1168,7 +1168,11 @@ __global__ __launch_bounds__(256, AMODE == MX_BNBWD ? 2 : 3) void gemm_nt_split3
       af[i][1] = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
       af[i][2] = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
     }
+    // s_barrier is not a memory clobber for the compiler: without the two compiler fences the ds_reads of `st` below and the next
+    // stage's LDS-DMA could legally be scheduled across it (the hardware ordering is the s_waitcnt above + the barrier itself)
+    asm volatile("" ::: "memory");
     __builtin_amdgcn_s_barrier();      // every wave's share of stage kt has landed; every read of the other stage is retired
+    asm volatile("" ::: "memory");
     if (kt + 1 < nk) { issue_w(kt + 1); load_a(kt + 1); }
     const unsigned char* st = smem + (kt & 1) * STAGE;
     constexpr int PW[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};

@@ -622,8 +622,11 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     // its length - at g = 8 (3136 rows at R = 25 088, 1568 at 12 544) it is 2.2-2.6x the exact-fp32 tiled kernel's, whose own
     // groups are short; tests/test_gpu_split.py holds the split kernel to 1.5x.  Sixteen groups (two per XCD under the XCD-aware
     // ids) keep every tested shape level with the fp32 kernel and are within 0.3 ms per step of g = 8.
+    // The bound is on the CHAIN, not on the count: at most 1568 rows per group, so R = 50 176 (B7 at batch 64, or batch 32 at larger
+    // images) takes 32 groups instead of running 3136-row chains at 16 (tests/test_gpu_split.py has R = 50 176 and 62 720 cases).
     const int maxg = R / 256 > 0 ? R / 256 : 1;
-    int groups = 16;
+    int groups = (cdiv(R, 1568) + 7) / 8 * 8;
+    if (groups < 16) groups = 16;
     // few output tiles (960 x 160: 16, 480 x 80: 4 - taken by this kernel when MX_WGRAD_SPLIT_EFF admits their padding): their partial
     // matrices are small, so the groups are what fills the chip - ~768 workgroups, at most 128 groups of at least 512 rows
     static const int fill = getenv("MX_WGRAD_SPLIT_FILL") ? atoi(getenv("MX_WGRAD_SPLIT_FILL")) : 1;

@@ -118,7 +118,11 @@ def fold_eval_bn(backbone, cfg: NetCfg):
     expand weight (+ bias), BN2 folded into the project weight (+ bias), BN1 as scale / shift for the depthwise kernel's
     SE squeeze and the project GEMM's operand prologue.  One launch per block (mx_fold_block): done once per model load by
     MuSCLe.fold_eval_bn(), or per forward when no cache is installed (always correct; the no-grad forward of view 2 in
-    the training loop, train_mcl.py:205-206, is that case: the weights have just been stepped)."""
+    the training loop, train_mcl.py:205-206, is that case: the weights have just been stepped).
+
+    The returned dict ALIASES the backbone's fold arena: the next fold overwrites the same tensors in place and returns a dict
+    with a new 'fingerprint' - a dict kept from an earlier call then holds the NEW values under its OLD fingerprint.  Holders
+    must re-fold when `fold_fingerprint` moves (backbone_forward does) or clone what they keep."""
     dev = backbone._conv_stem.weight.device
     # the folded tensors live with the backbone and are overwritten by every fold (the per-step refold of the training loop's
     # no-grad forward allocates nothing), so the pre-split images of the folded weights (ops.PlanesPlan: one table, one launch)
@@ -151,6 +155,8 @@ def fold_eval_bn(backbone, cfg: NetCfg):
         arena["ptrs"] = tuple(t.data_ptr() for _, _, t in mats)
         arena["plan"] = None if torch.cuda.is_current_stream_capturing() else ops.PlanesPlan([t for _, _, t in mats])
         backbone.__dict__["_fold_arena"] = arena
+    if arena["plan"] is None and not torch.cuda.is_current_stream_capturing():
+        arena["plan"] = ops.PlanesPlan([t for _, _, t in arena["mats"]])      # first built under capture: the plan is made on the next eager fold
     if arena["plan"] is not None:
         for (bi, name, _), im in zip(arena["mats"], arena["plan"].run()):
             arena["blocks"][bi][name] = im

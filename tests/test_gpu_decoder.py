@@ -24,35 +24,29 @@ def build_dec(name, seed):
     return cfg, sd, m.to(DEV)
 
 
+_PROBES = {}
+
+
 def test_seg_forward_backward_vs_oracle():
-    from oracle import mcl_oracle as O
+    """Against the stored fp32 + fp64 passes of the CPU oracle (oracle/gen_oracle_runs.py::seg_run)."""
+    from test_gpu_model import run_case
     name, n, size, seed = "efficientnet-b3", 2, 96, 31
     cfg, sd, model = build_dec(name, seed)
     x = T(synth.normal(seed, "x", (n, 3, size, size)).astype(np.float32))
     du = gu.drop_draws(cfg, n, 5)
-    def oracle():
-        nets = []
-        for dt in (torch.float32, torch.float64):
-            net = O.OracleDecNet(name, sd, dtype=dt)
-            net.train()
-            outs = net.forward_seg(x.to(dt), du)
-            probes = [T(synth.normal(seed, f"probe{i}", tuple(o.shape)).astype(np.float32)).to(dt) for i, o in enumerate(outs)]
-            sum((o * p).sum() for o, p in zip(outs, probes)).backward()
-            nets.append((net, [o.detach() for o in outs]))
-        return nets
-
-    nets = gu.cached(("seg", name, n, size, seed), oracle)
-    (net32, outs32), (net64, _) = nets
+    F = gu.load_run(run_case("seg", name, n, size, seed))
     model.train()
     got = model(x.to(DEV), cam="seg", drop_u={k: v.to(DEV) for k, v in du.items()})
-    for g, o in zip(got, outs32):
-        assert tuple(g.shape) == tuple(o.shape)
-        close(g, o.detach(), 5e-4)
+    gu.check_outputs(got, F, "out", 5e-4, _PROBES)
     sum((g * T(synth.normal(seed, f"probe{i}", tuple(g.shape)).astype(np.float32)).to(DEV)).sum() for i, g in enumerate(got)).backward()
-    print("worst grad rel err", check_grads(model, net32, net64, None))
+    print("worst grad rel err", check_grads(model, F, cache=_PROBES))
+    rs = {str(k): F["rs_vals"][F["rs_off"][i]:F["rs_off"][i + 1]] for i, k in enumerate(F["rs_keys"])}
+    seen = 0
     for k, v in model.state_dict().items():
         if k.endswith("running_var"):
-            assert gu.rel_err(v.cpu(), net32.t[k]) <= 1e-4, k
+            assert gu.rel_err(v.cpu().flatten(), rs[k]) <= 1e-4, k
+            seen += 1
+    assert seen == len(rs)
 
 
 def test_seg_forward_golden():

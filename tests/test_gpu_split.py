@@ -254,6 +254,7 @@ def test_mcl_step_golden_in_split_mode(split_everywhere, fname):
 
 
 @pytest.mark.parametrize("R,Co,Ci,mode", [(25088, 384, 2304, "plain"), (12544, 2304, 384, "bnact"), (1111, 200, 136, "bnact"),
+                                          (50176, 384, 640, "plain"), (62720 + 5, 256, 384, "bnact"),      # longer than the bench shape: the chain bound, not the group count
                                           (4096, 1344, 224, "affine"), (2048, 128, 128, "plain"), (5000 + 3, 640, 384, "bnact")])
 def test_split_wgrad_matches_fp64_as_well_as_fp32_mfma(R, Co, Ci, mode):
     """The tiled weight gradient in split arithmetic (wgrad_split_kernel: fragments along the pixel rows, transposed in

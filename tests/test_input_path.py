@@ -245,13 +245,7 @@ def test_dataset_and_worker_loader(tmp_path):
     assert got == names
 
 
-@pytest.mark.gpu
-def test_staged_loader_yields_loop_body_batches(tmp_path):
-    from muscle_amd import data as D
-    lst, root, labels, names = _voc_tree(tmp_path)
-    ds = D.VOC12ClsPix(lst, root, labels=labels)
-    loader = D.StagedLoader(ds, batch_size=2, device=torch.device("cuda:0"), num_workers=1, shuffle=True,
-                            generator=torch.Generator().manual_seed(3))
+def _check_staged_batches(loader, names):
     assert len(loader) == 3
     seen = []
     for nm, batch in loader:
@@ -260,6 +254,42 @@ def test_staged_loader_yields_loop_body_batches(tmp_path):
         assert batch["view2"].shape == (2, 3, 224, 224) and batch["ori_coord"].shape == (2, 4)
         assert torch.isfinite(batch["img"]).all()
     assert sorted(seen) == names
+
+
+@pytest.mark.gpu
+def test_staged_loader_yields_loop_body_batches(tmp_path):
+    """In this process the host half runs inline (num_workers=0): the pytest process has the HIP runtime's threads and
+    locks by now, and DataLoader workers are fork()ed children - in round 4 the driver's run died inside this test with a
+    worker forked out of the GPU-initialised test process.  The worker path on the GPU box is the next test's, in a fresh
+    child; the workers' seeding / hand-back is test_dataset_and_worker_loader's (CPU)."""
+    from muscle_amd import data as D
+    lst, root, labels, names = _voc_tree(tmp_path)
+    ds = D.VOC12ClsPix(lst, root, labels=labels)
+    loader = D.StagedLoader(ds, batch_size=2, device=torch.device("cuda:0"), num_workers=0, shuffle=True,
+                            generator=torch.Generator().manual_seed(3))
+    _check_staged_batches(loader, names)
+
+
+@pytest.mark.gpu
+def test_staged_loader_with_workers_in_a_fresh_process(tmp_path):
+    """StagedLoader(num_workers=2) the way a training script runs it: a fresh process creates the stager (GPU initialised),
+    then the DataLoader forks its workers at the first iteration (train_mcl.py:130-153 has the same order).  Child process
+    with its own time limit, like tests/test_gpu_dist.py."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = ("import sys, torch; sys.path.insert(0, %r); sys.path.insert(0, %r); torch.set_num_threads(2)\n"
+            "import pathlib, test_input_path as t\n"
+            "from muscle_amd import data as D\n"
+            "lst, root, labels, names = t._voc_tree(pathlib.Path(sys.argv[1]))\n"
+            "ds = D.VOC12ClsPix(lst, root, labels=labels)\n"
+            "loader = D.StagedLoader(ds, batch_size=2, device=torch.device('cuda:0'), num_workers=2, shuffle=True,\n"
+            "                        generator=torch.Generator().manual_seed(3))\n"
+            "t._check_staged_batches(loader, names); t._check_staged_batches(loader, names)\n"      # second epoch: persistent workers
+            "print('LOADER-OK')\n") % (here, os.path.dirname(here))
+    r = subprocess.run([sys.executable, "-c", code, str(tmp_path)], capture_output=True, text=True, timeout=150)
+    assert r.returncode == 0 and "LOADER-OK" in r.stdout, (r.stdout[-1000:], r.stderr[-3000:])
 
 
 @pytest.mark.gpu

@@ -4,6 +4,9 @@ CPU only.  Tolerances: the oracle and the reference are both fp32 on CPU and dif
 vectorisation / summation order, so element-wise 1e-5 relative to the tensor's max and 2e-5 on
 scalars; gradient summaries 1e-4 of the tensor's norm.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
@@ -348,3 +351,35 @@ def test_rapid_eval_matches_reference():
         m, per = O.eval_miou(TP, P, T_)
         assert np.allclose(per, z["loglists"][ti, :21], rtol=0, atol=1e-9)
         assert abs(m - z["loglists"][ti, 21]) <= 1e-9
+
+
+# ---- the stored oracle passes the GPU tests compare against must be what the oracle at HEAD produces -------------------
+def _run_cases():
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gen_oracle_runs as R
+    return [(n, f) for n, f in R.all_cases() if "b7" not in n]       # the B7 case (15 s) is regenerated by the script only
+
+
+@pytest.mark.parametrize("case", [n for n, _ in _run_cases()])
+def test_oracle_run_fixtures_are_current(case):
+    """tests/golden/oracle_runs/<case>.npz (what test_model_forward_backward, test_backbone_forward_backward and
+    test_seg_forward_backward_vs_oracle hold the HIP path to on the GPU box) equals a fresh fp32 + fp64 pass of
+    oracle/mcl_oracle.py: a change to the oracle or to the synthetic generators cannot leave a stale fixture behind."""
+    fresh = dict(_run_cases())[case]()
+    F = gu.load_run(case)
+    assert set(F.files) == set(fresh.keys())
+    for k, v in fresh.items():
+        a, b = np.asarray(v), F[k]
+        assert a.shape == b.shape and a.dtype.kind == b.dtype.kind, k
+        if a.dtype.kind in "iU":
+            assert np.array_equal(a, b), k
+        elif k == "g_stat":
+            assert np.array_equal(np.isnan(a), np.isnan(b))
+            live = ~np.isnan(a[:, 0])
+            sc = np.maximum(a[live, 0:1], 1e-30)
+            assert np.all(np.abs(a[live][:, [0, 2]] - b[live][:, [0, 2]]) <= 1e-5 * np.abs(b[live][:, [0, 2]]) + 1e-30)
+            assert np.all(np.abs(a[live][:, 3:] - b[live][:, 3:]) <= 1e-6 * b[live][:, 2:3] * 10 + 1e-30)
+            # column 1 = max|g32 - g64| is round-off itself: only its size is reproducible
+            assert np.all(a[live, 1] <= 4 * b[live, 1] + 1e-6 * sc[:, 0]) and np.all(b[live, 1] <= 4 * a[live, 1] + 1e-6 * sc[:, 0])
+        else:
+            assert np.abs(a.astype(np.float64) - b).max() <= 2e-5 * max(np.abs(b).max(), 1e-30), k

@@ -1,11 +1,9 @@
-# usage: lib_ab.sh A.so B.so [reps] - alternating bench.py runs (20 steps) with the library swapped, one box
+# usage: lib_ab.sh A.so B.so [reps] - alternating bench.py runs (20 steps) of two builds of the library on one box.
+# The builds are selected through MUSCLE_HIP_LIB (muscle_amd/_lib.py); the in-tree library is never overwritten.
 set -e
 mkdir -p gpurun_out
-cp muscle_amd/libmuscle_hip.so /tmp/lib_keep.so
 a=$1; b=$2; reps=${3:-2}
 for r in $(seq $reps); do for v in $a $b; do
-  cp $v muscle_amd/libmuscle_hip.so
-  timeout -k 10 200 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-other-arith --no-configs > gpurun_out/lib_ab.json 2>gpurun_out/lib_ab.err
+  MUSCLE_HIP_LIB=$(realpath $v) timeout -k 10 200 python bench.py --steps 20 --warmup 4 --no-cpu-baseline --no-other-arith --no-configs > gpurun_out/lib_ab.json 2>gpurun_out/lib_ab.err
   echo "$(basename $v) $(python -c "import json;d=json.loads(open('gpurun_out/lib_ab.json').read().strip().splitlines()[-1]);print(d['ms_per_step'],d['value'],d['roofline']['gemm_ms_per_step'],d['roofline']['non_gemm_ms_per_step'])")" | tee -a gpurun_out/lib_ab.txt
 done; done
-cp /tmp/lib_keep.so muscle_amd/libmuscle_hip.so

@@ -589,7 +589,437 @@ __global__ __launch_bounds__(256, 2) void wgrad_split_kernel(WtArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Round 5: the split weight gradient as ONE software-pipelined instruction stream (plain operands; the prologue modes keep
+// the kernel above).  Same tile, same loader mapping, same LDS image, same MFMA order as wgrad_split_kernel - the results
+// are bit-identical - but:
+//   * two LDS stages (96 KB, one workgroup = one wave per SIMD per CU) and ONE barrier per 32-row slab;
+//   * the fragments of a 16-row step are read one step AHEAD of their MFMAs (two fragment register sets), so no ds_read
+//     latency sits between a barrier and the matrix pipe; the split + plane stores of slab s+1 are placed BETWEEN the MFMAs of
+//     slab s, ~4 vector instructions per MFMA gap (an MFMA holds the vector issue for 8 of its 32 cycles,
+//     MI355X_MICROARCH.md 'vector-instruction ISSUE cost'); the raw rows of slab s+2 are in flight meanwhile (two raw sets);
+//   * every global load is a buffer load through a descriptor that covers exactly the group's rows: rows past the group's
+//     end and the columns past the matrix read as zeros by the range check - no compares, no branches, so the slab is one
+//     basic block the scheduler can order.
+// The first structure spent ~3500 cycles per slab and CU with three workgroups resident (MFMA work: 1536): a split/store
+// phase, a barrier, and an MFMA phase whose ds_reads were waited for right in front of their MFMAs.
+#ifndef WPIPE_PF
+#define WPIPE_PF 3         // raw row sets: slab s + WPIPE_PF is requested while slab s is multiplied (bytes in flight per CU = 32 KB x (WPIPE_PF - 1))
+#endif
+#ifndef WPIPE_KNOCK
+#define WPIPE_KNOCK 0      // diagnostic builds of tools/hip/gemm_lab only: 1 no split, 2 no split / plane stores, 3 no MFMA, 4 no fragment reads, 5 no global traffic, 6 split but no plane stores
+#endif
+
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t wbuf_rsrc(const float* base, long bytes) {
+  // wave-uniform by construction (blockIdx / wave-id only): the readfirstlanes make that provable, no waterfall loops
+  const unsigned long long p = (unsigned long long)base;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  const unsigned n = __builtin_amdgcn_readfirstlane((unsigned)bytes);
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long long)hi << 32) | lo), 0, n, 0x00020000);
+}
+
+#define WPIPE_MFMA(GV, XV, T, EF)                                                                                              \
+  acc[(EF) >> 1][(EF) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(GV[(EF) >> 1][PG[T]], XV[(EF) & 1][PX[T]], acc[(EF) >> 1][(EF) & 1], 0, 0, 0)
+
+#ifdef WPIPE_STAMPS        // diagnostic builds of tools/hip/gemm_lab only: shader-clock stamps per workgroup (start, loop start, loop end, end, 2 x realtime)
+__device__ unsigned long long* wpipe_stamps;
+#define WPIPE_STAMP(slot) do { if (wpipe_stamps && threadIdx.x == 0) { wpipe_stamps[blockIdx.x * 8l + (slot)] = __builtin_amdgcn_s_memtime(); \
+    if ((slot) == 0 || (slot) == 3) wpipe_stamps[blockIdx.x * 8l + 4 + ((slot) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define WPIPE_STAMP(slot) do { } while (0)
+#endif
+__global__ __launch_bounds__(256, 1) void wgrad_split_pipe_kernel(WtArgs a) {
+  // LDS image of one plane: [4 k-groups][4 column classes (col & 3)][36 = 32 columns (col >> 2) + 4 pad] chunks of 16 bytes (8 k of one
+  // column).  A loader pass (16 lanes = 16 consecutive 4-column chunks, one column class) writes 16 consecutive chunks; a fragment
+  // pass (16 consecutive columns of one k-group) reads chunks 36 b + a + 4 m (b = col & 3, a = (col >> 2) & 3): 16 different bank groups
+  // either way.  The first kernel's [128 columns][64 bytes] image is conflict-free for the reads only: its plane stores hit 4 bank
+  // groups per pass (4-way), which made the LDS, not the matrix pipe, the busiest unit (profiles/r05_wgrad_pipe_lab.txt).
+  constexpr int PLANE = 4 * 144 * 16, STAGE = 6 * PLANE;    // G h/m/l, X h/m/l per stage
+  extern __shared__ __attribute__((aligned(16))) unsigned char wp_smem[];      // 2 * STAGE
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform facts in SGPRs
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int wco = wave >> 1, wci = wave & 1;
+  const int tiles = a.tiles_co * a.tiles_ci;
+  const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+  const int group = (j / tiles) * 8 + xcd, tile = j % tiles;
+  if (group >= a.groups) return;
+  const int co0 = (tile / a.tiles_ci) * 128, ci0 = (tile % a.tiles_ci) * 128;
+  const long r_beg = (long)group * a.rows_per_group;
+  const long r_end = min((long)a.R, r_beg + a.rows_per_group);
+  const int rows = (int)(r_end - r_beg);
+
+  // loader: waves 0-1 move G, 2-3 move X; thread = (4-column chunk c of 32, row group rg of 4): rows 8 rg .. 8 rg + 7 of the slab
+  const bool isx = wave >= 2;
+  const int lt = tid & 127, c = lt & 31, rg = lt >> 5;
+  const int col0 = (isx ? ci0 : co0) + 4 * c;
+  const bool colok = col0 < (isx ? a.Ci : a.Co);
+  const int ld = __builtin_amdgcn_readfirstlane(isx ? a.ldx : a.ldg);
+  const __amdgpu_buffer_rsrc_t rs = wbuf_rsrc((isx ? a.X.p : a.G) + r_beg * ld, WPIPE_KNOCK == 5 ? 0 : (long)rows * ld * 4);
+  const unsigned vbase = colok ? (unsigned)((8 * rg * ld + col0) * 4) : 0x7f000000u;      // past every record: reads as zero
+  const unsigned slab_bytes = (unsigned)(32 * ld * 4), row_bytes = (unsigned)(ld * 4);
+
+  typedef float wf4 __attribute__((ext_vector_type(4)));
+  wf4 raw[WPIPE_PF][8];
+  auto gload = [&](wf4 (&rv)[8], int s) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      rv[i] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + (unsigned)i * row_bytes, (unsigned)s * slab_bytes, 0));
+  };
+  // split of column 4 c + jc, row pair q (rows 2 q, 2 q + 1 of the thread's eight): slices A / B / C of 4 / 4 / 3 vector instructions
+  unsigned sh_[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, sm_[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, sl_[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};      // two columns' planes
+  float r0_, r1_, s0_, s1_;
+  unsigned u0_, u1_, v0_, v1_;
+  unsigned char* const wbase = wp_smem + (isx ? 3 * PLANE : 0);
+  const int woff0 = (rg * 144 + c) * 16;                     // + 36 * 16 per column class
+
+#define WPIPE_X(RV, JC, Q, ROW) ((JC) == 0 ? RV[2 * (Q) + (ROW)][0] : (JC) == 1 ? RV[2 * (Q) + (ROW)][1] : (JC) == 2 ? RV[2 * (Q) + (ROW)][2] : RV[2 * (Q) + (ROW)][3])
+#define WPIPE_SLICE_A(RV, JC, Q)                                                              \
+  { const float x0 = WPIPE_X(RV, JC, Q, 0), x1 = WPIPE_X(RV, JC, Q, 1);                       \
+    u0_ = __float_as_uint(x0) & 0xffff0000u; u1_ = __float_as_uint(x1) & 0xffff0000u;        \
+    r0_ = x0 - __uint_as_float(u0_); r1_ = x1 - __uint_as_float(u1_); }
+#define WPIPE_SLICE_B()                                                                       \
+  { v0_ = __float_as_uint(r0_) & 0xffff0000u; v1_ = __float_as_uint(r1_) & 0xffff0000u;      \
+    s0_ = r0_ - __uint_as_float(v0_); s1_ = r1_ - __uint_as_float(v1_); }
+#define WPIPE_SLICE_C(B, Q)                                                                   \
+  { sh_[B][Q] = __builtin_amdgcn_perm(u1_, u0_, 0x07060302u); sm_[B][Q] = __builtin_amdgcn_perm(v1_, v0_, 0x07060302u); \
+    sl_[B][Q] = __builtin_amdgcn_perm(__float_as_uint(s1_), __float_as_uint(s0_), 0x07060302u); }
+#define WPIPE_WRITE(STG, JC)                                                                                  \
+  { unsigned char* o_ = wbase + (STG) * STAGE + woff0 + (JC) * 576;                                                    \
+    *reinterpret_cast<uint4*>(o_) = make_uint4(sh_[0][0], sh_[0][1], sh_[0][2], sh_[0][3]);                   \
+    *reinterpret_cast<uint4*>(o_ + PLANE) = make_uint4(sm_[0][0], sm_[0][1], sm_[0][2], sm_[0][3]);           \
+    *reinterpret_cast<uint4*>(o_ + 2 * PLANE) = make_uint4(sl_[0][0], sl_[0][1], sl_[0][2], sl_[0][3]); }
+
+  wf32x16 acc[2][2];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+  wbf16x8 gv0[2][3], xv0[2][3], gv1[2][3], xv1[2][3];
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { gv1[e][p][i] = (__bf16)0.f; xv1[e][p][i] = (__bf16)0.f; }
+  const int fro = (hf * 144 + (l31 & 3) * 36 + (l31 >> 2)) * 16;         // this lane's chunk of k-group hf, column l31 of a 32-column block
+  const int cgo = fro + wco * 256, cxo = fro + 3 * PLANE + wci * 256;       // + 128 per 32-column block e, + 2 * 144 * 16 per 16-row step
+  auto frd = [&](const unsigned char* st, int ks, wbf16x8 (&gv)[2][3], wbf16x8 (&xv)[2][3]) {
+    if (WPIPE_KNOCK == 4) return;
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        gv[e][p] = *reinterpret_cast<const wbf16x8*>(st + cgo + p * PLANE + e * 128 + ks * 4608);
+        xv[e][p] = *reinterpret_cast<const wbf16x8*>(st + cxo + p * PLANE + e * 128 + ks * 4608);
+      }
+  };
+  constexpr int PG[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
+
+  const int ns = (rows + 31) / 32;
+  WPIPE_STAMP(0);
+  // prologue: slab 0 split into stage 0, slab 1 in flight
+  gload(raw[0], 0);
+  gload(raw[1], 1);
+  if (WPIPE_PF >= 3) gload(raw[WPIPE_PF >= 3 ? 2 : 0], 2);
+  if (WPIPE_PF >= 4) gload(raw[WPIPE_PF >= 4 ? 3 : 0], 3);
+#pragma unroll
+  for (int jc = 0; jc < 4; ++jc) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { WPIPE_SLICE_A(raw[0], jc, q); WPIPE_SLICE_B(); WPIPE_SLICE_C(0, q); }
+    WPIPE_WRITE(0, jc);
+  }
+  __builtin_amdgcn_s_waitcnt(0xc07f);      /* lgkmcnt(0), as a builtin: the compiler's own wait counting sees it */
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // One slab: MFMAs of (slab s - 1, second step) from set 1, then of (slab s, first step) from set 0; between them the split of the raw
+  // set RB (slab s + 1) into the other stage.  48 MFMAs, 32 row pairs: a pair's three slices go behind three consecutive MFMAs,
+  // a column's three plane stores behind its fourth pair.
+  // Every gap (the 24 cycles an MFMA leaves the vector issue free) gets one slice of the split (3-4 vector instructions) and at most one
+  // memory instruction: the 12 fragment reads of the NEXT 16-row step in gaps 0-11 (consumption order), 4 of the 8 raw-row requests of
+  // slab s + WPIPE_PF in gaps 13 / 16 / 19 / 22, and the three plane stores of a finished column two gaps apart behind it (second register
+  // set, so the next column's split goes on).  Bursts cost: 8 x 1 KB requests in a row hold the CU's one address unit for ~130 cycles, a
+  // 16-byte LDS store takes its wave's issue for >= 13 (MI355X_MICROARCH.md, LDS table) - neither fits into one gap.
+#define WPIPE_FRD1(ST, KS, R, GVT, XVT)                                                                       \
+  { const int g_ = (R) >> 2, e_ = (R) & 1;                                                                     \
+    if (WPIPE_KNOCK != 4) {                                                                                    \
+      if ((((R) >> 1) & 1) == 0) GVT[e_][g_ == 0 ? 0 : g_ == 1 ? 2 : 1] = *reinterpret_cast<const wbf16x8*>((ST) + cgo + (g_ == 0 ? 0 : g_ == 1 ? 2 : 1) * PLANE + e_ * 128 + (KS) * 4608); \
+      else XVT[e_][g_ == 0 ? 2 : g_ == 1 ? 0 : 1] = *reinterpret_cast<const wbf16x8*>((ST) + cxo + (g_ == 0 ? 2 : g_ == 1 ? 0 : 1) * PLANE + e_ * 128 + (KS) * 4608); } }
+#define WPIPE_GLD1(RVT, I, S)                                                                                 \
+  RVT[I] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + (unsigned)(I) * row_bytes, (unsigned)(S) * slab_bytes, 0));
+#define WPIPE_WRITE1(STG, JC, P)                                                                              \
+  if (WPIPE_KNOCK == 6) { _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) asm volatile("" :: "v"((P) == 0 ? sh_[(JC) & 1][k_] : (P) == 1 ? sm_[(JC) & 1][k_] : sl_[(JC) & 1][k_])); } else \
+  { unsigned char* o_ = wbase + (STG) * STAGE + woff0 + (JC) * 576 + (P) * PLANE;                              \
+    if ((P) == 0) *reinterpret_cast<uint4*>(o_) = make_uint4(sh_[(JC) & 1][0], sh_[(JC) & 1][1], sh_[(JC) & 1][2], sh_[(JC) & 1][3]);      \
+    else if ((P) == 1) *reinterpret_cast<uint4*>(o_) = make_uint4(sm_[(JC) & 1][0], sm_[(JC) & 1][1], sm_[(JC) & 1][2], sm_[(JC) & 1][3]); \
+    else *reinterpret_cast<uint4*>(o_) = make_uint4(sl_[(JC) & 1][0], sl_[(JC) & 1][1], sl_[(JC) & 1][2], sl_[(JC) & 1][3]); }
+  // HALF: 24 MFMAs on the fragment set (GV, XV); reads the other set (GVN, XVN) for step KSN of stage STN; splits columns JC0, JC0 + 1 of RV
+  // into stage NSTG; requests rows I0 .. I0 + 3 of slab SL into RVL
+#define WPIPE_HALF(GV, XV, GVN, XVN, STN, KSN, RV, JC0, NSTG, RVL, I0, SL)                                    \
+  _Pragma("unroll") for (int n_ = 0; n_ < 24; ++n_) {                                                         \
+    if (WPIPE_KNOCK != 3) { WPIPE_MFMA(GV, XV, n_ >> 2, n_ & 3); }                                            \
+    const int jc_ = (JC0) + n_ / 12, q_ = (n_ % 12) / 3, sl3_ = n_ % 3;                                       \
+    if (n_ < 12) { WPIPE_FRD1(STN, KSN, n_, GVN, XVN); }                                                      \
+    else if (n_ % 3 == 1) { WPIPE_GLD1(RVL, (I0) + (n_ - 13) / 3, SL); }                                      \
+    if (WPIPE_KNOCK != 1 && WPIPE_KNOCK != 2) {                                                               \
+      if (sl3_ == 0) { WPIPE_SLICE_A(RV, jc_, q_); }                                                          \
+      else if (sl3_ == 1) { WPIPE_SLICE_B(); }                                                                \
+      else { WPIPE_SLICE_C(jc_ & 1, q_); }                                                                    \
+    }                                                                                                         \
+    if (WPIPE_KNOCK != 2) {                                                                                   \
+      if ((JC0) == 2 && (n_ == 1 || n_ == 3 || n_ == 5)) { WPIPE_WRITE1(NSTG, 1, (n_ - 1) / 2); }             \
+      if (n_ == 13 || n_ == 15 || n_ == 17) { WPIPE_WRITE1(NSTG, JC0, (n_ - 13) / 2); }                       \
+      if ((JC0) == 2 && n_ == 23) { WPIPE_WRITE1(NSTG, 3, 0); WPIPE_WRITE1(NSTG, 3, 1); WPIPE_WRITE1(NSTG, 3, 2); } \
+    }                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                        \
+  }
+#define WPIPE_BODY(S, RB)                                                                                     \
+  {                                                                                                           \
+    const unsigned char* st_ = wp_smem + ((S) & 1) * STAGE;                                                   \
+    const int nstg_ = ((S) + 1) & 1;                                                                          \
+    WPIPE_HALF(gv1, xv1, gv0, xv0, st_, 0, raw[RB], 0, nstg_, raw[((RB) + WPIPE_PF - 1) % WPIPE_PF], 0, (S) + WPIPE_PF) \
+    WPIPE_HALF(gv0, xv0, gv1, xv1, st_, 1, raw[RB], 2, nstg_, raw[((RB) + WPIPE_PF - 1) % WPIPE_PF], 4, (S) + WPIPE_PF) \
+    __builtin_amdgcn_s_waitcnt(0xc07f);      /* lgkmcnt(0), as a builtin: the compiler's own wait counting sees it */ \
+    __builtin_amdgcn_s_barrier();                                                                             \
+    asm volatile("" ::: "memory");                                                                            \
+  }
+  WPIPE_STAMP(1);
+  for (int s = 0; s < ns; s += WPIPE_PF) {        // unrolled by the number of raw sets: their indices are compile-time constants
+    WPIPE_BODY(s, 1)
+    if (s + 1 < ns) WPIPE_BODY(s + 1, 2 % WPIPE_PF)
+    if (WPIPE_PF >= 3 && s + 2 < ns) WPIPE_BODY(s + 2, 3 % WPIPE_PF)
+    if (WPIPE_PF >= 4 && s + 3 < ns) WPIPE_BODY(s + 3, 0)
+  }
+  WPIPE_STAMP(2);
+  // the last slab's second step
+#pragma unroll
+  for (int n_ = 0; n_ < 24; ++n_) { WPIPE_MFMA(gv1, xv1, n_ >> 2, n_ & 3); }
+#undef WPIPE_BODY
+#undef WPIPE_HALF
+#undef WPIPE_FRD1
+#undef WPIPE_GLD1
+#undef WPIPE_WRITE1
+#undef WPIPE_WRITE
+#undef WPIPE_SLICE_A
+#undef WPIPE_SLICE_B
+#undef WPIPE_SLICE_C
+#undef WPIPE_X
+
+  // acc[e][f][4 g + r] = dW[co0 + 64 wco + 32 e + 8 g + 4 hf + r][ci0 + 64 wci + 32 f + l31]
+  float* out = a.part + (a.accumulate ? 0 : (long)group * a.Co * a.Ci);
+#pragma unroll
+  for (int e = 0; e < 2; ++e)
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      const int ci = ci0 + 64 * wci + 32 * f + l31;
+      if (ci >= a.Ci) continue;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int co = co0 + 64 * wco + 32 * e + 8 * (r >> 2) + 4 * hf + (r & 3);
+        if (co >= a.Co) continue;
+        float* o = out + (long)co * a.Ci + ci;
+        *o = a.accumulate ? *o + acc[e][f][r] : acc[e][f][r];
+      }
+    }
+  WPIPE_STAMP(3);
+}
+#undef WPIPE_MFMA
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same product with the two kinds of work on DIFFERENT waves (round 5).  Stamps of the single-stream kernel above say what the
+// matrix pipe tolerates beside it in ONE wave (cycles per 32-row slab and workgroup, floor 48 MFMAs x 32 = 1536): MFMAs + fragment
+// reads + row requests 1585; + the plane stores 1824; + the 176 vector instructions of the split 2298 with the stores left out, 2538
+// with them - in one wave's stream a vector instruction adds its 4 issue cycles to the MFMA's 32 instead of hiding under them.
+// A second wave on the SIMD does hide (MI355X_MICROARCH.md 'Two waves per SIMD'): so 512 threads - waves 0-3 only read fragments and
+// issue MFMAs (2 x 2 wave tiles of 64 x 64 as before), waves 4-7 only request rows, split and store planes; one of each per SIMD, one
+// barrier per slab for all eight, two LDS stages, same image, same MFMA order: bit-identical results again.
+#ifdef WPIPE_STAMPS
+#define WWS_STAMP(slot) do { if (wpipe_stamps && threadIdx.x == 0) { wpipe_stamps[blockIdx.x * 8l + (slot)] = __builtin_amdgcn_s_memtime(); \
+    if ((slot) == 0 || (slot) == 3) wpipe_stamps[blockIdx.x * 8l + 4 + ((slot) == 3)] = __builtin_amdgcn_s_memrealtime(); } } while (0)
+#else
+#define WWS_STAMP(slot) do { } while (0)
+#endif
+#ifndef WWS_PF
+#define WWS_PF 3           // raw row sets of a loader wave (slabs requested ahead)
+#endif
+#ifndef WWS_PRIO
+#define WWS_PRIO 1         // s_setprio of the MFMA waves
+#endif
+__global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
+  constexpr int PLANE = 4 * 144 * 16, STAGE = 6 * PLANE;    // the image of wgrad_split_pipe_kernel
+  extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];      // 2 * STAGE
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = a.tiles_co * a.tiles_ci;
+  // Persistent: one workgroup per CU walks work items (group, tile), tile fastest.  Items are dealt in chunks of 32 consecutive ones
+  // (gridDim / 8; mostly one group's tiles: they read the same rows) to the XCDs in turn; blocks b and b + 8 share an XCD (round-robin dispatch -
+  // a placement for speed only), so block b takes item (b >> 3) of the chunks (b & 7), (b & 7) + 8, ...  The loader waves start an
+  // item's first slabs while the MFMA waves still store the previous item's tile.
+  const int items = tiles * a.groups;
+  const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7, chunk = gridDim.x >> 3;      // (the grid is a multiple of 8: 256, or fewer for a short list)
+  WWS_STAMP(0);
+
+  if (wave >= 4) {
+    // ---- loader waves: thread = (4-column chunk c of 32, row group rg of 4) of G (waves 4-5) or X (waves 6-7): rows 8 rg .. 8 rg + 7 of the slab
+    const bool isx = wave >= 6;
+    const int lt = tid & 127, c = lt & 31, rg = lt >> 5;
+    const int ld = __builtin_amdgcn_readfirstlane(isx ? a.ldx : a.ldg);
+    const unsigned slab_bytes = (unsigned)(32 * ld * 4), row_bytes = (unsigned)(ld * 4);
+    typedef float wf4 __attribute__((ext_vector_type(4)));
+    wf4 raw[WWS_PF][8];
+    unsigned char* const wb = ws_smem + (isx ? 3 * PLANE : 0) + (rg * 144 + c) * 16;
+#define WWS_GLOAD(RV, S)                                                                                                            \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                                \
+      RV[i_] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + (unsigned)i_ * row_bytes, (unsigned)(S) * slab_bytes, 0));
+#define WWS_SPLIT(RV, STG)                                                                                                          \
+    _Pragma("unroll") for (int jc_ = 0; jc_ < 4; ++jc_) {                                                                           \
+      unsigned h_[4], m_[4], l_[4];                                                                                                 \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) wsplit3_pair(RV[2 * q_][jc_], RV[2 * q_ + 1][jc_], h_[q_], m_[q_], l_[q_]);  \
+      unsigned char* o_ = wb + (STG) * STAGE + jc_ * 576;                                                                           \
+      *reinterpret_cast<uint4*>(o_) = make_uint4(h_[0], h_[1], h_[2], h_[3]);                                                       \
+      *reinterpret_cast<uint4*>(o_ + PLANE) = make_uint4(m_[0], m_[1], m_[2], m_[3]);                                               \
+      *reinterpret_cast<uint4*>(o_ + 2 * PLANE) = make_uint4(l_[0], l_[1], l_[2], l_[3]);                                           \
+    }
+#define WWS_LBODY(S, RB)                                                                                                            \
+    {                                                                                                                               \
+      WWS_GLOAD(raw[((RB) + WWS_PF - 1) % WWS_PF], (S) + WWS_PF)                                                                    \
+      WWS_SPLIT(raw[RB], ((S) + 1) & 1)                                                                                             \
+      __builtin_amdgcn_s_waitcnt(0xc07f);                                                                                           \
+      __builtin_amdgcn_s_barrier();                                                                                                 \
+      asm volatile("" ::: "memory");                                                                                                \
+    }
+    for (int it = 0;; ++it) {
+      const int item = (xcd + 8 * it) * chunk + slot;
+      if (item >= items) break;
+      const int group = item / tiles, tile = item - group * tiles;
+      const int c0 = isx ? (tile % a.tiles_ci) * 128 : (tile / a.tiles_ci) * 128;
+      const long r_beg = (long)group * a.rows_per_group;
+      const int rows = (int)(min((long)a.R, r_beg + a.rows_per_group) - r_beg);
+      const int ns = (rows + 31) / 32;
+      const int col0 = c0 + 4 * c;
+      const bool colok = col0 < (isx ? a.Ci : a.Co);
+      // the descriptor covers exactly the group's rows: rows past its end and columns past the matrix read as zeros by the range check
+      const __amdgpu_buffer_rsrc_t rs = wbuf_rsrc((isx ? a.X.p : a.G) + r_beg * ld, (long)rows * ld * 4);
+      const unsigned vbase = colok ? (unsigned)((8 * rg * ld + col0) * 4) : 0x7f000000u;
+      WWS_GLOAD(raw[0], 0)
+      WWS_GLOAD(raw[1], 1)
+      if (WWS_PF >= 3) { WWS_GLOAD(raw[WWS_PF >= 3 ? 2 : 0], 2) }
+      if (WWS_PF >= 4) { WWS_GLOAD(raw[WWS_PF >= 4 ? 3 : 0], 3) }
+      WWS_SPLIT(raw[0], 0)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for (int s = 0; s < ns; s += WWS_PF) {
+        WWS_LBODY(s, 1)
+        if (s + 1 < ns) WWS_LBODY(s + 1, 2 % WWS_PF)
+        if (WWS_PF >= 3 && s + 2 < ns) WWS_LBODY(s + 2, 3 % WWS_PF)
+        if (WWS_PF >= 4 && s + 3 < ns) WWS_LBODY(s + 3, 0)
+      }
+    }
+#undef WWS_LBODY
+#undef WWS_SPLIT
+#undef WWS_GLOAD
+    return;
+  }
+
+  // ---- MFMA waves
+  if (WWS_PRIO) __builtin_amdgcn_s_setprio(WWS_PRIO);
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int wco = wave >> 1, wci = wave & 1;
+  const int fro = (hf * 144 + (l31 & 3) * 36 + (l31 >> 2)) * 16;
+  const int cgo = fro + wco * 256, cxo = fro + 3 * PLANE + wci * 256;
+  constexpr int PG[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
+#define WWS_MFMA(GV, XV, T, EF)                                                                                                \
+  acc[(EF) >> 1][(EF) & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(GV[(EF) >> 1][PG[T]], XV[(EF) & 1][PX[T]], acc[(EF) >> 1][(EF) & 1], 0, 0, 0)
+#define WWS_FRD1(ST, KS, R, GVT, XVT)                                                                          \
+  { const int g_ = (R) >> 2, e_ = (R) & 1;                                                                     \
+    if ((((R) >> 1) & 1) == 0) GVT[e_][g_ == 0 ? 0 : g_ == 1 ? 2 : 1] = *reinterpret_cast<const wbf16x8*>((ST) + cgo + (g_ == 0 ? 0 : g_ == 1 ? 2 : 1) * PLANE + e_ * 128 + (KS) * 4608); \
+    else XVT[e_][g_ == 0 ? 2 : g_ == 1 ? 0 : 1] = *reinterpret_cast<const wbf16x8*>((ST) + cxo + (g_ == 0 ? 2 : g_ == 1 ? 0 : 1) * PLANE + e_ * 128 + (KS) * 4608); }
+  // 24 MFMAs on (GV, XV); the 12 fragments of the next 16-row step go into the other set, one read per MFMA gap, in the order the MFMAs want them
+#define WWS_HALF(GV, XV, GVN, XVN, STN, KSN)                                                                   \
+  _Pragma("unroll") for (int n_ = 0; n_ < 24; ++n_) {                                                          \
+    WWS_MFMA(GV, XV, n_ >> 2, n_ & 3);                                                                         \
+    if (n_ < 12) { WWS_FRD1(STN, KSN, n_, GVN, XVN); }                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                         \
+  }
+  for (int it = 0;; ++it) {
+    const int item = (xcd + 8 * it) * chunk + slot;
+    if (item >= items) break;
+    const int group = item / tiles, tile = item - group * tiles;
+    const int co0 = (tile / a.tiles_ci) * 128, ci0 = (tile % a.tiles_ci) * 128;
+    const long r_beg = (long)group * a.rows_per_group;
+    const int rows = (int)(min((long)a.R, r_beg + a.rows_per_group) - r_beg);
+    const int ns = (rows + 31) / 32;
+    wf32x16 acc[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+    wbf16x8 gv0[2][3], xv0[2][3], gv1[2][3], xv1[2][3];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { gv1[e][p][i] = (__bf16)0.f; xv1[e][p][i] = (__bf16)0.f; }      // the first half step multiplies zeros
+    __builtin_amdgcn_s_barrier();                // slab 0 of this item is in stage 0
+    asm volatile("" ::: "memory");
+    if (it == 0) WWS_STAMP(1);
+    for (int s = 0; s < ns; ++s) {
+      const unsigned char* st_ = ws_smem + (s & 1) * STAGE;
+      WWS_HALF(gv1, xv1, gv0, xv0, st_, 0)
+      WWS_HALF(gv0, xv0, gv1, xv1, st_, 1)
+      __builtin_amdgcn_s_waitcnt(0xc07f);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (it == 0) WWS_STAMP(2);
+#pragma unroll
+    for (int n_ = 0; n_ < 24; ++n_) { WWS_MFMA(gv1, xv1, n_ >> 2, n_ & 3); }
+    // acc[e][f][4 g + r] = dW[co0 + 64 wco + 32 e + 8 g + 4 hf + r][ci0 + 64 wci + 32 f + l31]
+    if (!a.accumulate) {
+      // partial tile of this group: 64 one-dword buffer stores per lane, the row / block part of the address in the scalar offset, rows past
+      // Co clipped by the descriptor's range check and columns past Ci parked behind it - no compares, no branches, no 64-bit address math
+      const __amdgpu_buffer_rsrc_t ro = wbuf_rsrc(a.part + (long)group * a.Co * a.Ci, (long)a.Co * a.Ci * 4);
+      const int cib = ci0 + 64 * wci + l31;
+      const unsigned rowo = (unsigned)(((co0 + 64 * wco + 4 * hf) * a.Ci) * 4);
+      const unsigned vo[2] = {cib < a.Ci ? rowo + (unsigned)cib * 4u : 0x7f000000u, cib + 32 < a.Ci ? rowo + (unsigned)(cib + 32) * 4u : 0x7f000000u};
+      const unsigned rstep = (unsigned)(a.Ci * 4);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[e][f][r]), ro, vo[f], (unsigned)(32 * e + 8 * (r >> 2) + (r & 3)) * rstep, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int ci = ci0 + 64 * wci + 32 * f + l31;
+          if (ci >= a.Ci) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 64 * wco + 32 * e + 8 * (r >> 2) + 4 * hf + (r & 3);
+            if (co >= a.Co) continue;
+            float* o = a.part + (long)co * a.Ci + ci;
+            *o = *o + acc[e][f][r];
+          }
+        }
+    }
+    if (it == 0) WWS_STAMP(3);
+  }
+#undef WWS_HALF
+#undef WWS_FRD1
+#undef WWS_MFMA
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 struct WtPlan { int te, tf, tiles_co, tiles_ci, groups, rows_per_group; };
+int mx_wgrad_pipe_override = -1;      // lab hook (tools/hip/gemm_lab.hip): 0 / 1 selects the first / pipelined split kernel per call
 
 static int wt_order() {
   static const int order = getenv("MX_WGRAD_TILE_ORDER") ? atoi(getenv("MX_WGRAD_TILE_ORDER")) : 0;
@@ -606,6 +1036,12 @@ static bool wt_use_split(int Co, int Ci) {
   // step 96.9 -> 95.15 ms on one box (profiles/r04_knob_sweep.txt)
   static const double min_eff = getenv("MX_WGRAD_SPLIT_EFF") ? atof(getenv("MX_WGRAD_SPLIT_EFF")) : 0.55;
   return mx_get_gemm_mode() == 2 || eff >= min_eff;
+}
+
+// which split weight-gradient kernel takes the plain-operand launches: 0 wgrad_split_kernel, 1 wgrad_split_pipe_kernel, 2 wgrad_split_ws_kernel
+static int wt_pipe_mode() {
+  static const int pipe_env = getenv("MX_WGRAD_PIPE") ? atoi(getenv("MX_WGRAD_PIPE")) : 2;
+  return mx_wgrad_pipe_override >= 0 ? mx_wgrad_pipe_override : pipe_env;
 }
 
 static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
@@ -625,6 +1061,28 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     // The bound is on the CHAIN, not on the count: at most 1568 rows per group, so R = 50 176 (B7 at batch 64, or batch 32 at larger
     // images) takes 32 groups instead of running 3136-row chains at 16 (tests/test_gpu_split.py has R = 50 176 and 62 720 cases).
     const int maxg = R / 256 > 0 ? R / 256 : 1;
+    if (x_mode == MX_PLAIN && wt_pipe_mode() >= 2) {
+      // wgrad_split_ws_kernel: ONE persistent workgroup per CU deals the (group, tile) items out evenly, so the count that matters is
+      // items / 256 rounded up.  Cost model from the kernel's own stamps at the clock it holds (~1.75 GHz): 1.09 us per 32-row slab,
+      // 3.4 us per item (first slabs + storing the partial tile), and the partial matrices once more through the reduce kernel.
+      // The chain bound (<= 1568 rows per group) is the floor; 54 tiles take 18 groups (3.8 rounds) instead of 16 (3.4 -> 4 rounds).
+      const int tiles = p->tiles_co * p->tiles_ci;
+      int gmin = cdiv(R, 1568);
+      if (gmin > maxg) gmin = maxg;
+      int best_g = gmin;
+      double best_t = 1e30;
+      for (int g = gmin; g <= maxg && g <= 3 * gmin + 8; ++g) {
+        const int rpg = cdiv(cdiv(R, g), 32) * 32, ga = cdiv(R, rpg);
+        if (ga != g) continue;                                 // (the rounding of the rows makes some counts unreachable)
+        const double t = cdiv(tiles * g, 256) * (rpg / 32 * 1.09 + 3.4) + g * ((double)Co * Ci * 4.0 / 4e6);
+        if (t < best_t - 1e-9) { best_t = t; best_g = g; }
+      }
+      static const int forced_ws = getenv("MX_WGRAD_WS_GROUPS") ? atoi(getenv("MX_WGRAD_WS_GROUPS")) : 0;
+      if (forced_ws > 0) best_g = forced_ws < maxg ? forced_ws : maxg;
+      p->rows_per_group = cdiv(cdiv(R, best_g), 32) * 32;
+      p->groups = cdiv(R, p->rows_per_group);
+      return true;
+    }
     int groups = (cdiv(R, 1568) + 7) / 8 * 8;
     if (groups < 16) groups = 16;
     // few output tiles (960 x 160: 16, 480 x 80: 4 - taken by this kernel when MX_WGRAD_SPLIT_EFF admits their padding): their partial
@@ -830,7 +1288,19 @@ static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, 
     // experiment knob: unused dynamic LDS caps the kernel's workgroups per CU (32 KB -> 2 per CU, 64 KB -> 1), leaving wave slots
     // and registers to the main stream's kernels it runs beside
     static const int pad = getenv("MX_WGRAD_SPLIT_LDS_PAD") ? atoi(getenv("MX_WGRAD_SPLIT_LDS_PAD")) : 0;
-    if (a.G2) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, true>), grid, dim3(256), 0, st, a);
+    // the pipelined kernel addresses a group through 32-bit buffer offsets: (rows + 64) * ld * 4 bytes must stay far below 2^31
+    const int pipe = wt_pipe_mode();
+    const bool pipe_ok = pipe && !a.G2 && a.X.mode == MX_PLAIN && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30);
+    if (pipe_ok && pipe >= 2) {
+      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4 * 144 * 16), 0);
+      (void)once;
+      const int items = a.groups * a.tiles_co * a.tiles_ci;
+      hipLaunchKernelGGL(wgrad_split_ws_kernel, dim3(items < 256 ? 8 * cdiv(items, 8) : 256), dim3(512), 12 * 4 * 144 * 16, st, a);
+    } else if (pipe_ok) {
+      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4 * 144 * 16), 0);
+      (void)once;
+      hipLaunchKernelGGL(wgrad_split_pipe_kernel, grid, dim3(256), 12 * 4 * 144 * 16, st, a);
+    } else if (a.G2) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, true>), grid, dim3(256), 0, st, a);
     else if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, false>), grid, dim3(256), pad, st, a);
     else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_split_kernel<MX_BNACT, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_split_kernel<MX_AFFINE, false>), grid, dim3(256), 0, st, a);

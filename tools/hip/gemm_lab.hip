@@ -340,7 +340,82 @@ static void run_widths(int M, int K, int N) {
   CK(hipFree(planes)); CK(hipFree(table));
 }
 
+static int wlab_mode() { return getenv("WLAB_MODE") ? atoi(getenv("WLAB_MODE")) : 2; }
+// wgrad [R Co Ci]: the first split weight-gradient kernel against the round-5 ones (WLAB_MODE = 1 single-stream pipeline, 2 wave-specialised), same process: time, bits
+static int run_wgrad(int R, int Co, int Ci) {
+  if (!ws) CK(hipMalloc(&ws, ws_bytes));
+  float* G = dalloc((long)R * Co, 11, 1.f); float* X = dalloc((long)R * Ci, 12, 1.f);
+  float* d0 = dalloc((long)Co * Ci, 13, 0.f); float* d1 = dalloc((long)Co * Ci, 13, 0.f);
+  if (mx_pw_wgrad_tile_ws(R, Co, Ci, 0) <= 0) { printf("  R=%d Co=%d Ci=%d: not a tiled shape\n", R, Co, Ci); return 0; }
+  const double fl = 2.0 * R * Co * Ci;
+  float t[2];
+  for (int v = 0; v < 2; ++v) {
+    mx_wgrad_pipe_override = v ? wlab_mode() : 0;
+    float* d = v ? d1 : d0;
+    CK(hipMemset(d, 0, (long)Co * Ci * 4));
+    if (mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, d, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr)) { printf("error: %s\n", mx_last_error()); return 1; }
+    CK(hipDeviceSynchronize());
+    float best = 1e30f;
+    for (int rep = 0; rep < 3; ++rep)
+      best = std::min(best, time_us([&] { mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, d, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr); }, 5));
+    t[v] = best;
+  }
+  mx_wgrad_pipe_override = -1;
+  // bits: one fresh call each into zeroed outputs
+  std::vector<float> h0((long)Co * Ci), h1((long)Co * Ci);
+  for (int v = 0; v < 2; ++v) {
+    mx_wgrad_pipe_override = v ? wlab_mode() : 0;
+    float* d = v ? d1 : d0;
+    CK(hipMemset(d, 0, (long)Co * Ci * 4));
+    mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, d, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr);
+    CK(hipMemcpy((v ? h1 : h0).data(), d, (long)Co * Ci * 4, hipMemcpyDeviceToHost));
+  }
+  mx_wgrad_pipe_override = -1;
+#ifdef WPIPE_STAMPS
+  {
+    const long nwg = 1 << 16;
+    unsigned long long* st; CK(hipMalloc(&st, nwg * 8 * sizeof(unsigned long long))); CK(hipMemset(st, 0, nwg * 8 * sizeof(unsigned long long)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(wpipe_stamps), &st, sizeof(st)));
+    mx_wgrad_pipe_override = wlab_mode();
+    for (int i = 0; i < 200; ++i) mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, d1, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr);     // the clock the chip HOLDS
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(nwg * 8);
+    CK(hipMemcpy(h.data(), st, nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> loop, tot, ghz, pro;
+    for (long w = 0; w < nwg; ++w) {
+      if (!h[w * 8 + 3]) continue;
+      loop.push_back((double)(h[w * 8 + 2] - h[w * 8 + 1])); tot.push_back((double)(h[w * 8 + 3] - h[w * 8 + 0])); pro.push_back((double)(h[w * 8 + 1] - h[w * 8 + 0]));
+      ghz.push_back((double)(h[w * 8 + 3] - h[w * 8 + 0]) / ((double)(h[w * 8 + 5] - h[w * 8 + 4]) * 10.0));
+    }
+    auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+    WtPlan pl; wt_plan(R, Co, Ci, 0, &pl);
+    const int ns = (pl.rows_per_group + 31) / 32;
+    printf("    stamps: %zu workgroups, %d slabs each: loop %.0f cycles = %.1f per slab (%.1f per MFMA), prologue %.0f, whole %.0f, clock %.2f GHz\n", loop.size(), ns,
+           med(loop), med(loop) / ns, med(loop) / ns / 48, med(pro), med(tot), med(ghz));
+    unsigned long long* z = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(wpipe_stamps), &z, sizeof(z)));
+    mx_wgrad_pipe_override = -1;
+    CK(hipFree(st));
+  }
+#endif
+  double md = 0, mx = 0;
+  for (long i = 0; i < (long)Co * Ci; ++i) { md = std::max(md, (double)fabsf(h0[i] - h1[i])); mx = std::max(mx, (double)fabsf(h0[i])); }
+  printf("  R=%d Co=%d Ci=%d: v1 %7.1f us %6.1f TF | pipe %7.1f us %6.1f TF | max|d| = %g (max|v1| = %g)\n", R, Co, Ci, t[0], fl / t[0] / 1e6, t[1],
+         fl / t[1] / 1e6, md, mx);
+  fflush(stdout);
+  for (float* p : {G, X, d0, d1}) CK(hipFree(p));
+  return md == 0 ? 0 : 2;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "wgrad")) {
+    if (argc >= 5) return run_wgrad(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
+    static const Shape sh[] = {{25088, 2304, 384}, {25088, 384, 2304}, {25088, 3840, 640}, {25088, 640, 3840}, {25088, 1344, 224}, {25088, 224, 1344},
+                               {25088, 960, 160}, {25088, 160, 960}, {6272, 2304, 384}, {12544, 1152, 192}, {25088 + 19, 640, 2304}, {100352, 480, 80}};
+    int rc = 0;
+    for (const Shape& s : sh) rc |= run_wgrad(s.M, s.K, s.N);
+    return rc;
+  }
+
   if (argc >= 2 && !strcmp(argv[1], "widths")) {
     if (argc >= 5) { run_widths(atoi(argv[2]), atoi(argv[3]), atoi(argv[4])); return 0; }
     static const Shape sh[] = {{25088, 160, 960}, {25088, 960, 160}, {25088, 224, 1344}, {25088, 1344, 224}, {25088, 384, 2304}, {25088, 2304, 384},

@@ -58,6 +58,13 @@ int mx_pw_fwd(const float* A, int a_mode, const float* a_scale, const float* a_s
  * 2: split arithmetic for every NT GEMM (tests). */
 int mx_set_gemm_mode(int mode);
 int mx_get_gemm_mode(void);
+/* Which kernel takes the split-arithmetic weight gradients with plain operands (backward of model.py:77,86), and an optional fixed
+ * number of row groups for them (process-wide; for tests and measurement).  kernel: 0 = wgrad_split_kernel (rounds 3-4), 1 = the
+ * single-stream pipelined kernel, 2 = (default; initial value from MX_WGRAD_PIPE) the wave-specialised persistent kernel of round 5,
+ * -1 = leave as is.  groups: > 0 fixes the row groups of every such launch (same groups => the three kernels give the same bits:
+ * same tiles, same MFMA order per group, same fixed-order sum of the groups), 0 = back to the planner's choice, -1 = leave as is. */
+int mx_set_wgrad_kernel(int kernel, int groups);
+int mx_get_wgrad_kernel(void);
 /* 1 if, in the current mode, this GEMM runs in split arithmetic on the bf16 pipe (kind 0: mx_pw_fwd / data gradient
  * C[M,N] = A[M,K] W[N,K]^T; kind 1: weight gradient dW[M=Co,N=Ci] over K=R rows), else 0 - for measurement code. */
 int mx_gemm_uses_split(int kind, int M, int N, int K);

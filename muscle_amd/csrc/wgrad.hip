@@ -1043,6 +1043,7 @@ static int wt_pipe_mode() {
   static const int pipe_env = getenv("MX_WGRAD_PIPE") ? atoi(getenv("MX_WGRAD_PIPE")) : 2;
   return mx_wgrad_pipe_override >= 0 ? mx_wgrad_pipe_override : pipe_env;
 }
+static int g_wgrad_groups = 0;         // mx_set_wgrad_kernel: > 0 fixes the row groups of the plain split launches
 
 static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
   if (Co % 4 || Ci % 4 || R < 1024 || (long)Co * Ci < 16384) return false;
@@ -1077,7 +1078,8 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
         const double t = cdiv(tiles * g, 256) * (rpg / 32 * 1.09 + 3.4) + g * ((double)Co * Ci * 4.0 / 4e6);
         if (t < best_t - 1e-9) { best_t = t; best_g = g; }
       }
-      static const int forced_ws = getenv("MX_WGRAD_WS_GROUPS") ? atoi(getenv("MX_WGRAD_WS_GROUPS")) : 0;
+      static const int forced_env = getenv("MX_WGRAD_WS_GROUPS") ? atoi(getenv("MX_WGRAD_WS_GROUPS")) : 0;
+      const int forced_ws = g_wgrad_groups > 0 ? g_wgrad_groups : forced_env;
       if (forced_ws > 0) best_g = forced_ws < maxg ? forced_ws : maxg;
       p->rows_per_group = cdiv(cdiv(R, best_g), 32) * 32;
       p->groups = cdiv(R, p->rows_per_group);
@@ -1099,6 +1101,7 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     if (groups > maxg) groups = maxg >= 8 ? maxg / 8 * 8 : maxg;
     static const int forced_split = getenv("MX_WGRAD_SPLIT_GROUPS") ? atoi(getenv("MX_WGRAD_SPLIT_GROUPS")) : 0;
     if (forced_split > 0) groups = forced_split < maxg ? forced_split : maxg;
+    if (g_wgrad_groups > 0 && x_mode == MX_PLAIN) groups = g_wgrad_groups < maxg ? g_wgrad_groups : maxg;
     p->rows_per_group = cdiv(cdiv(R, groups), 32) * 32;
     p->groups = cdiv(R, p->rows_per_group);
     return true;
@@ -1154,6 +1157,15 @@ static void wt_launch(const WtArgs& a, hipStream_t st) {
 }
 
 extern "C" {
+
+int mx_set_wgrad_kernel(int kernel, int groups) {
+  MX_CHECK_ARG(kernel >= -1 && kernel <= 2, "set_wgrad_kernel: kernel %d (0 first split kernel, 1 pipelined, 2 wave-specialised, -1 keep)", kernel);
+  MX_CHECK_ARG(groups >= -1, "set_wgrad_kernel: groups %d (> 0 fixed, 0 planner, -1 keep)", groups);
+  if (kernel >= 0) mx_wgrad_pipe_override = kernel;
+  if (groups >= 0) g_wgrad_groups = groups;
+  return MX_OK;
+}
+int mx_get_wgrad_kernel(void) { return wt_pipe_mode(); }
 
 // bytes of scratch mx_pw_wgrad_small needs for (R, Co, Ci, x_mode), or 0 when the shape is not one it takes
 long mx_pw_wgrad_small_ws(int R, int Co, int Ci, int x_mode) {

@@ -119,6 +119,17 @@ def get_gemm_mode() -> int:
     return int(lib().mx_get_gemm_mode())
 
 
+def set_wgrad_kernel(kernel: int = -1, groups: int = -1):
+    """Which kernel takes the plain-operand split weight gradients (include/muscle_hip.h, mx_set_wgrad_kernel): 0 = the first split
+    kernel, 1 = the single-stream pipeline, 2 = the wave-specialised persistent kernel (default); `groups` > 0 fixes their row groups
+    (0 = planner).  -1 leaves a setting as it is.  Tests and measurement only."""
+    call("mx_set_wgrad_kernel", int(kernel), int(groups))
+
+
+def get_wgrad_kernel() -> int:
+    return int(lib().mx_get_wgrad_kernel())
+
+
 class TransposePlan:
     """Persistent W^T buffers of a fixed set of 2-D weights and the device table that transposes them all in one launch."""
 

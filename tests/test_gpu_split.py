@@ -295,3 +295,33 @@ def test_split_wgrad_matches_fp64_as_well_as_fp32_mfma(R, Co, Ci, mode):
     scale = ref.abs().max().item()
     assert errs[0] <= 2e-5 * scale, (errs, scale)
     assert errs[1] <= 1.5 * errs[0] + 2e-7 * scale, (errs, scale)
+
+
+@pytest.mark.parametrize("R,Co,Ci,groups", [(25088, 384, 2304, 16), (12544 + 7, 1344, 224, 9), (5003, 640, 384, 4), (3136, 256, 132, 2),
+                                              (6272, 2304, 384, 5)])
+def test_wgrad_kernels_of_round_5_equal_the_first_split_kernel_bit_for_bit(R, Co, Ci, groups):
+    """wgrad_split_pipe_kernel (one software-pipelined stream) and wgrad_split_ws_kernel (4 MFMA waves + 4 loader waves, persistent)
+    keep the first split kernel's tiles, MFMA order and fixed-order sum of the row groups: with the group count held equal the three
+    give the same bits - on ragged row counts (the last slab and the last group are short) and on outputs that pad their tiles.  The
+    fp64 bound of the planner's own group count is test_split_wgrad_matches_fp64_as_well_as_fp32_mfma's."""
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(R + Ci)
+    G = torch.randn(R, Co, device=DEV, generator=g)
+    X = torch.randn(R, Ci, device=DEV, generator=g)
+    base = torch.randn(Co, Ci, device=DEV, generator=g)
+    muscle_amd.set_gemm_mode(2)
+    was = ops.get_wgrad_kernel()
+    outs = []
+    try:
+        for kern in (0, 1, 2):
+            ops.set_wgrad_kernel(kern, groups)
+            dW = base.clone()
+            ops.pw_wgrad(G, X, dW)
+            outs.append(dW)
+    finally:
+        ops.set_wgrad_kernel(was, 0)
+        muscle_amd.set_gemm_mode(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ref = base.double() + G.double().t() @ X.double()
+    assert (outs[2].double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()

@@ -504,7 +504,7 @@ def main():
                    "arithmetic": f"{a.arith}: {ARITH_TEXT[a.arith]}"},
         "losses": {k: (float(v.detach()) if torch.is_tensor(v) else v) for k, v in out.items()},
         "roofline": {"bound": "mfma",
-                     "kernel": "gemm_nt_kernel<*> / gemm_nt_split_kernel<*> / wgrad_tile_kernel<*> / wgrad_split_kernel<*> / wgrad_small_kernel<*> / "
+                     "kernel": "gemm_nt_split3_kernel<*> / gemm_nt_kernel<*> / wgrad_split_ws_kernel / wgrad_split_kernel<*> / wgrad_tile_kernel<*> / wgrad_small_kernel<*> / "
                                "gemm_kernel<*> (the pointwise-conv GEMMs: forward, data gradient, weight gradient; stem)",
                      "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": (achieved / peak) if achieved else None, "traffic": traffic,

@@ -871,10 +871,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
 #define WWS_GLOAD(RV, S)                                                                                                            \
     _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                                \
       RV[i_] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + (unsigned)i_ * row_bytes, (unsigned)(S) * slab_bytes, 0));
+// (lab, round 5: the two residual subtractions of adjacent columns as ONE v_pk_add_f32 - 144 instead of 176 vector instructions per
+// slab - took the MFMA waves from 39.8 to 62.6 cycles per MFMA: packed f32 arithmetic on the partner wave stalls the matrix pipe)
 #define WWS_SPLIT(RV, STG)                                                                                                          \
     _Pragma("unroll") for (int jc_ = 0; jc_ < 4; ++jc_) {                                                                           \
       unsigned h_[4], m_[4], l_[4];                                                                                                 \
-      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) wsplit3_pair(RV[2 * q_][jc_], RV[2 * q_ + 1][jc_], h_[q_], m_[q_], l_[q_]);  \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                                            \
+        if (WPIPE_KNOCK == 1) { h_[q_] = __float_as_uint(RV[2 * q_][jc_]); m_[q_] = __float_as_uint(RV[2 * q_ + 1][jc_]); l_[q_] = 0; }    \
+        else wsplit3_pair(RV[2 * q_][jc_], RV[2 * q_ + 1][jc_], h_[q_], m_[q_], l_[q_]); }                                          \
       unsigned char* o_ = wb + (STG) * STAGE + jc_ * 576;                                                                           \
       *reinterpret_cast<uint4*>(o_) = make_uint4(h_[0], h_[1], h_[2], h_[3]);                                                       \
       *reinterpret_cast<uint4*>(o_ + PLANE) = make_uint4(m_[0], m_[1], m_[2], m_[3]);                                               \

@@ -12,7 +12,13 @@ def load(d):
     out = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.Counter()
     seen = set()
-    for r in csv.DictReader(open(cc)):
+    rows = list(csv.DictReader(open(cc)))
+    # everything before the first step's first kernel (the stem's im2col) is set-up: ~1 700 `__amd_rocclr_copyBuffer` of the model's
+    # parameters going to the device and the generators' fills - round 4 counted them into `launches_per_step_all` (172 + 20 "per step")
+    first = min((int(r["Dispatch_Id"]) for r in rows if r["Kernel_Name"].startswith("stem_im2col")), default=0)
+    for r in rows:
+        if int(r["Dispatch_Id"]) < first:
+            continue
         fam = family(r["Kernel_Name"])
         out[fam][r["Counter_Name"]] += float(r["Counter_Value"])
         key = (r["Dispatch_Id"], r["Counter_Name"])
@@ -33,6 +39,8 @@ def family(n):
         return "gemm_nt_split3_kernel<NT fwd + dgrad, split arithmetic, weight planes>"
     if n.startswith("gemm_nt_split_kernel"):
         return "gemm_nt_split_kernel<NT fwd + dgrad, split arithmetic>"
+    if n.startswith(("wgrad_split_ws_kernel", "wgrad_split_pipe_kernel")):
+        return "wgrad_split_kernel"                      # round 5: the split weight gradient's kernels are one family
     if n.startswith("dw_bwd_fused_kernel"):
         return "dw_bwd_fused_kernel<%s>" % re.match(r"dw_bwd_fused_kernel<(\d)", n).group(1)
     return re.sub(r"<.*", "", n)

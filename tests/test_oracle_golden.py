@@ -377,8 +377,11 @@ def test_oracle_run_fixtures_are_current(case):
             assert np.array_equal(np.isnan(a), np.isnan(b))
             live = ~np.isnan(a[:, 0])
             sc = np.maximum(a[live, 0:1], 1e-30)
-            assert np.all(np.abs(a[live][:, [0, 2]] - b[live][:, [0, 2]]) <= 1e-5 * np.abs(b[live][:, [0, 2]]) + 1e-30)
-            assert np.all(np.abs(a[live][:, 3:] - b[live][:, 3:]) <= 1e-6 * b[live][:, 2:3] * 10 + 1e-30)
+            # tensors whose gradient is round-off only (parameters a train-mode BatchNorm cancels) differ from run to run even in
+            # fp64 (threaded sums): judged on the scale of the whole gradient
+            floor = 1e-9 * b[live, 0].max()
+            assert np.all(np.abs(a[live][:, [0, 2]] - b[live][:, [0, 2]]) <= 1e-5 * np.abs(b[live][:, [0, 2]]) + floor)
+            assert np.all(np.abs(a[live][:, 3:] - b[live][:, 3:]) <= 1e-5 * b[live][:, 2:3] + floor * np.sqrt(1e6))
             # column 1 = max|g32 - g64| is round-off itself: only its size is reproducible
             assert np.all(a[live, 1] <= 4 * b[live, 1] + 1e-6 * sc[:, 0]) and np.all(b[live, 1] <= 4 * a[live, 1] + 1e-6 * sc[:, 0])
         else:

@@ -26,9 +26,12 @@ class GradAverager:
     `attach(model)` additionally lets the model's backward report progress (arena[lo:] complete), which starts the
     chunks early; without it everything is launched from the hook (same result, no overlap)."""
 
-    def __init__(self, group=None, chunk_bytes: int = CHUNK_BYTES):
+    def __init__(self, group=None, chunk_bytes: int = CHUNK_BYTES, single_rank_collectives: bool = False):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # a one-rank group normally skips the exchange; `single_rank_collectives` issues it anyway (the average over one rank is the
+        # identity): the only way to run the RCCL calls and their stream ordering on a one-GPU box (tests/test_gpu_dist.py)
+        self.active = self.world > 1 or (single_rank_collectives and dist.is_initialized())
         self.bytes_reduced = 0
         self.chunk = max(1, chunk_bytes // 4)          # elements
         self._sink = None
@@ -67,7 +70,7 @@ class GradAverager:
 
     # ---- progress from the backward: arena[lo:] is complete on the current stream ---------------------------------
     def on_ready(self, sink, lo: int):
-        if self.world == 1:
+        if not self.active:
             return
         if sink is not self._sink:
             self._begin(sink)
@@ -78,7 +81,7 @@ class GradAverager:
 
     # ---- the hook: after backward, before optimizer.step() ----------------------------------------------------------
     def __call__(self, model, phase: int):
-        if self.world == 1:
+        if not self.active:
             return
         sink = model.last_grad_sink
         check = getattr(sink, "check_aliases", None)
@@ -95,9 +98,9 @@ class GradAverager:
         self._sink = None
 
 
-def broadcast_parameters(model, src: int = 0, group=None):
+def broadcast_parameters(model, src: int = 0, group=None, single_rank_collectives: bool = False):
     """Make every replica start from rank `src`'s parameters and buffers."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_initialized() or (dist.get_world_size(group) == 1 and not single_rank_collectives):
         return
     gloo = dist.get_backend(group) != "nccl"
     for t in list(model.parameters()) + list(model.buffers()):

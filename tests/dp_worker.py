@@ -12,7 +12,8 @@ sys.path.insert(0, ROOT)
 mode, out_path = sys.argv[2], sys.argv[3]
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 backend = os.environ.get("DP_BACKEND", "gloo")            # "nccl" (= RCCL): one GPU per rank, needs >= world GPUs
-if world > 1:
+force1 = os.environ.get("DP_SINGLE_RANK_RCCL") == "1"   # world 1 over "nccl" with the collectives forced on: the RCCL branch on a one-GPU box
+if world > 1 or force1:
     if backend == "nccl":
         torch.cuda.set_device(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
@@ -64,8 +65,11 @@ else:
     torch.manual_seed(3)
     du = {b.index: torch.rand(n).to(dev) for b in cfg.blocks if b.skip and b.drop_rate}
     hook = None
-    if world > 1:
-        hook = GradAverager(chunk_bytes=256 * 1024).attach(model)      # ~16 MB arena -> dozens of chunks
+    if world > 1 or force1:
+        from muscle_amd.dist import broadcast_parameters, sync_buffers_from_rank0
+        hook = GradAverager(chunk_bytes=256 * 1024, single_rank_collectives=force1).attach(model)      # ~16 MB arena -> dozens of chunks
+        if force1:
+            broadcast_parameters(model, single_rank_collectives=True)                                   # (RCCL broadcast of every tensor)
     out = muscle_amd.mcl_step(model, opt, batch, ep, drop_u=du, grad_hook=hook)
     torch.cuda.synchronize()
     res = {"arena": model.last_grad_sink.arena.cpu().numpy(),
@@ -73,6 +77,6 @@ else:
            "early": np.array(hook.launched_early if hook else 0),
            "params": torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu().numpy()}
     np.savez(out_path, **res)
-if world > 1:
+if world > 1 or force1:
     dist.destroy_process_group()
 print("ok", rank)

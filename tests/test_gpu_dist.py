@@ -14,8 +14,9 @@ pytestmark = pytest.mark.gpu
 WORKER = os.path.join(ROOT, "tests", "dp_worker.py")
 
 
-def _run(world, tmp_path, tag, backend="gloo"):
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), DP_BACKEND=backend)
+def _run(world, tmp_path, tag, backend="gloo", **extra):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), WORLD_SIZE=str(world), DP_BACKEND=backend,
+               HSA_ENABLE_IPC_MODE_LEGACY="0", **extra)
     outs = [str(tmp_path / f"{tag}_{r}.npz") for r in range(world)]
     procs = [subprocess.Popen([sys.executable, WORKER, ROOT, "step", outs[r]], env=dict(env, RANK=str(r)),
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
@@ -50,6 +51,20 @@ def test_two_ranks_same_batch_reproduce_single_process_update(tmp_path, backend)
     # parameters: Adam's first update is lr * sign(g): identical except where a round-off gradient changes sign
     d = np.abs(r0["params"].astype(np.float64) - single["params"].astype(np.float64))
     assert d.max() <= 2.05e-4 and (d > 1e-6).mean() < 0.02, (d.max(), (d > 1e-6).mean())
+
+
+def test_rccl_branch_runs_on_one_rank_and_is_the_identity(tmp_path):
+    """The RCCL branch of muscle_amd.dist (`all_reduce(AVG, async_op=True)` of arena chunks issued from the weight-gradient side
+    stream as backward fills the arena, `work.wait()` before the optimizer, `broadcast` of every parameter) on the hardware that is
+    there: a ONE-rank "nccl" group with the collectives forced on.  The average over one rank is the identity, so the step must equal
+    the plain single-process step bit for bit - which also holds the stream ordering: a collective that ran before its chunk was
+    complete, or an optimizer step that did not wait for it, would change the update.  (Two ranks over RCCL need two GPUs: the
+    parametrised test above runs them where they are visible.)"""
+    (plain,) = _run(1, tmp_path, "p1")
+    (rccl,) = _run(1, tmp_path, "r1", "nccl", DP_SINGLE_RANK_RCCL="1")
+    assert int(rccl["early"]) > 0                                  # chunks went to RCCL while backward was still running
+    assert np.array_equal(plain["arena"], rccl["arena"]) and np.array_equal(plain["params"], rccl["params"])
+    assert np.array_equal(plain["losses"], rccl["losses"])
 
 
 def test_bench_two_ranks_on_one_gpu_prints_the_contract_line():

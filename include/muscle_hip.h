@@ -121,6 +121,13 @@ int mx_pw_wgrad_small_bnbwd(const float* G, const float* G2, const float* coef, 
                             int ldg, int ldx, void* ws, long ws_bytes, void* stream);
 int mx_pw_wgrad_tile_bnbwd(const float* G, const float* G2, const float* coef, const float* X, float* dW, int R, int Co, int Ci,
                            int ldg, int ldx, void* ws, long ws_bytes, void* stream);
+/* Round 5: the fold on the weight-gradient side ONLY.  The weight gradient of the expand convolution (backward of model.py:77) runs
+ * first; the loader waves of its wave-specialised kernel form dZ = c1*G + c2*G2 + c3 and also STORE it (dz [R, ldg], not aliasing G or
+ * G2), and the data gradient then reads that materialised dZ like before: the apply pass mx_bn_bwd_apply (2 reads + 1 write of the
+ * Cexp-wide tensors) is not launched, and no matrix wave carries a second operand stream.  _ok: 1 where the kernel takes the shape. */
+int mx_pw_wgrad_tile_bnbwd_dz_ok(int R, int Co, int Ci, int ldg, int ldx);
+int mx_pw_wgrad_tile_bnbwd_dz(const float* G, const float* G2, const float* coef, const float* X, float* dW, float* dz, int R, int Co,
+                              int Ci, int ldg, int ldx, void* ws, long ws_bytes, void* stream);
 
 /* dW[Co,Ci] += G[R,Co]^T * X'[R,Ci]: weight gradient, general kernel (the shapes the two below do not take).  The R pixel
  * rows are split into slices; with more than one slice each adds into its own partial matrix in `ws` (mx_pw_wgrad_ws bytes)

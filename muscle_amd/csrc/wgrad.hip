@@ -300,6 +300,7 @@ struct WtArgs {
   int order;               // 0: XCD-aware (tiles of a group on one XCD); 1: group-major; 2: tile-major
   const float* G2;         // wgrad_split_kernel<*, true>: the G operand is c1*G + c2*G2 + c3 per column (BatchNorm backward apply
   const float* gcoef;      //   folded into the load; gcoef = [3][Co]); G2 shares G's leading dimension
+  float* dz;               // wgrad_split_ws_kernel<true> only: if set, that operand is also WRITTEN here ([R, ldg]; by the ci-tile-0 items)
 };
 
 template <int TE, int TF, int XMODE>
@@ -846,8 +847,14 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_pipe_kernel(WtArgs a) {
 #ifndef WWS_PRIO
 #define WWS_PRIO 1         // s_setprio of the MFMA waves
 #endif
+// GBN: the G operand is the BatchNorm backward apply dZ = c1*G + c2*G2 + c3 (per column), formed by the G loader waves from two tensors
+// (their vector work grows by 2 FMAs per element, their requests double); with a.dz set the items of ci tile 0 also STORE it, so the
+// data gradient that follows reads a materialised dZ and the separate 2R + 1W pass (bn_bwd_apply) is gone - unlike round 4's fold into
+// BOTH consumers, no GEMM kernel carries a second operand stream in its matrix waves.
+template <bool GBN>
 __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
   constexpr int PLANE = 4 * 144 * 16, STAGE = 6 * PLANE;    // the image of wgrad_split_pipe_kernel
+  constexpr int PF = WWS_PF;                                // raw row sets (the folded form holds two tensors' rows in each)
   extern __shared__ __attribute__((aligned(16))) unsigned char ws_smem[];      // 2 * STAGE
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = a.tiles_co * a.tiles_ci;
@@ -866,11 +873,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
     const int ld = __builtin_amdgcn_readfirstlane(isx ? a.ldx : a.ldg);
     const unsigned slab_bytes = (unsigned)(32 * ld * 4), row_bytes = (unsigned)(ld * 4);
     typedef float wf4 __attribute__((ext_vector_type(4)));
-    wf4 raw[WWS_PF][8];
+    wf4 raw[PF][8];
+    wf4 raw2[GBN ? PF : 1][8];
+    const bool isg = GBN && !isx;                            // (wave-uniform: waves 4-5)
     unsigned char* const wb = ws_smem + (isx ? 3 * PLANE : 0) + (rg * 144 + c) * 16;
-#define WWS_GLOAD(RV, S)                                                                                                            \
-    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                                \
-      RV[i_] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + (unsigned)i_ * row_bytes, (unsigned)(S) * slab_bytes, 0));
+#define WWS_GLOAD(K, S)                                                                                                             \
+    _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                              \
+      raw[K][i_] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + (unsigned)i_ * row_bytes, (unsigned)(S) * slab_bytes, 0)); \
+      if (isg) raw2[GBN ? (K) : 0][i_] = __builtin_bit_cast(wf4, __builtin_amdgcn_raw_buffer_load_b128(rs2, vbase + (unsigned)i_ * row_bytes, (unsigned)(S) * slab_bytes, 0)); \
+    }
+    // the folded operand: dZ in place of the raw rows of slab S (rows past the group give c3 - they meet zero rows of X), stored once per G block
+#define WWS_FOLD(K, S)                                                                                                              \
+    if (isg) {                                                                                                                      \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_) {                                                                            \
+        _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_)                                                                            \
+          raw[K][i_][e_] = __builtin_fmaf(gc1[e_], raw[K][i_][e_], __builtin_fmaf(gc2[e_], raw2[GBN ? (K) : 0][i_][e_], gc3[e_])); \
+        if (wr_dz) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(wu4, raw[K][i_]), rdz, vbase + (unsigned)i_ * row_bytes, (unsigned)(S) * slab_bytes, 0); \
+      }                                                                                                                             \
+    }
 // (lab, round 5: the two residual subtractions of adjacent columns as ONE v_pk_add_f32 - 144 instead of 176 vector instructions per
 // slab - took the MFMA waves from 39.8 to 62.6 cycles per MFMA: packed f32 arithmetic on the partner wave stalls the matrix pipe)
 #define WWS_SPLIT(RV, STG)                                                                                                          \
@@ -886,7 +906,8 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
     }
 #define WWS_LBODY(S, RB)                                                                                                            \
     {                                                                                                                               \
-      WWS_GLOAD(raw[((RB) + WWS_PF - 1) % WWS_PF], (S) + WWS_PF)                                                                    \
+      WWS_GLOAD(((RB) + PF - 1) % PF, (S) + PF)                                                                                     \
+      WWS_FOLD(RB, (S) + 1)                                                                                                         \
       WWS_SPLIT(raw[RB], ((S) + 1) & 1)                                                                                             \
       __builtin_amdgcn_s_waitcnt(0xc07f);                                                                                           \
       __builtin_amdgcn_s_barrier();                                                                                                 \
@@ -905,22 +926,33 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
       // the descriptor covers exactly the group's rows: rows past its end and columns past the matrix read as zeros by the range check
       const __amdgpu_buffer_rsrc_t rs = wbuf_rsrc((isx ? a.X.p : a.G) + r_beg * ld, (long)rows * ld * 4);
       const unsigned vbase = colok ? (unsigned)((8 * rg * ld + col0) * 4) : 0x7f000000u;
-      WWS_GLOAD(raw[0], 0)
-      WWS_GLOAD(raw[1], 1)
-      if (WWS_PF >= 3) { WWS_GLOAD(raw[WWS_PF >= 3 ? 2 : 0], 2) }
-      if (WWS_PF >= 4) { WWS_GLOAD(raw[WWS_PF >= 4 ? 3 : 0], 3) }
+      const __amdgpu_buffer_rsrc_t rs2 = isg ? wbuf_rsrc(a.G2 + r_beg * ld, (long)rows * ld * 4) : rs;
+      const bool wr_dz = isg && a.dz != nullptr && tile % a.tiles_ci == 0;
+      const __amdgpu_buffer_rsrc_t rdz = wr_dz ? wbuf_rsrc(a.dz + r_beg * ld, (long)rows * ld * 4) : rs;
+      typedef unsigned wu4 __attribute__((ext_vector_type(4)));
+      wf4 gc1 = {1.f, 1.f, 1.f, 1.f}, gc2 = {0.f, 0.f, 0.f, 0.f}, gc3 = gc2;
+      if (isg && colok) {
+        gc1 = *reinterpret_cast<const wf4*>(a.gcoef + col0); gc2 = *reinterpret_cast<const wf4*>(a.gcoef + a.Co + col0);
+        gc3 = *reinterpret_cast<const wf4*>(a.gcoef + 2 * a.Co + col0);
+      }
+      WWS_GLOAD(0, 0)
+      WWS_GLOAD(1, 1)
+      if (PF >= 3) { WWS_GLOAD(PF >= 3 ? 2 : 0, 2) }
+      if (PF >= 4) { WWS_GLOAD(PF >= 4 ? 3 : 0, 3) }
+      WWS_FOLD(0, 0)
       WWS_SPLIT(raw[0], 0)
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-      for (int s = 0; s < ns; s += WWS_PF) {
+      for (int s = 0; s < ns; s += PF) {
         WWS_LBODY(s, 1)
-        if (s + 1 < ns) WWS_LBODY(s + 1, 2 % WWS_PF)
-        if (WWS_PF >= 3 && s + 2 < ns) WWS_LBODY(s + 2, 3 % WWS_PF)
-        if (WWS_PF >= 4 && s + 3 < ns) WWS_LBODY(s + 3, 0)
+        if (s + 1 < ns) WWS_LBODY(s + 1, 2 % PF)
+        if (PF >= 3 && s + 2 < ns) WWS_LBODY(s + 2, 3 % PF)
+        if (PF >= 4 && s + 3 < ns) WWS_LBODY(s + 3, 0)
       }
     }
 #undef WWS_LBODY
+#undef WWS_FOLD
 #undef WWS_SPLIT
 #undef WWS_GLOAD
     return;
@@ -1253,7 +1285,7 @@ long mx_pw_wgrad_tile_ws(int R, int Co, int Ci, int x_mode) {
 
 static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, const float* X, int x_mode, const float* x_scale,
                            const float* x_shift, const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg,
-                           int ldx, void* ws, long ws_bytes, void* stream);
+                           int ldx, void* ws, long ws_bytes, void* stream, float* dz = nullptr);
 
 // dW[Co,Ci] += G[R,Co]^T X'[R,Ci], large outputs: tiled, deterministic (partial tiles per row group, fixed-order reduce).
 int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
@@ -1276,11 +1308,30 @@ int mx_pw_wgrad_tile_bnbwd(const float* G, const float* G2, const float* coef, c
   return wgrad_tile_impl(G, G2, coef, X, MX_PLAIN, nullptr, nullptr, nullptr, 1, dW, R, Co, Ci, ldg, ldx, ws, ws_bytes, stream);
 }
 
+// 1 when mx_pw_wgrad_tile_bnbwd_dz can leave dZ for this shape (the wave-specialised kernel takes it), else 0
+int mx_pw_wgrad_tile_bnbwd_dz_ok(int R, int Co, int Ci, int ldg, int ldx) {
+  WtPlan p;
+  if (!mx_wgrad_uses_split(R, Co, Ci) || wt_pipe_mode() < 2 || !wt_plan(R, Co, Ci, MX_PLAIN, &p)) return 0;
+  return ((long)p.rows_per_group + 96) * (ldg > ldx ? ldg : ldx) * 4 < (1l << 30) ? 1 : 0;
+}
+
+// The same, and dZ[R, ldg] = c1*G + c2*G2 + c3 is also WRITTEN (round 5): the weight gradient runs FIRST and its loader waves leave the
+// materialised operand for the data gradient (mx_pw_fwd_planes / mx_pw_dgrad on dZ), so the separate apply pass (mx_bn_bwd_apply:
+// 2 reads + 1 write of the Cexp-wide tensors) is not launched at all.  dz must not alias G or G2.  Shapes: mx_pw_wgrad_tile_bnbwd_dz_ok.
+int mx_pw_wgrad_tile_bnbwd_dz(const float* G, const float* G2, const float* coef, const float* X, float* dW, float* dz, int R, int Co,
+                              int Ci, int ldg, int ldx, void* ws, long ws_bytes, void* stream) {
+  MX_CHECK_ARG(G2 && coef && dz, "wgrad_tile_bnbwd_dz: null pointer");
+  MX_CHECK_ARG((((uintptr_t)G2 | (uintptr_t)coef | (uintptr_t)dz) & 15) == 0, "wgrad_tile_bnbwd_dz: pointers must be 16-byte aligned");
+  MX_CHECK_ARG(dz != G && dz != G2, "wgrad_tile_bnbwd_dz: dz aliases an input (other workgroups still read it)");
+  MX_CHECK_ARG(mx_pw_wgrad_tile_bnbwd_dz_ok(R, Co, Ci, ldg, ldx), "wgrad_tile_bnbwd_dz: shape R=%d Co=%d Ci=%d not taken (mx_pw_wgrad_tile_bnbwd_dz_ok)", R, Co, Ci);
+  return wgrad_tile_impl(G, G2, coef, X, MX_PLAIN, nullptr, nullptr, nullptr, 1, dW, R, Co, Ci, ldg, ldx, ws, ws_bytes, stream, dz);
+}
+
 }  // extern "C"
 
 static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, const float* X, int x_mode, const float* x_scale,
                            const float* x_shift, const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg,
-                           int ldx, void* ws, long ws_bytes, void* stream) {
+                           int ldx, void* ws, long ws_bytes, void* stream, float* dz) {
   MX_CHECK_ARG(G && X && dW && ws, "wgrad_tile: null pointer");
   MX_CHECK_ARG(((uintptr_t)dW & 15) == 0 && ((uintptr_t)ws & 15) == 0 && ((uintptr_t)G & 15) == 0 && ((uintptr_t)X & 15) == 0,
                "wgrad_tile: pointers must be 16-byte aligned");
@@ -1295,7 +1346,7 @@ static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, 
   a.rows_per_group = p.rows_per_group; a.groups = p.groups; a.tiles_co = p.tiles_co; a.tiles_ci = p.tiles_ci;
   a.accumulate = p.groups == 1;
   a.order = wt_order();
-  a.G2 = G2; a.gcoef = gcoef;
+  a.G2 = G2; a.gcoef = gcoef; a.dz = dz;
   a.part = a.accumulate ? dW : (float*)ws;
   hipStream_t st = (hipStream_t)stream;
   if (wt_use_split(Co, Ci)) {
@@ -1307,11 +1358,18 @@ static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, 
     // the pipelined kernel addresses a group through 32-bit buffer offsets: (rows + 64) * ld * 4 bytes must stay far below 2^31
     const int pipe = wt_pipe_mode();
     const bool pipe_ok = pipe && !a.G2 && a.X.mode == MX_PLAIN && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30);
-    if (pipe_ok && pipe >= 2) {
-      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4 * 144 * 16), 0);
+    const bool ws_gbn = pipe >= 2 && a.G2 && a.X.mode == MX_PLAIN && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30);
+    MX_CHECK_ARG(!a.dz || ws_gbn, "wgrad_tile_bnbwd: the dZ output exists in the wave-specialised kernel only (mx_set_wgrad_kernel 2, rows per group x ld < 2^28)");
+    if (ws_gbn) {
+      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4 * 144 * 16), 0);
       (void)once;
       const int items = a.groups * a.tiles_co * a.tiles_ci;
-      hipLaunchKernelGGL(wgrad_split_ws_kernel, dim3(items < 256 ? 8 * cdiv(items, 8) : 256), dim3(512), 12 * 4 * 144 * 16, st, a);
+      hipLaunchKernelGGL(wgrad_split_ws_kernel<true>, dim3(items < 256 ? 8 * cdiv(items, 8) : 256), dim3(512), 12 * 4 * 144 * 16, st, a);
+    } else if (pipe_ok && pipe >= 2) {
+      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_ws_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4 * 144 * 16), 0);
+      (void)once;
+      const int items = a.groups * a.tiles_co * a.tiles_ci;
+      hipLaunchKernelGGL(wgrad_split_ws_kernel<false>, dim3(items < 256 ? 8 * cdiv(items, 8) : 256), dim3(512), 12 * 4 * 144 * 16, st, a);
     } else if (pipe_ok) {
       static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4 * 144 * 16), 0);
       (void)once;

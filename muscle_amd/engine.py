@@ -400,6 +400,13 @@ FOLD_BN0_BOTH = os.environ.get("MUSCLE_FOLD_BN0_BOTH", "0") == "1"
 # (data gradient through the planes kernel, weight gradient through wgrad_small_kernel<..., GBN>) trades a 3-pass kernel for one
 # more operand stream in two kernels that wait on memory anyway.  MUSCLE_FOLD_BN0_EARLY=0 restores the pass.
 FOLD_BN0_EARLY = os.environ.get("MUSCLE_FOLD_BN0_EARLY", "1") == "1"
+# Round 5: the fold on the weight-gradient side only.  The expand convolution's weight gradient runs FIRST, on the main stream; the
+# loader waves of wgrad_split_ws_kernel<true> form dZ and store it, the data gradient reads the stored dZ as before: bn_bwd_apply is gone
+# for the split-arithmetic layers (stages 4-7), neither GEMM's matrix waves carry a second operand.  Measured (profiles/r05_knob_ab.txt):
+# bn_bwd_apply 7.00 -> 2.94 ms per step, but the 42 folded weight gradients 6.6 -> 10.4 ms (their two G loader waves carry twice the
+# requests, the stores and the FMAs; the kernel is sensitive to its L2 traffic, which grows 1.75x) - step 96.50 -> 96.16 ms A/B/A/B.
+# Too little for a second dZ buffer per block: off by default (MUSCLE_FOLD_BN0_WGRAD=1); kernel and test stay.
+FOLD_BN0_WGRAD = os.environ.get("MUSCLE_FOLD_BN0_WGRAD", "0") == "1"
 # Weight-gradient GEMMs on a second HIP stream (MUSCLE_WGRAD_STREAM=0 turns it off; `engine.WGRAD_SIDE_STREAM` can be
 # flipped at run time).  Nothing in the backward chain consumes them (only the optimizer and the gradient exchange do),
 # they are MFMA-bound, and the chain between two of them (BN backward, SE, depthwise) is HBM-bound.  Measured on
@@ -621,9 +628,13 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
             wtp = tape.wtp.get(id(m._expand_conv.weight)) if b.expand else None
             kind = ops.bnbwd_fold_takes(M, b.cexp, b.cin) if (fused and b.expand and not fold and wtp is not None and ops.DGRAD_AS_FORWARD) else None
             fold2 = (kind == "tile" and FOLD_BN0_BOTH) or (kind == "small" and FOLD_BN0_EARLY)
+            fold3 = (fused and b.expand and not fold and not fold2 and FOLD_BN0_WGRAD and gx2.is_contiguous() and raw2.is_contiguous()
+                     and ops.wgrad_bnbwd_dz_takes(M, b.cexp, b.cin))
             if fused:
                 c0 = c0_fin if c0_fin is not None else ops.bn_bwd_coeffs(part0, M, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training)
-                if not fold and not fold2:
+                if fold3:
+                    dz = ops.pw_wgrad_bnbwd_dz(gx2, raw2, c0, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
+                elif not fold and not fold2:
                     dz = ops.bn_bwd_apply_plain(gx2, raw2, c0, gx2)
             else:
                 dz = ops.bn_backward(gx2, raw2, bn_mod, dw_st, sink.of(bn_mod.weight), sink.of(bn_mod.bias), training,
@@ -644,7 +655,8 @@ def backbone_backward(backbone, cfg: NetCfg, tape: Tape, tap_grads: Dict[int, to
                 lane.flush()
                 g_out = g_in.view(N, t.H, t.W, b.cin)
             elif b.expand:
-                lane.wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
+                if not fold3:
+                    lane.wgrad(dz, t.x.view(M, b.cin), sink.of(m._expand_conv.weight).view(b.cexp, b.cin))
                 g_in = ops.pw_dgrad(dz, m._expand_conv.weight.view(b.cexp, b.cin), b.cin, wt=tape.wt.get(id(m._expand_conv.weight)),
                                     planes=tape.wtp.get(id(m._expand_conv.weight)),
                                     residual=skip_res.reshape(M, b.cin) if skip_res is not None else None)

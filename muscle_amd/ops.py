@@ -293,6 +293,29 @@ def pw_wgrad_bnbwd(G, G2, coef, X, dW):
     call("mx_pw_wgrad_tile_bnbwd", ptr(G), ptr(G2), ptr(coef), ptr(X), ptr(dW), R, Co, Ci, G.stride(0), X.stride(0), ws.data_ptr(), ws.numel(), stream())
 
 
+def wgrad_bnbwd_dz_takes(R, Co, Ci) -> bool:
+    """True where `pw_wgrad_bnbwd_dz` exists: the wave-specialised split weight-gradient kernel takes dW [Co, Ci] over R rows."""
+    key = ("dzfold", get_gemm_mode(), get_wgrad_kernel(), R, Co, Ci)
+    r = _uses_planes.get(key)
+    if r is None:
+        r = _uses_planes[key] = bool(lib().mx_pw_wgrad_tile_bnbwd_dz_ok(R, Co, Ci, Co, Ci))
+    return r
+
+
+def pw_wgrad_bnbwd_dz(G, G2, coef, X, dW, dz=None):
+    """dW[Co, Ci] += dZ^T X with dZ = c1*G + c2*G2 + c3 formed AND stored by the weight-gradient kernel's loader waves (round 5):
+    returns dZ [R, Co] for the data gradient that follows; mx_bn_bwd_apply is not launched."""
+    R, Co = G.shape
+    Ci = X.shape[1]
+    if dz is None:
+        dz = torch.empty_like(G)
+    need = lib().mx_pw_wgrad_tile_ws(R, Co, Ci, PLAIN)
+    ws = _wgrad_workspace(G.device, max(need, 16))
+    call("mx_pw_wgrad_tile_bnbwd_dz", ptr(G), ptr(G2), ptr(coef), ptr(X), ptr(dW), ptr(dz), R, Co, Ci, G.stride(0), X.stride(0),
+         ws.data_ptr(), ws.numel(), stream())
+    return dz
+
+
 _wgrad_ws: dict = {}
 _wgrad_ws_retired: list = []      # outgrown workspaces stay alive: captured graphs keep writing to them
 WGRAD_TILE = os.environ.get("MUSCLE_WGRAD_TILE", "1") == "1"   # large outputs: tiled deterministic kernel (wgrad.hip) instead of the atomic TN GEMM

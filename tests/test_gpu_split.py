@@ -325,3 +325,45 @@ def test_wgrad_kernels_of_round_5_equal_the_first_split_kernel_bit_for_bit(R, Co
     assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
     ref = base.double() + G.double().t() @ X.double()
     assert (outs[2].double() - ref).abs().max().item() <= 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("M,K,N", [(25088, 960, 160), (12544 + 5, 2304, 384), (6272, 1344, 224), (3136 * 3, 3840, 640)])
+def test_wgrad_side_fold_leaves_dz_for_the_data_gradient(M, K, N):
+    """Round 5's form of the BatchNorm-backward fold: mx_pw_wgrad_tile_bnbwd_dz forms dZ = c1*G + c2*X + c3 in the loader waves of the
+    weight-gradient kernel, uses it and STORES it; the data gradient then reads the stored dZ.  Held to the unfused pair (bn_bwd_apply,
+    then the plain weight gradient) and to float64: dZ itself to one rounding of its three terms, dW like the unfused kernel; the rows
+    past a ragged end and the padded tile columns leave nothing behind; bit-identical from run to run."""
+    import muscle_amd
+    from muscle_amd import ops
+    g = torch.Generator(device=DEV).manual_seed(M + N)
+    G = torch.randn(M, K, device=DEV, generator=g)
+    X = torch.randn(M, K, device=DEV, generator=g)
+    coef = torch.stack([torch.rand(K, device=DEV, generator=g) + 0.5, torch.randn(K, device=DEV, generator=g) * 0.3,
+                        torch.randn(K, device=DEV, generator=g) * 0.1]).contiguous()
+    Xin = torch.randn(M, N, device=DEV, generator=g)
+    dz64 = coef[0].double() * G.double() + coef[1].double() * X.double() + coef[2].double()
+    want_dw = dz64.t() @ Xin.double()
+    muscle_amd.set_gemm_mode(1)
+    try:
+        if not ops.wgrad_bnbwd_dz_takes(M, K, N):
+            pytest.skip("shape not taken by the wave-specialised kernel in mode 1")
+        dz_ref = ops.bn_bwd_apply_plain(G, X, coef, torch.empty_like(G))
+        dw_ref = torch.zeros(K, N, device=DEV)
+        ops.pw_wgrad(dz_ref, Xin, dw_ref)
+        outs = []
+        for _ in range(2):
+            dw = torch.zeros(K, N, device=DEV)
+            dz = torch.full_like(G, float("nan"))                      # every element must be written
+            ops.pw_wgrad_bnbwd_dz(G, X, coef, Xin, dw, dz)
+            outs.append((dz, dw))
+    finally:
+        muscle_amd.set_gemm_mode(0)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    dz, dw = outs[0]
+    assert torch.isfinite(dz).all()
+    mag = (coef[0].abs() * G.abs() + coef[1].abs() * X.abs() + coef[2].abs()).double()
+    assert float(((dz.double() - dz64).abs() / mag).max()) <= 2.0 * 2 ** -24            # two fused roundings at most
+    assert float((dz - dz_ref).abs().max()) <= 4e-7 * float(dz64.abs().max())
+    scale = float(want_dw.abs().max())
+    e_got, e_ref = float((dw.double() - want_dw).abs().max()), float((dw_ref.double() - want_dw).abs().max())
+    assert e_got <= 1.5 * e_ref + 3e-7 * scale, (e_got, e_ref, scale)

@@ -31,13 +31,17 @@ class GradAverager:
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         # a one-rank group normally skips the exchange; `single_rank_collectives` issues it anyway (the average over one rank is the
         # identity): the only way to run the RCCL calls and their stream ordering on a one-GPU box (tests/test_gpu_dist.py)
-        self.active = self.world > 1 or (single_rank_collectives and dist.is_initialized())
+        self._force = bool(single_rank_collectives and dist.is_initialized())
         self.bytes_reduced = 0
         self.chunk = max(1, chunk_bytes // 4)          # elements
         self._sink = None
         self._next = -1                                # highest chunk index not launched yet
         self._works: List = []
         self.launched_early = 0                        # chunks that went out before the hook (statistics / tests)
+
+    @property
+    def active(self) -> bool:
+        return self.world > 1 or self._force
 
     # ---- wiring ---------------------------------------------------------------------------------------------
     def attach(self, model):

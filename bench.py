@@ -301,6 +301,9 @@ def short_run_infer(dev, steps=3):
 
 
 def main():
+    # host threads: the GPU boxes show 256 CPUs under a cgroup quota of 16; torch's default of 128 intra-op threads makes every CPU-side
+    # torch call that parallelises 10-30x slower there (profiles/r05_cpu_probe.txt).  Per rank: the quota shared by the ranks of the node.
+    torch.set_num_threads(max(1, min(16, cpu_share() // max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1"))))))
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)

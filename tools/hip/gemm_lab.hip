@@ -29,6 +29,7 @@
 #include "../../muscle_amd/csrc/gemm.hip"
 #include "../../muscle_amd/csrc/wgrad.hip"
 #include "../../muscle_amd/csrc/api.cpp"
+#include "../../muscle_amd/csrc/bn.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -406,7 +407,66 @@ static int run_wgrad(int R, int Co, int Ci) {
   return md == 0 ? 0 : 2;
 }
 
+// wgradf [R Co Ci]: the weight-gradient-side BatchNorm-backward fold (wgrad_split_ws_kernel<true>, dZ stored) against the plain kernel + the apply pass it replaces
+static int run_wgradf(int R, int Co, int Ci) {
+  if (!ws) CK(hipMalloc(&ws, ws_bytes));
+  float* G = dalloc((long)R * Co, 11, 1.f); float* G2 = dalloc((long)R * Co, 14, 1.f); float* X = dalloc((long)R * Ci, 12, 1.f);
+  float* coef = dalloc(3l * Co, 15, 1.f); float* dz = dalloc((long)R * Co, 16, 0.f);
+  float* d0 = dalloc((long)Co * Ci, 13, 0.f);
+  if (!mx_pw_wgrad_tile_bnbwd_dz_ok(R, Co, Ci, Co, Ci)) { printf("  R=%d Co=%d Ci=%d: not taken\n", R, Co, Ci); return 0; }
+  const double fl = 2.0 * R * Co * Ci;
+  float t0 = 1e30f, t1 = 1e30f, t2 = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    t0 = std::min(t0, time_us([&] { mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, d0, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr); }, 5));
+    t1 = std::min(t1, time_us([&] { mx_pw_wgrad_tile_bnbwd_dz(G, G2, coef, X, d0, dz, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr); }, 5));
+    t2 = std::min(t2, time_us([&] { mx_bn_bwd_apply(G, G2, nullptr, nullptr, nullptr, nullptr, nullptr, coef, coef + Co, coef + 2 * Co, dz, R, Co, 1, nullptr); }, 5));
+  }
+  printf("  R=%d Co=%d Ci=%d: plain %7.1f us %6.1f TF | folded + dZ %7.1f us | bn_bwd_apply alone %6.1f us -> %+.1f us\n", R, Co, Ci, t0, fl / t0 / 1e6, t1, t2, t1 - t0 - t2);
+  {   // what of the fold costs: without the dZ stores; with G2 = G (the second tensor's requests hit the lines just fetched)
+    float t3 = 1e30f, t4 = 1e30f, t5 = 1e30f;
+    for (int rep = 0; rep < 3; ++rep) {
+      t3 = std::min(t3, time_us([&] { mx_pw_wgrad_tile_bnbwd(G, G2, coef, X, d0, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr); }, 5));
+      t4 = std::min(t4, time_us([&] { mx_pw_wgrad_tile_bnbwd(G, G, coef, X, d0, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr); }, 5));
+      t5 = std::min(t5, time_us([&] { mx_pw_wgrad_tile_bnbwd_dz(G, G, coef, X, d0, dz, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr); }, 5));
+    }
+    printf("    folded without dZ stores %7.1f us | with G2 = G, no stores %7.1f us | with G2 = G and stores %7.1f us\n", t3, t4, t5);
+  }
+#ifdef WPIPE_STAMPS
+  {
+    const long nwg = 1 << 16;
+    unsigned long long* st; CK(hipMalloc(&st, nwg * 8 * sizeof(unsigned long long))); CK(hipMemset(st, 0, nwg * 8 * sizeof(unsigned long long)));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(wpipe_stamps), &st, sizeof(st)));
+    for (int i = 0; i < 100; ++i) mx_pw_wgrad_tile_bnbwd_dz(G, G2, coef, X, d0, dz, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr);
+    CK(hipDeviceSynchronize());
+    std::vector<unsigned long long> h(nwg * 8);
+    CK(hipMemcpy(h.data(), st, nwg * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    std::vector<double> loop, ghz;
+    for (long w = 0; w < nwg; ++w) {
+      if (!h[w * 8 + 3]) continue;
+      loop.push_back((double)(h[w * 8 + 2] - h[w * 8 + 1]));
+      ghz.push_back((double)(h[w * 8 + 3] - h[w * 8 + 0]) / ((double)(h[w * 8 + 5] - h[w * 8 + 4]) * 10.0));
+    }
+    auto med = [](std::vector<double>& v) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[v.size() / 2]; };
+    WtPlan pl; wt_plan(R, Co, Ci, 0, &pl);
+    const int ns = (pl.rows_per_group + 31) / 32;
+    printf("    stamps (folded): %zu workgroups, %d slabs: %.1f cycles per slab (%.1f per MFMA), clock %.2f GHz\n", loop.size(), ns, med(loop) / ns, med(loop) / ns / 48, med(ghz));
+    unsigned long long* z = nullptr; CK(hipMemcpyToSymbol(HIP_SYMBOL(wpipe_stamps), &z, sizeof(z)));
+    CK(hipFree(st));
+  }
+#endif
+  fflush(stdout);
+  for (float* p : {G, G2, X, coef, dz, d0}) CK(hipFree(p));
+  return 0;
+}
+
 int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "wgradf")) {
+    if (argc >= 5) return run_wgradf(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
+    static const Shape sh[] = {{25088, 2304, 384}, {25088, 3840, 640}, {25088, 1344, 224}, {25088, 960, 160}};
+    for (const Shape& s : sh) run_wgradf(s.M, s.K, s.N);
+    return 0;
+  }
+
   if (argc >= 2 && !strcmp(argv[1], "wgrad")) {
     if (argc >= 5) return run_wgrad(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     static const Shape sh[] = {{25088, 2304, 384}, {25088, 384, 2304}, {25088, 3840, 640}, {25088, 640, 3840}, {25088, 1344, 224}, {25088, 224, 1344},

@@ -273,6 +273,8 @@ def short_run_dec(dev, warm=2, steps=10):
     v = n * steps / dt
     return {"value": v, "unit": "images/sec", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warm,
             "ceiling_fp32_mfma": 1290.0, "frac_of_ceiling": v / 1290.0,
+            "arithmetic": "split" if muscle_amd.get_gemm_mode() >= 1 else "fp32",
+            "ceiling_split_mfma": round(1290.0 * (2500.0 / 6.0) / 157.3, 1), "frac_of_split_ceiling": v / (1290.0 * (2500.0 / 6.0) / 157.3),
             "workload": "train_muscle.py loop body (decoder + BEACON, lambda 0.05, k 128), efficientnet-b7 448x448 batch 16, last_pooling=True"}
 
 
@@ -293,8 +295,13 @@ def short_run_infer(dev, steps=3):
                 model(x, cam="cam_lr")
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / steps
+        # the forward runs in the library's default (split) arithmetic: its matrix ceiling is the bf16 pipe's 2500 / 6 TFLOP/s, 2.65 x the
+        # exact-fp32 one; both are quoted
+        split_ceil = ceil * (2500.0 / 6.0) / 157.3
         out[str(size)] = {"value": 64 / dt, "unit": "images/sec", "ms_per_batch": dt * 1e3, "steps": steps,
-                          "ceiling_fp32_mfma": ceil, "frac_of_ceiling": 64 / dt / ceil}
+                          "arithmetic": "split" if muscle_amd.get_gemm_mode() >= 1 else "fp32",
+                          "ceiling_fp32_mfma": ceil, "frac_of_ceiling": 64 / dt / ceil,
+                          "ceiling_split_mfma": round(split_ceil, 1), "frac_of_split_ceiling": 64 / dt / split_ceil}
         del x
     out["workload"] = "infer_mcl.py eval forward (cam='cam_lr', BatchNorm folded), efficientnet-b7, batch 64, 448 / 512 / 768"
     return out

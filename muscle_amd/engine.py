@@ -404,7 +404,7 @@ FOLD_BN0_EARLY = os.environ.get("MUSCLE_FOLD_BN0_EARLY", "1") == "1"
 # loader waves of wgrad_split_ws_kernel<true> form dZ and store it, the data gradient reads the stored dZ as before: bn_bwd_apply is gone
 # for the split-arithmetic layers (stages 4-7), neither GEMM's matrix waves carry a second operand.  Measured (profiles/r05_knob_ab.txt):
 # bn_bwd_apply 7.00 -> 2.94 ms per step, but the 42 folded weight gradients 6.6 -> 10.4 ms (their two G loader waves carry twice the
-# requests, the stores and the FMAs; the kernel is sensitive to its L2 traffic, which grows 1.75x) - step 96.50 -> 96.16 ms A/B/A/B.
+# requests, the stores and the FMAs; the kernel is sensitive to its L2 traffic, which grows 1.75x) - step 96.50 -> 96.16 ms A/B/A/B on one box, 96.77 -> 97.09 on another.
 # Too little for a second dZ buffer per block: off by default (MUSCLE_FOLD_BN0_WGRAD=1); kernel and test stay.
 FOLD_BN0_WGRAD = os.environ.get("MUSCLE_FOLD_BN0_WGRAD", "0") == "1"
 # Weight-gradient GEMMs on a second HIP stream (MUSCLE_WGRAD_STREAM=0 turns it off; `engine.WGRAD_SIDE_STREAM` can be

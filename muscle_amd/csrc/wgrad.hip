@@ -1312,7 +1312,7 @@ int mx_pw_wgrad_tile_bnbwd(const float* G, const float* G2, const float* coef, c
 int mx_pw_wgrad_tile_bnbwd_dz_ok(int R, int Co, int Ci, int ldg, int ldx) {
   WtPlan p;
   if (!mx_wgrad_uses_split(R, Co, Ci) || wt_pipe_mode() < 2 || !wt_plan(R, Co, Ci, MX_PLAIN, &p)) return 0;
-  return ((long)p.rows_per_group + 96) * (ldg > ldx ? ldg : ldx) * 4 < (1l << 30) ? 1 : 0;
+  return (((long)p.rows_per_group + 96) * (ldg > ldx ? ldg : ldx) * 4 < (1l << 30) && (long)Co * Ci * 4 < (1l << 30)) ? 1 : 0;
 }
 
 // The same, and dZ[R, ldg] = c1*G + c2*G2 + c3 is also WRITTEN (round 5): the weight gradient runs FIRST and its loader waves leave the
@@ -1357,8 +1357,11 @@ static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, 
     static const int pad = getenv("MX_WGRAD_SPLIT_LDS_PAD") ? atoi(getenv("MX_WGRAD_SPLIT_LDS_PAD")) : 0;
     // the pipelined kernel addresses a group through 32-bit buffer offsets: (rows + 64) * ld * 4 bytes must stay far below 2^31
     const int pipe = wt_pipe_mode();
-    const bool pipe_ok = pipe && !a.G2 && a.X.mode == MX_PLAIN && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30);
-    const bool ws_gbn = pipe >= 2 && a.G2 && a.X.mode == MX_PLAIN && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30);
+    // (and the partial tile is stored through 32-bit buffer offsets as well: Co x Ci x 4 bytes)
+    const bool pipe_ok = pipe && !a.G2 && a.X.mode == MX_PLAIN && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30) &&
+                         (long)a.Co * a.Ci * 4 < (1l << 30);
+    const bool ws_gbn = pipe >= 2 && a.G2 && a.X.mode == MX_PLAIN && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30) &&
+                        (long)a.Co * a.Ci * 4 < (1l << 30);
     MX_CHECK_ARG(!a.dz || ws_gbn, "wgrad_tile_bnbwd: the dZ output exists in the wave-specialised kernel only (mx_set_wgrad_kernel 2, rows per group x ld < 2^28)");
     if (ws_gbn) {
       static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_split_ws_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 12 * 4 * 144 * 16), 0);

@@ -844,6 +844,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_split_pipe_kernel(WtArgs a) {
 #ifndef WWS_PF
 #define WWS_PF 3           // raw row sets of a loader wave (slabs requested ahead)
 #endif
+#ifndef WWS_CHAIN
+#define WWS_CHAIN 49       // slabs (32 rows) of one fp32 accumulation chain: 1568 rows
+#endif
 #ifndef WWS_PRIO
 #define WWS_PRIO 1         // s_setprio of the MFMA waves
 #endif
@@ -1003,9 +1006,25 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
     __builtin_amdgcn_s_barrier();                // slab 0 of this item is in stage 0
     asm volatile("" ::: "memory");
     if (it == 0) WWS_STAMP(1);
+    // A group may hold several accumulation chains: every WWS_CHAIN slabs (1568 rows, the bound the fp64 tests set for ONE fp32 chain)
+    // the accumulators are added into a second set and cleared - the same roundings as that many separate groups added by the reduce
+    // kernel, without their items, partial tiles and reduce traffic.
+    wf32x16 acc2[2][2];
+    bool flushed = false;
+    int flush_at = WWS_CHAIN;
     for (int s = 0; s < ns; ++s) {
       const unsigned char* st_ = ws_smem + (s & 1) * STAGE;
       WWS_HALF(gv1, xv1, gv0, xv0, st_, 0)
+      if (s == flush_at) {                       // slabs < s are complete in acc (the half above was slab s - 1's second step)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc2[e][f][r] = flushed ? acc2[e][f][r] + acc[e][f][r] : acc[e][f][r]; acc[e][f][r] = 0.f; }
+        flushed = true;
+        flush_at += WWS_CHAIN;
+      }
       WWS_HALF(gv0, xv0, gv1, xv1, st_, 1)
       __builtin_amdgcn_s_waitcnt(0xc07f);
       __builtin_amdgcn_s_barrier();
@@ -1014,6 +1033,14 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
     if (it == 0) WWS_STAMP(2);
 #pragma unroll
     for (int n_ = 0; n_ < 24; ++n_) { WWS_MFMA(gv1, xv1, n_ >> 2, n_ & 3); }
+    if (flushed) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[e][f][r] = acc2[e][f][r] + acc[e][f][r];
+    }
     // acc[e][f][4 g + r] = dW[co0 + 64 wco + 32 e + 8 g + 4 hf + r][ci0 + 64 wci + 32 f + l31]
     if (!a.accumulate) {
       // partial tile of this group: 64 one-dword buffer stores per lane, the row / block part of the address in the scalar offset, rows past
@@ -1104,7 +1131,10 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
       // 3.4 us per item (first slabs + storing the partial tile), and the partial matrices once more through the reduce kernel.
       // The chain bound (<= 1568 rows per group) is the floor; 54 tiles take 18 groups (3.8 rounds) instead of 16 (3.4 -> 4 rounds).
       const int tiles = p->tiles_co * p->tiles_ci;
-      int gmin = cdiv(R, 1568);
+      // (a group may hold up to MX_WGRAD_WS_CHAINS chains of 1568 rows, flushed inside the kernel: fewer items and partial tiles)
+      static const int chains = getenv("MX_WGRAD_WS_CHAINS") ? atoi(getenv("MX_WGRAD_WS_CHAINS")) : 3;
+      int gmin = cdiv(R, 1568 * (chains > 0 ? chains : 1));
+      if (gmin < 1) gmin = 1;
       if (gmin > maxg) gmin = maxg;
       int best_g = gmin;
       double best_t = 1e30;

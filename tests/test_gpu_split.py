@@ -297,7 +297,7 @@ def test_split_wgrad_matches_fp64_as_well_as_fp32_mfma(R, Co, Ci, mode):
     assert errs[1] <= 1.5 * errs[0] + 2e-7 * scale, (errs, scale)
 
 
-@pytest.mark.parametrize("R,Co,Ci,groups", [(25088, 384, 2304, 16), (12544 + 7, 1344, 224, 9), (5003, 640, 384, 4), (3136, 256, 132, 2), (2048, 256, 256, 1),
+@pytest.mark.parametrize("R,Co,Ci,groups", [(25088, 384, 2304, 16), (12544 + 7, 1344, 224, 9), (5003, 640, 384, 4), (3136, 256, 132, 2), (1536, 256, 256, 1),
                                               (6272, 2304, 384, 5)])
 def test_wgrad_kernels_of_round_5_equal_the_first_split_kernel_bit_for_bit(R, Co, Ci, groups):
     """wgrad_split_pipe_kernel (one software-pipelined stream) and wgrad_split_ws_kernel (4 MFMA waves + 4 loader waves, persistent)

@@ -129,22 +129,55 @@ __device__ __forceinline__ void bn_bwd_finalize_one(int c, double sg, double sgx
 // The reduction of bn_reduce_finalize_kernel<true> (bn.hip) for 32 channels starting at c0, by ONE workgroup of 256 threads: 8 row
 // lanes walk the P partial rows part[P][2][C] in the same order and association, so a producer that finishes its own statistics
 // (the last workgroup to arrive) leaves the same bits as the separate launch did.  `sh` = 2 x 8 x 32 doubles of LDS.
+// One row lane's share of the partial rows of a channel: rows rl, rl + 8, ... in batches of four (the summation order every BatchNorm
+// finalisation has used since round 2: ((a0 + a1) + (a2 + a3)) per batch, batches in ascending order, fp64).  U batches are REQUESTED before
+// the first is added - the kernels that call this are one short dependent chain of loads each (7-9 us for 196 rows at one batch per round
+// trip, 244 launches per B7 step), and the order of the additions, hence every bit of the result, does not depend on U.
+template <int U>
+__device__ __forceinline__ void bn_parts_batches(const float* part, int P, int C, int c, int& p, double& s0, double& s1) {
+  for (; p + 24 + 32 * (U - 1) < P; p += 32 * U) {
+    float a[U][4], b[U][4];
+    const unsigned o = (unsigned)p * 2u * (unsigned)C + (unsigned)c;          // (the partial rows are far below 2^31 bytes: P <= 1024 rows of 2C)
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned q = o + (unsigned)(32 * u + 8 * k) * 2u * (unsigned)C;
+        a[u][k] = part[q]; b[u][k] = part[q + (unsigned)C];
+      }
+    __builtin_amdgcn_sched_barrier(0);                 // every request before the first addition (the scheduler interleaves them otherwise)
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      s0 += ((double)a[u][0] + (double)a[u][1]) + ((double)a[u][2] + (double)a[u][3]);
+      s1 += ((double)b[u][0] + (double)b[u][1]) + ((double)b[u][2] + (double)b[u][3]);
+    }
+  }
+}
+__device__ __forceinline__ void bn_parts_lane_sum(const float* part, int P, int C, int c, int rl, double& s0, double& s1) {
+  int p = rl;
+  bn_parts_batches<6>(part, P, C, c, p, s0, s1);
+  bn_parts_batches<2>(part, P, C, c, p, s0, s1);
+  bn_parts_batches<1>(part, P, C, c, p, s0, s1);
+  float ta[3], tb[3];                                  // the last rows (fewer than four per lane): requested together from clamped rows, no branches
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const unsigned q = (unsigned)min(p + 8 * k, P - 1) * 2u * (unsigned)C + (unsigned)c;
+    ta[k] = part[q]; tb[k] = part[q + (unsigned)C];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool on = p + 8 * k < P;
+    const double n0 = s0 + (double)ta[k], n1 = s1 + (double)tb[k];
+    s0 = on ? n0 : s0; s1 = on ? n1 : s1;
+  }
+}
+
 __device__ __forceinline__ void bn_bwd_reduce_finalize_32(const float* part, int P, int C, int c0, const BnBwdFin& b, double* sh) {
   const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c = c0 + cl;
   double s0 = 0.0, s1 = 0.0;
-  if (c < C) {
-    int p = rl;
-    for (; p + 24 < P; p += 32) {
-      float a0 = part[(long)p * 2 * C + c], b0 = part[(long)p * 2 * C + C + c];
-      float a1 = part[(long)(p + 8) * 2 * C + c], b1 = part[(long)(p + 8) * 2 * C + C + c];
-      float a2 = part[(long)(p + 16) * 2 * C + c], b2 = part[(long)(p + 16) * 2 * C + C + c];
-      float a3 = part[(long)(p + 24) * 2 * C + c], b3 = part[(long)(p + 24) * 2 * C + C + c];
-      s0 += ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-      s1 += ((double)b0 + (double)b1) + ((double)b2 + (double)b3);
-    }
-    for (; p < P; p += 8) { s0 += (double)part[(long)p * 2 * C + c]; s1 += (double)part[(long)p * 2 * C + C + c]; }
-  }
+  if (c < C) bn_parts_lane_sum(part, P, C, c, rl, s0, s1);
   sh[rl * 32 + cl] = s0; sh[256 + rl * 32 + cl] = s1;
   __syncthreads();
   if (rl != 0 || c >= C) return;

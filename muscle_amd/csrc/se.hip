@@ -72,27 +72,44 @@ __global__ __launch_bounds__(256) void se_fwd_expand_kernel(const float* h, cons
 
 // ---- backward --------------------------------------------------------------------------------------
 // (A) g_r[n,j] = sum_c ge[n,c] W2[c,j] with ge = ggate*gate*(1-gate);  gh[n,j] = g_r * swish'(h)   (db1 leaves kernel B).
-//     One wave per (n, four consecutive j): W2 is [C,SQ] row-major, so a lane's load is one 16-byte piece of row c
-//     (a wave per single j fetched 4 useful bytes per 64-byte request).  SQ is a multiple of 4 for every EfficientNet width.
-__global__ __launch_bounds__(256) void se_bwd_a_kernel(const float* ggate, const float* gate, const float* h, const float* W2,
-                                                       float* gh, int C, int SQ) {
-  const int n = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int j = (blockIdx.y * 4 + wave) * 4;
-  if (j >= SQ) return;
+//     One workgroup of 1024 threads per (n, sixteen consecutive j): W2 is [C,SQ] row-major, a thread's load is one 16-byte piece of
+//     row c and four neighbouring lanes read 64 consecutive bytes of it; 256 channel lanes share the C rows (9 independent
+//     loads per thread at C = 2304 - round 4's form, one wave per four j, walked all 36 in one lane: 14 us of load latency on the
+//     backward chain of every block).  Sums: lanes of a wave by xor-shuffle, the 16 waves in ascending order - the same bits every run.
+//     SQ is a multiple of 4 for every EfficientNet-B7 width.
+__global__ __launch_bounds__(1024) void se_bwd_a_kernel(const float* ggate, const float* gate, const float* h, const float* W2,
+                                                        float* gh, int C, int SQ) {
+  __shared__ float red[16][16];
+  const int n = blockIdx.x, quad = threadIdx.x & 3, cl = threadIdx.x >> 2, wave = threadIdx.x >> 6;
+  const int j = (blockIdx.y * 4 + quad) * 4;
   const float* gg = ggate + (long)n * C;
   const float* gt = gate + (long)n * C;
   float4 acc = make_float4(0, 0, 0, 0);
-  for (int c = lane; c < C; c += 64) {
-    const float g = gt[c];
-    const float ge = gg[c] * g * (1.f - g);
-    const float4 w = ld4(W2 + (long)c * SQ + j);
-    acc.x += ge * w.x; acc.y += ge * w.y; acc.z += ge * w.z; acc.w += ge * w.w;
+  if (j < SQ) {
+#pragma unroll 4
+    for (int c = cl; c < C; c += 256) {
+      const float g = gt[c];
+      const float ge = gg[c] * g * (1.f - g);
+      const float4 w = ld4(W2 + (long)c * SQ + j);
+      acc.x += ge * w.x; acc.y += ge * w.y; acc.z += ge * w.z; acc.w += ge * w.w;
+    }
   }
-  acc.x = wave_sum(acc.x); acc.y = wave_sum(acc.y); acc.z = wave_sum(acc.z); acc.w = wave_sum(acc.w);
-  if (lane < 4) {
-    const float a = lane == 0 ? acc.x : lane == 1 ? acc.y : lane == 2 ? acc.z : acc.w;
-    const float v = a * swish_gradf_(h[(long)n * SQ + j + lane]);
-    gh[(long)n * SQ + j + lane] = v;
+#pragma unroll
+  for (int off = 4; off < 64; off <<= 1) {
+    acc.x += __shfl_xor(acc.x, off); acc.y += __shfl_xor(acc.y, off); acc.z += __shfl_xor(acc.z, off); acc.w += __shfl_xor(acc.w, off);
+  }
+  if ((threadIdx.x & 63) < 4) {
+    red[wave][quad * 4 + 0] = acc.x; red[wave][quad * 4 + 1] = acc.y; red[wave][quad * 4 + 2] = acc.z; red[wave][quad * 4 + 3] = acc.w;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    const int jj = blockIdx.y * 16 + threadIdx.x;
+    if (jj < SQ) {
+      float a = red[0][threadIdx.x];
+#pragma unroll
+      for (int w = 1; w < 16; ++w) a += red[w][threadIdx.x];
+      gh[(long)n * SQ + jj] = a * swish_gradf_(h[(long)n * SQ + jj]);
+    }
   }
 }
 
@@ -217,7 +234,7 @@ int mx_se_bwd_gh(const float* ggate, const float* gate, const float* h, const fl
   MX_CHECK_ARG(ggate && gate && h && W2 && gh, "se_bwd_gh: null pointer");
   MX_CHECK_ARG(N > 0 && C > 0 && SQ > 0 && SQ <= SQ_MAX, "se_bwd_gh: bad extents N=%d C=%d SQ=%d", N, C, SQ);
   if (SQ % 4 == 0 && ((uintptr_t)W2 & 15) == 0)
-    hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 16)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh, C, SQ);
+    hipLaunchKernelGGL(se_bwd_a_kernel, dim3(N, cdiv(SQ, 16)), dim3(1024), 0, (hipStream_t)stream, ggate, gate, h, W2, gh, C, SQ);
   else
     hipLaunchKernelGGL(se_bwd_a1_kernel, dim3(N, cdiv(SQ, 4)), dim3(256), 0, (hipStream_t)stream, ggate, gate, h, W2, gh, C, SQ);
   MX_LAUNCH_CHECK();

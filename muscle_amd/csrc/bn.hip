@@ -101,6 +101,33 @@ __global__ __launch_bounds__(256) void colreduce_kernel(F f, ColGeom g, OutT* ou
     long r = r0 + tr;
     const long st = g.rpp;
     float4 b0 = make_float4(0, 0, 0, 0), b1 = b0, c0 = b0, c1 = b0, d0 = b0, d1 = b0;
+    if constexpr (F::kPipelined) {
+      // The SE squeeze (one tensor, two transcendentals per element): 2.25 workgroups per CU at C = 2304 cannot hide a round trip behind
+      // the evaluation of the previous eight rows, so the requests for rows r + 8 st .. r + 15 st leave BEFORE rows r .. r + 7 st are
+      // evaluated (78 -> ~50 us on the 231 MB tensors of stage 6; round 5).  Same accumulators in the same order as the plain loop below.
+      if (f.G == nullptr && r + 7 * st < r1) {
+        const int c = 4 * c4;
+        float4 cur[8], nxt[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) cur[i] = ld4(f.X + (r + i * st) * f.C + c);
+        for (;;) {
+          const bool more = r + 15 * st < r1;
+          if (more) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) nxt[i] = ld4(f.X + (r + (8 + i) * st) * f.C + c);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#define MX_POOL_ACC(s, v) { const float4 y = f.value(v, c); s.x += y.x; s.y += y.y; s.z += y.z; s.w += y.w; }
+          MX_POOL_ACC(a0, cur[0]) MX_POOL_ACC(b0, cur[1]) MX_POOL_ACC(c0, cur[2]) MX_POOL_ACC(d0, cur[3])
+          MX_POOL_ACC(a0, cur[4]) MX_POOL_ACC(b0, cur[5]) MX_POOL_ACC(c0, cur[6]) MX_POOL_ACC(d0, cur[7])
+#undef MX_POOL_ACC
+          r += 8 * st;
+          if (!more) break;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) cur[i] = nxt[i];
+        }
+      }
+    }
     if (NOUT == 1) {        // (eight rows for the two-tensor reductions as well: measured 0.1-0.2 ms per step slower, profiles/r04_knob_sweep.txt)
       for (; r + 7 * st < r1; r += 8 * st) {     // one-tensor reductions (pooling): eight independent rows in flight
         f.eval(r, 4 * c4, a0, a1);
@@ -226,6 +253,7 @@ struct GEff {
 };
 
 struct FBwdReduce {      // sum g, sum g*x
+  static constexpr bool kPipelined = false;
   GEff e;
   __device__ __forceinline__ void eval(long r, int c, float4& s0, float4& s1) const {
     float4 g, x;
@@ -236,6 +264,7 @@ struct FBwdReduce {      // sum g, sum g*x
 };
 
 struct FStats {          // sum x, sum x^2
+  static constexpr bool kPipelined = false;
   const float* X; int C;
   __device__ __forceinline__ void eval(long r, int c, float4& s0, float4& s1) const {
     float4 x = ld4(X + r * C + c);
@@ -245,14 +274,18 @@ struct FStats {          // sum x, sum x^2
 };
 
 struct FPool {           // per-sample: sum act(x) ; optionally sum g*act(x)
+  static constexpr bool kPipelined = true;      // colreduce_kernel requests the next eight rows before it evaluates the current eight (G == nullptr)
   const float* X; const float* G; const float* a; const float* b; int C; int act;
-  __device__ __forceinline__ void eval(long r, int c, float4& s0, float4& s1) const {
-    float4 x = ld4(X + r * C + c);
+  __device__ __forceinline__ float4 value(float4 x, int c) const {
     if (a) {
       float4 aa = ld4(a + c), bb = ld4(b + c);
       x.x = aa.x * x.x + bb.x; x.y = aa.y * x.y + bb.y; x.z = aa.z * x.z + bb.z; x.w = aa.w * x.w + bb.w;
     }
     if (act) { x.x = swishf_(x.x); x.y = swishf_(x.y); x.z = swishf_(x.z); x.w = swishf_(x.w); }
+    return x;
+  }
+  __device__ __forceinline__ void eval(long r, int c, float4& s0, float4& s1) const {
+    float4 x = value(ld4(X + r * C + c), c);
     if (G) {
       float4 g = ld4(G + r * C + c);
       x.x *= g.x; x.y *= g.y; x.z *= g.z; x.w *= g.w;

@@ -1124,7 +1124,7 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     // ids) keep every tested shape level with the fp32 kernel and are within 0.3 ms per step of g = 8.
     // The bound is on the CHAIN, not on the count: at most 1568 rows per group, so R = 50 176 (B7 at batch 64, or batch 32 at larger
     // images) takes 32 groups instead of running 3136-row chains at 16 (tests/test_gpu_split.py has R = 50 176 and 62 720 cases).
-    const int maxg = R / 256 > 0 ? R / 256 : 1;
+    const int maxg = R / 128 > 0 ? R / 128 : 1;
     if (x_mode == MX_PLAIN && wt_pipe_mode() >= 2) {
       // wgrad_split_ws_kernel: ONE persistent workgroup per CU deals the (group, tile) items out evenly, so the count that matters is
       // items / 256 rounded up.  Cost model from the kernel's own stamps at the clock it holds (~1.75 GHz): 1.09 us per 32-row slab,
@@ -1138,7 +1138,10 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
       if (gmin > maxg) gmin = maxg;
       int best_g = gmin;
       double best_t = 1e30;
-      for (int g = gmin; g <= maxg && g <= 3 * gmin + 8; ++g) {
+      // (every count up to 128-row groups is priced: outputs of a few tiles - 672 x 112 at 12 544 rows, B0 at batch 16 - fill the 256
+      //  workgroups only with 40+ groups; the search used to stop at 3 gmin + 8)
+      static const int wide = getenv("MX_WGRAD_WS_WIDE") ? atoi(getenv("MX_WGRAD_WS_WIDE")) : 1;
+      for (int g = gmin; g <= maxg && (wide || g <= 3 * gmin + 8); ++g) {
         const int rpg = cdiv(cdiv(R, g), 32) * 32, ga = cdiv(R, rpg);
         if (ga != g) continue;                                 // (the rounding of the rows makes some counts unreachable)
         const double t = cdiv(tiles * g, 256) * (rpg / 32 * 1.09 + 3.4) + g * ((double)Co * Ci * 4.0 / 4e6);
@@ -1159,7 +1162,8 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     const int tiles = p->tiles_co * p->tiles_ci;
     if (fill && tiles < 48) {
       int want = (cdiv(768, tiles) + 7) / 8 * 8;
-      const int cap = R / 512 >= 8 ? R / 512 / 8 * 8 : 8;
+      static const int minrows = getenv("MX_WGRAD_SPLIT_MINROWS") ? atoi(getenv("MX_WGRAD_SPLIT_MINROWS")) : 512;
+      const int cap = R / minrows >= 8 ? R / minrows / 8 * 8 : 8;
       if (want > 128) want = 128;
       if (want > cap) want = cap;
       if (want > groups) groups = want;

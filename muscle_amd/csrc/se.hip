@@ -174,6 +174,31 @@ __global__ __launch_bounds__(256) void se_bwd_b_kernel(const float* ggate, const
       }
     }
     if (blockIdx.y == 0) db2[c] += sb;
+    if (jn == SE_JB && (SQ & 3) == 0 && ((uintptr_t)dW2 & 15) == 0) {
+      // a full chunk: the four dW2[c, j0..j0+3] of this channel are ONE 16-byte read-modify-write (they were four 4-byte ones, 384 bytes
+      // apart between neighbouring lanes), and the gradient rows are requested before the sums are formed
+      float4* p2 = reinterpret_cast<float4*>(dW2 + (long)c * SQ + j0);
+      float4 o2 = *p2;
+      float o1[SE_JB];
+#pragma unroll
+      for (int jj = 0; jj < SE_JB; ++jj) o1[jj] = dW1[(long)(j0 + jj) * C + c];
+      float a2[SE_JB], a1[SE_JB];
+#pragma unroll
+      for (int jj = 0; jj < SE_JB; ++jj) {
+        a2[jj] = 0.f; a1[jj] = 0.f;
+#pragma unroll
+        for (int n = 0; n < SE_NB; ++n) {
+          const int nn = (n0 + n < N) ? n0 + n : 0;     // ge/sv are 0 beyond N
+          a2[jj] += ge[n] * r[nn * SE_JB + jj];
+          a1[jj] += ghs[nn * SE_JB + jj] * sv[n];
+        }
+      }
+      o2.x += a2[0]; o2.y += a2[1]; o2.z += a2[2]; o2.w += a2[3];
+      *p2 = o2;
+#pragma unroll
+      for (int jj = 0; jj < SE_JB; ++jj) dW1[(long)(j0 + jj) * C + c] = o1[jj] + a1[jj];
+      continue;
+    }
     for (int jj = 0; jj < jn; ++jj) {
       float a2 = 0.f, a1 = 0.f;
 #pragma unroll

@@ -75,3 +75,49 @@ def test_se_backward_is_the_same_bits_every_run():
     a = ops.se_bwd_gh(ggate, gate, h, W2).cpu()
     for _ in range(3):
         assert torch.equal(a, ops.se_bwd_gh(ggate, gate, h, W2).cpu())
+
+
+@pytest.mark.parametrize("N,C,SQ", [(32, 2304, 96), (32, 960, 40), (3, 48, 12), (16, 672, 28), (2, 240, 10), (33, 1344, 56), (64, 3840, 160), (5, 32, 8)])
+def test_bn1_sums_finalize_vs_fp64(N, C, SQ):
+    """mx_bn1_sums_finalize: the pooled-path gradient add[n,c] = inv_hw * sum_j gh[n,j] W1[j,c] (model.py:82-83 backward) and, from the five
+    per-sample sums of mx_se_bn1_pool, the BatchNorm-1 backward sums sum_n gate*S1 + add*S2 and sum_n gate*S3 + add*S4 with their
+    finalisation (dgamma / dbeta +=, coefficients of dX = c1*g + c2*x + c3) - against numpy fp64."""
+    import numpy as np
+    from muscle_amd import ops
+    from muscle_amd.ops import BNState
+    dev = torch.device("cuda:0")
+    rng = np.random.default_rng(N * 7919 + C + SQ)
+    hw = 784
+    rows = float(N * hw)
+    pooled5 = rng.normal(0, 30.0, size=(5, N, C)).astype(np.float32)
+    gate = rng.uniform(0.05, 0.95, size=(N, C)).astype(np.float32)
+    gh = rng.normal(0, 1.0, size=(N, SQ)).astype(np.float32)
+    W1 = (rng.normal(size=(SQ, C)) / np.sqrt(C)).astype(np.float32)
+    bn = torch.nn.BatchNorm2d(C).to(dev)
+    with torch.no_grad():
+        bn.weight.copy_(torch.from_numpy(rng.uniform(0.5, 1.5, size=C).astype(np.float32)))
+    mean = rng.normal(0, 0.5, size=C).astype(np.float32)
+    rstd = rng.uniform(0.5, 2.0, size=C).astype(np.float32)
+    T = lambda a: torch.from_numpy(a).to(dev)  # noqa: E731
+    st = BNState(T(rstd), T(mean), T(mean), T(rstd))
+    dg0, db0 = rng.normal(size=C).astype(np.float32), rng.normal(size=C).astype(np.float32)
+    dgamma, dbeta = T(dg0.copy()), T(db0.copy())
+    c, add = ops.bn1_coeffs(T(pooled5), T(gate), T(gh), T(W1), 1.0 / hw, rows, bn, st, dgamma, dbeta, True)
+    torch.cuda.synchronize()
+    add64 = (gh.astype(np.float64) @ W1.astype(np.float64)) / hw
+    np.testing.assert_allclose(add.cpu().numpy(), add64, rtol=2e-5, atol=2e-6 * np.abs(add64).max())
+    a32 = add.cpu().numpy().astype(np.float64)            # the sums are formed from the fp32 `add` the kernel stores
+    p = pooled5.astype(np.float64)
+    g64 = gate.astype(np.float64)
+    s0 = (g64 * p[1] + a32 * p[2]).sum(0)
+    s1 = (g64 * p[3] + a32 * p[4]).sum(0)
+    gam, m, r = bn.weight.detach().cpu().numpy().astype(np.float64), mean.astype(np.float64), rstd.astype(np.float64)
+    dgam = r * (s1 - m * s0)
+    k = gam * r * r * (dgam / rows)
+    sc = np.abs(s1).max() + np.abs(s0).max() + 1.0
+    np.testing.assert_allclose(dgamma.cpu().numpy(), dg0 + dgam, rtol=2e-5, atol=3e-6 * sc)
+    np.testing.assert_allclose(dbeta.cpu().numpy(), db0 + s0, rtol=2e-5, atol=3e-6 * sc)
+    got = c.cpu().numpy()
+    np.testing.assert_allclose(got[0], gam * r, rtol=3e-6)
+    np.testing.assert_allclose(got[1], -k, rtol=2e-5, atol=3e-6 * sc / rows)
+    np.testing.assert_allclose(got[2], -gam * r * (s0 / rows) + k * m, rtol=2e-5, atol=6e-6 * sc / rows)

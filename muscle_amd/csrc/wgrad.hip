@@ -1081,7 +1081,169 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-struct WtPlan { int te, tf, tiles_co, tiles_ci, groups, rows_per_group; };
+// The exact-fp32 weight gradient on specialised waves (round 5; mx_set_gemm_mode(0) only - the default arithmetic never gets here).
+// fp32 MFMA operands need no split and no transposition: v_mfma_f32_32x32x2_f32 takes ONE float per lane for each operand, element
+// (column l % 32, row l / 32 of a two-row K step), which is how the rows of G and X lie in memory.  So the loader waves (4-7) only MOVE rows,
+// with buffer_load_dwordx4 ... lds (range-checked LDS-DMA: rows past the group and columns past the matrix land as zeros), two rows of 128
+// columns per instruction, 8 instructions per wave and 32-row slab, no vector arithmetic and no ds_write at all; the MFMA waves (0-3, a 64 x 64
+// quadrant each) read 4 fragments (ds_read_b32) per 4 MFMAs of 64 cycles.  LDS image of an operand's slab: [32 rows][128 floats], the 16-byte unit u
+// of an odd row stored at position u ^ 8, so that the two rows one fragment read touches sit in different halves of the 64 banks.  Three stages
+// (96 KB).  Same persistent item loop, row groups, 1568-row chains and partial-tile stores as wgrad_split_ws_kernel.
+#ifndef WF32_NST
+#define WF32_NST 3
+#endif
+__global__ __launch_bounds__(512, 1) void wgrad_f32_ws_kernel(WtArgs a) {
+  constexpr int OPB = 32 * 512, STAGE = 2 * OPB, NST = WF32_NST;
+  extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];      // NST * STAGE
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tiles = a.tiles_co * a.tiles_ci;
+  const int items = tiles * a.groups;
+  const int slot = blockIdx.x >> 3, xcd = blockIdx.x & 7, chunk = gridDim.x >> 3;
+  typedef __attribute__((address_space(3))) void* wlds_t;
+
+  if (wave >= 4) {
+    // ---- loader waves: 4 / 5 move rows 0-15 / 16-31 of G's slab, 6 / 7 those of X's; lane = (row parity, 16-byte unit of the 128 columns)
+    const bool isx = wave >= 6;
+    const int half = wave & 1;
+    const int ld = __builtin_amdgcn_readfirstlane(isx ? a.ldx : a.ldg);
+    const int rpar = lane >> 5, gu = (lane & 31) ^ (rpar << 3);
+    const unsigned slab_bytes = (unsigned)(32 * ld * 4), row2_bytes = (unsigned)(2 * ld * 4);
+    unsigned char* const lbase = wf_smem + (isx ? OPB : 0) + 16 * half * 512;
+#define WF32_ISSUE(S)                                                                                                              \
+    { unsigned char* d_ = lbase + ((S) % NST) * STAGE;                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                                                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (wlds_t)(d_ + i_ * 1024), 16, vbase + (unsigned)i_ * row2_bytes, (unsigned)(S) * slab_bytes, 0, 0); }
+    for (int it = 0;; ++it) {
+      const int item = (xcd + 8 * it) * chunk + slot;
+      if (item >= items) break;
+      const int group = item / tiles, tile = item - group * tiles;
+      const int c0 = isx ? (tile % a.tiles_ci) * 128 : (tile / a.tiles_ci) * 128;
+      const long r_beg = (long)group * a.rows_per_group;
+      const int rows = (int)(min((long)a.R, r_beg + a.rows_per_group) - r_beg);
+      const int ns = (rows + 31) / 32;
+      const int col0 = c0 + 4 * gu;
+      const __amdgpu_buffer_rsrc_t rs = wbuf_rsrc((isx ? a.X.p : a.G) + r_beg * ld, (long)rows * ld * 4);
+      const unsigned vbase = col0 < (isx ? a.Ci : a.Co) ? (unsigned)(((16 * half + rpar) * ld + col0) * 4) : 0x7f000000u;
+      WF32_ISSUE(0)
+      if (ns > 1) {
+        WF32_ISSUE(1)
+        __builtin_amdgcn_s_waitcnt(0x0f78);       // vmcnt(8): slab 0 has landed
+      } else __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0)
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      for (int s = 0; s < ns; ++s) {
+        if (s + 2 < ns) {
+          WF32_ISSUE(s + 2)                         // into the stage the MFMA waves left at the last barrier
+          __builtin_amdgcn_s_waitcnt(0x0f78);       // slab s + 1 has landed
+        } else __builtin_amdgcn_s_waitcnt(0x0f70);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+    }
+#undef WF32_ISSUE
+    return;
+  }
+
+  // ---- MFMA waves
+  const int l31 = lane & 31, hf = lane >> 5;
+  const int wco = wave >> 1, wci = wave & 1;
+  // float f of a row sits at byte ((f >> 2) ^ (8 * row parity)) * 16 + (f & 3) * 4; this lane reads rows of parity hf
+  const int fg = 64 * wco + l31, fx = 64 * wci + l31;
+  const int og0 = hf * 512 + (((fg >> 2) ^ (hf << 3)) << 4) + ((fg & 3) << 2), og1 = hf * 512 + ((((fg + 32) >> 2) ^ (hf << 3)) << 4) + ((fg & 3) << 2);
+  const int ox0 = OPB + hf * 512 + (((fx >> 2) ^ (hf << 3)) << 4) + ((fx & 3) << 2), ox1 = OPB + hf * 512 + ((((fx + 32) >> 2) ^ (hf << 3)) << 4) + ((fx & 3) << 2);
+  for (int it = 0;; ++it) {
+    const int item = (xcd + 8 * it) * chunk + slot;
+    if (item >= items) break;
+    const int group = item / tiles, tile = item - group * tiles;
+    const int co0 = (tile / a.tiles_ci) * 128, ci0 = (tile % a.tiles_ci) * 128;
+    const long r_beg = (long)group * a.rows_per_group;
+    const int rows = (int)(min((long)a.R, r_beg + a.rows_per_group) - r_beg);
+    const int ns = (rows + 31) / 32;
+    wf32x16 acc[2][2], acc2[2][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e)
+#pragma unroll
+      for (int f = 0; f < 2; ++f)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
+    bool flushed = false;
+    int flush_at = WWS_CHAIN;
+    __builtin_amdgcn_s_barrier();                // slab 0 of this item is in stage 0
+    asm volatile("" ::: "memory");
+    for (int s = 0; s < ns; ++s) {
+      if (s == flush_at) {                       // one fp32 accumulation chain is at most 1568 rows (as in the split kernel)
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+          for (int f = 0; f < 2; ++f)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc2[e][f][r] = flushed ? acc2[e][f][r] + acc[e][f][r] : acc[e][f][r]; acc[e][f][r] = 0.f; }
+        flushed = true;
+        flush_at += WWS_CHAIN;
+      }
+      const unsigned char* st_ = wf_smem + (s % NST) * STAGE;
+      float g0 = *reinterpret_cast<const float*>(st_ + og0), g1 = *reinterpret_cast<const float*>(st_ + og1);
+      float x0 = *reinterpret_cast<const float*>(st_ + ox0), x1 = *reinterpret_cast<const float*>(st_ + ox1);
+#pragma unroll
+      for (int kk = 0; kk < 16; ++kk) {
+        float ng0 = 0.f, ng1 = 0.f, nx0 = 0.f, nx1 = 0.f;
+        if (kk < 15) {                           // the next two rows' fragments, under this step's MFMAs
+          ng0 = *reinterpret_cast<const float*>(st_ + og0 + (kk + 1) * 1024); ng1 = *reinterpret_cast<const float*>(st_ + og1 + (kk + 1) * 1024);
+          nx0 = *reinterpret_cast<const float*>(st_ + ox0 + (kk + 1) * 1024); nx1 = *reinterpret_cast<const float*>(st_ + ox1 + (kk + 1) * 1024);
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x1, acc[1][1], 0, 0, 0);
+        g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
+      }
+      __builtin_amdgcn_s_waitcnt(0xc07f);        // every LDS read of this stage has returned
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (flushed) {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[e][f][r] = acc2[e][f][r] + acc[e][f][r];
+    }
+    // acc[e][f][4 g + r] = dW[co0 + 64 wco + 32 e + 8 g + 4 hf + r][ci0 + 64 wci + 32 f + l31]  (the layout of every 32 x 32 MFMA result)
+    if (!a.accumulate) {
+      const __amdgpu_buffer_rsrc_t ro = wbuf_rsrc(a.part + (long)group * a.Co * a.Ci, (long)a.Co * a.Ci * 4);
+      const int cib = ci0 + 64 * wci + l31;
+      const unsigned rowo = (unsigned)(((co0 + 64 * wco + 4 * hf) * a.Ci) * 4);
+      const unsigned vo[2] = {cib < a.Ci ? rowo + (unsigned)cib * 4u : 0x7f000000u, cib + 32 < a.Ci ? rowo + (unsigned)(cib + 32) * 4u : 0x7f000000u};
+      const unsigned rstep = (unsigned)(a.Ci * 4);
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[e][f][r]), ro, vo[f], (unsigned)(32 * e + 8 * (r >> 2) + (r & 3)) * rstep, 0);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 2; ++e)
+#pragma unroll
+        for (int f = 0; f < 2; ++f) {
+          const int ci = ci0 + 64 * wci + 32 * f + l31;
+          if (ci >= a.Ci) continue;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int co = co0 + 64 * wco + 32 * e + 8 * (r >> 2) + 4 * hf + (r & 3);
+            if (co >= a.Co) continue;
+            float* o = a.part + (long)co * a.Ci + ci;
+            *o = *o + acc[e][f][r];
+          }
+        }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct WtPlan { int te, tf, tiles_co, tiles_ci, groups, rows_per_group, f32ws; };
 int mx_wgrad_pipe_override = -1;      // lab hook (tools/hip/gemm_lab.hip): 0 / 1 selects the first / pipelined split kernel per call
 
 static int wt_order() {
@@ -1107,9 +1269,11 @@ static int wt_pipe_mode() {
   return mx_wgrad_pipe_override >= 0 ? mx_wgrad_pipe_override : pipe_env;
 }
 static int g_wgrad_groups = 0;         // mx_set_wgrad_kernel: > 0 fixes the row groups of the plain split launches
+static int g_wgrad_f32ws = getenv("MX_WGRAD_F32_WS") ? atoi(getenv("MX_WGRAD_F32_WS")) : 1;      // exact-fp32 mode: wgrad_f32_ws_kernel for the 128 x 128 tiles (0: the tiled kernel)
 
 static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
   if (Co % 4 || Ci % 4 || R < 1024 || (long)Co * Ci < 16384) return false;
+  p->f32ws = 0;
   if (wt_use_split(Co, Ci)) {
     p->te = p->tf = 4;
     p->tiles_co = cdiv(Co, 128); p->tiles_ci = cdiv(Ci, 128);
@@ -1186,6 +1350,26 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     }
   p->tiles_co = cdiv(Co, 32 * p->te); p->tiles_ci = cdiv(Ci, 32 * p->tf);
   const int tiles = p->tiles_co * p->tiles_ci;
+  // exact-fp32 arithmetic (mx_set_gemm_mode(0)), 128 x 128 tiles, plain operands: wgrad_f32_ws_kernel - one persistent workgroup per CU, so
+  // the row groups come from the same 256-slot model as the split kernel's (2.15 us per 32-row slab: 64 MFMAs of 64 cycles per wave at the
+  // clock the chip holds; 3.4 us per item; chains of 1568 rows flushed inside the kernel)
+  if (g_wgrad_f32ws && mx_get_gemm_mode() == 0 && p->te == 4 && p->tf == 4 && x_mode == MX_PLAIN && g_wgrad_groups <= 0) {
+    const int maxg = R / 128 > 0 ? R / 128 : 1;
+    int gmin = cdiv(R, 1568 * 3);
+    if (gmin > maxg) gmin = maxg;
+    int best_g = gmin;
+    double best_t = 1e30;
+    for (int g = gmin; g <= maxg; ++g) {
+      const int rpg = cdiv(cdiv(R, g), 32) * 32, ga = cdiv(R, rpg);
+      if (ga != g) continue;
+      const double t = cdiv(tiles * g, 256) * (rpg / 32 * 2.15 + 3.4) + g * ((double)Co * Ci * 4.0 / 4e6);
+      if (t < best_t - 1e-9) { best_t = t; best_g = g; }
+    }
+    p->rows_per_group = cdiv(cdiv(R, best_g), 32) * 32;
+    p->groups = cdiv(R, p->rows_per_group);
+    p->f32ws = 1;
+    return true;
+  }
   // Row groups: tiles x groups should fill a whole number of residency rounds (256 CUs x 4 workgroups, 3 for the 128 x 128
   // tile with the BN+SiLU+gate prologue).  1026 workgroups on 1024 slots cost 25 % (two stragglers run alone after a full
   // round); every extra group costs a partial matrix written and read back.
@@ -1415,6 +1599,11 @@ static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, 
     else if (a.X.mode == MX_PLAIN) hipLaunchKernelGGL((wgrad_split_kernel<MX_PLAIN, false>), grid, dim3(256), pad, st, a);
     else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_split_kernel<MX_BNACT, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_split_kernel<MX_AFFINE, false>), grid, dim3(256), 0, st, a);
+  } else if (p.f32ws && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30) && (long)a.Co * a.Ci * 4 < (1l << 30)) {
+    static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WF32_NST * 2 * 32 * 512), 0);
+    (void)once;
+    const int items = a.groups * a.tiles_co * a.tiles_ci;
+    hipLaunchKernelGGL(wgrad_f32_ws_kernel, dim3(items < 256 ? 8 * cdiv(items, 8) : 256), dim3(512), WF32_NST * 2 * 32 * 512, st, a);
   } else if (p.te == 4 && p.tf == 4) wt_launch<4, 4>(a, st);
   else if (p.te == 4) wt_launch<4, 2>(a, st);
   else if (p.tf == 4) wt_launch<2, 4>(a, st);

@@ -341,6 +341,44 @@ static void run_widths(int M, int K, int N) {
   CK(hipFree(planes)); CK(hipFree(table));
 }
 
+// wgradf32 R Co Ci: exact-fp32 weight gradient, the tiled kernel against wgrad_f32_ws_kernel (gemm mode 0), same process: time, max difference,
+// both against fp64 on a sample of output elements
+static int run_wgradf32(int R, int Co, int Ci) {
+  if (!ws) CK(hipMalloc(&ws, ws_bytes));
+  mx_set_gemm_mode(0);
+  float* G = dalloc((long)R * Co, 11, 1.f); float* X = dalloc((long)R * Ci, 12, 1.f);
+  float* d0 = dalloc((long)Co * Ci, 13, 0.f); float* d1 = dalloc((long)Co * Ci, 13, 0.f);
+  float t[2] = {1e30f, 1e30f};
+  for (int round = 0; round < 3; ++round)
+    for (int v = 0; v < 2; ++v) {
+      g_wgrad_f32ws = v;
+      if (mx_pw_wgrad_tile_ws(R, Co, Ci, 0) > ws_bytes) { printf("  workspace too small\n"); return 1; }
+      t[v] = std::min(t[v], time_us([&] { mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, v ? d1 : d0, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr); }, 5));
+    }
+  CK(hipMemset(d0, 0, (size_t)Co * Ci * 4)); CK(hipMemset(d1, 0, (size_t)Co * Ci * 4));
+  g_wgrad_f32ws = 0; mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, d0, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr);
+  g_wgrad_f32ws = 1; mx_pw_wgrad_tile(G, X, 0, nullptr, nullptr, nullptr, 1, d1, R, Co, Ci, Co, Ci, ws, ws_bytes, nullptr);
+  CK(hipDeviceSynchronize());
+  std::vector<float> h0((size_t)Co * Ci), h1((size_t)Co * Ci), hG((size_t)R * Co), hX((size_t)R * Ci);
+  CK(hipMemcpy(h0.data(), d0, h0.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h1.data(), d1, h1.size() * 4, hipMemcpyDeviceToHost));
+  CK(hipMemcpy(hG.data(), G, hG.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(hX.data(), X, hX.size() * 4, hipMemcpyDeviceToHost));
+  double dmax = 0, e0 = 0, e1 = 0, vmax = 0;
+  for (size_t i = 0; i < h0.size(); ++i) { dmax = std::max(dmax, (double)fabs(h0[i] - h1[i])); vmax = std::max(vmax, (double)fabs(h0[i])); }
+  for (int k = 0; k < 64; ++k) {
+    const int co = (int)((k * 7919L + 3) % Co), ci = (int)((k * 104729L + 5) % Ci);
+    double acc = 0;
+    for (long r = 0; r < R; ++r) acc += (double)hG[r * Co + co] * hX[r * Ci + ci];
+    e0 = std::max(e0, fabs(acc - h0[(size_t)co * Ci + ci])); e1 = std::max(e1, fabs(acc - h1[(size_t)co * Ci + ci]));
+  }
+  const double fl = 2.0 * R * Co * Ci;
+  printf("  R=%d Co=%d Ci=%d: tiled %7.1f us %6.1f TF | ws %7.1f us %6.1f TF | max|d| = %g (max|v| = %g); vs fp64 on 64 elements: tiled %.3g ws %.3g%s\n", R, Co, Ci,
+         t[0], fl / t[0] * 1e-6, t[1], fl / t[1] * 1e-6, dmax, vmax, e0, e1, (dmax > 2e-3 * vmax || e1 > 2.0 * e0 + 1e-4 * vmax) ? "  FAILED" : "");
+  fflush(stdout);
+  for (float* p : {G, X, d0, d1}) CK(hipFree(p));
+  g_wgrad_f32ws = 1;
+  return 0;
+}
+
 static int wlab_mode() { return getenv("WLAB_MODE") ? atoi(getenv("WLAB_MODE")) : 2; }
 // wgrad [R Co Ci]: the first split weight-gradient kernel against the round-5 ones (WLAB_MODE = 1 single-stream pipeline, 2 wave-specialised), same process: time, bits
 static int run_wgrad(int R, int Co, int Ci) {
@@ -460,6 +498,7 @@ static int run_wgradf(int R, int Co, int Ci) {
 }
 
 int main(int argc, char** argv) {
+  if (argc >= 5 && !strcmp(argv[1], "wgradf32")) return run_wgradf32(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
   if (argc >= 2 && !strcmp(argv[1], "wgradf")) {
     if (argc >= 5) return run_wgradf(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     static const Shape sh[] = {{25088, 2304, 384}, {25088, 3840, 640}, {25088, 1344, 224}, {25088, 960, 160}};

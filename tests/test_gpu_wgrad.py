@@ -113,3 +113,42 @@ def test_dgrad_with_folded_bn_backward_apply():
         dx, dz = ops.pw_dgrad_bnbwd(G, X, c, W, N, residual=res)
         assert torch.allclose(dz, dz_ref, rtol=0, atol=2e-6 * float(dz_ref.abs().max()))
         assert (dx - dx_ref).abs().max().item() <= 2e-5 * dx_ref.abs().max().item()
+
+
+@pytest.mark.parametrize("R,Co,Ci,pad", [(25088, 2304, 384, 0), (25107, 640, 2304, 0), (12551, 1344, 256, 0), (1024, 128, 128, 0), (2048, 256, 384, 64),
+                                         (50176, 384, 640, 0), (4700, 512, 128, 32), (3136, 1280, 640, 0)])
+def test_exact_fp32_wgrad_on_specialised_waves_vs_fp64(R, Co, Ci, pad):
+    """wgrad_f32_ws_kernel (mx_set_gemm_mode(0), plain operands, outputs tiled 128 x 128): rows moved by range-checked LDS-DMA, one float per
+    operand and lane into v_mfma_f32_32x32x2_f32.  Ragged row counts, a last tile of 64 columns, operands that are column slices of wider
+    tensors (leading dimension > width), one / two / three 1568-row chains per group, a running sum in dW, the same bits on a second run -
+    against fp64, held to the error of an fp32 dot product of that length."""
+    from muscle_amd import ops
+    from muscle_amd._lib import lib
+    prev = ops.get_gemm_mode()
+    ops.set_gemm_mode(0)
+    try:
+        assert lib().mx_pw_wgrad_small_ws(R, Co, Ci, 0) == 0 and lib().mx_pw_wgrad_tile_ws(R, Co, Ci, 0) > 0
+        g = torch.Generator(device=DEV).manual_seed(R * 3 + Co + Ci)
+        Gw = torch.randn(R, Co + pad, device=DEV, generator=g)
+        Xw = torch.randn(R, Ci + pad, device=DEV, generator=g)
+        G, X = Gw[:, :Co], Xw[:, pad:] if pad else Xw          # (the X slice starts `pad` columns in: a base pointer off the row start)
+        ref = G.double().t() @ X.double()
+        base = torch.randn(Co, Ci, device=DEV, generator=g)
+        outs = []
+        from muscle_amd._lib import call, ptr, stream
+        need = lib().mx_pw_wgrad_tile_ws(R, Co, Ci, 0)
+        ws = torch.zeros(need, dtype=torch.uint8, device=DEV)
+        for _ in range(2):
+            dW = base.clone()
+            if pad:      # the C entry point takes the leading dimensions; the Python wrapper only hands over whole tensors
+                call("mx_pw_wgrad_tile", G.data_ptr(), X.data_ptr(), 0, None, None, None, 1, ptr(dW), R, Co, Ci, G.stride(0), X.stride(0),
+                     ws.data_ptr(), ws.numel(), stream())
+            else:
+                ops.pw_wgrad(G, X, dW)
+            outs.append(dW)
+        assert torch.equal(outs[0], outs[1])
+        scale = ref.abs().max().item()
+        err = (outs[0].double() - base.double() - ref).abs().max().item()
+        assert err <= 2e-6 * scale + 4e-7 * float(R) ** 0.5 * 4.0, (err, scale)
+    finally:
+        ops.set_gemm_mode(prev)

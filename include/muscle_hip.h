@@ -147,7 +147,12 @@ int mx_pw_wgrad_small(const float* G, const float* X, int x_mode, const float* x
 
 /* The same weight gradient for LARGE outputs (Co*Ci >= 16384): dW cut into 128/64-wide tiles, the rows into groups, partial
  * tiles per group added in a fixed order - deterministic, no atomics; workgroup ids are XCD-aware so that a row slab crosses
- * the fabric once.  mx_pw_wgrad_tile_ws: bytes of scratch needed, 0 = shape not taken. */
+ * the fabric once.  mx_pw_wgrad_tile_ws: bytes of scratch needed, 0 = shape not taken.
+ * Kernels behind it (same results contract, chosen per shape and arithmetic): split arithmetic, plain operands - one persistent
+ * workgroup per CU of 4 MFMA waves + 4 loader waves (wgrad_split_ws_kernel; mx_set_wgrad_kernel selects the earlier forms);
+ * exact-fp32 arithmetic (mx_set_gemm_mode(0)), plain operands, 128 x 128 tiles - the same workgroup with loader waves that only move
+ * rows by LDS-DMA and v_mfma_f32_32x32x2 MFMA waves (wgrad_f32_ws_kernel); operand prologues and the other tile sizes - the first
+ * split kernel / the tiled fp32 kernel.  One fp32 accumulation chain is at most 1568 rows in the wave-specialised forms. */
 long mx_pw_wgrad_tile_ws(int R, int Co, int Ci, int x_mode);
 int mx_pw_wgrad_tile(const float* G, const float* X, int x_mode, const float* x_scale, const float* x_shift,
                      const float* x_gate, int rows_per_sample, float* dW, int R, int Co, int Ci, int ldg, int ldx,

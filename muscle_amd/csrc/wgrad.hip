@@ -1092,8 +1092,12 @@ __global__ __launch_bounds__(512, 1) void wgrad_split_ws_kernel(WtArgs a) {
 #ifndef WF32_NST
 #define WF32_NST 3
 #endif
+// E, F: 32-row / 32-column blocks of a wave's quadrant - the workgroup's tile is 64 E x 64 F (128 x 128, 128 x 64 for narrow Ci such as 960 x 160,
+// 64 x 128 for its mirror); the LDS image keeps its 128-float rows, the loader lanes past a 64-wide tile ask for nothing.
+template <int E, int F>
 __global__ __launch_bounds__(512, 1) void wgrad_f32_ws_kernel(WtArgs a) {
   constexpr int OPB = 32 * 512, STAGE = 2 * OPB, NST = WF32_NST;
+  constexpr int BCO = 64 * E, BCI = 64 * F;
   extern __shared__ __attribute__((aligned(16))) unsigned char wf_smem[];      // NST * STAGE
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int tiles = a.tiles_co * a.tiles_ci;
@@ -1117,13 +1121,13 @@ __global__ __launch_bounds__(512, 1) void wgrad_f32_ws_kernel(WtArgs a) {
       const int item = (xcd + 8 * it) * chunk + slot;
       if (item >= items) break;
       const int group = item / tiles, tile = item - group * tiles;
-      const int c0 = isx ? (tile % a.tiles_ci) * 128 : (tile / a.tiles_ci) * 128;
+      const int c0 = isx ? (tile % a.tiles_ci) * BCI : (tile / a.tiles_ci) * BCO;
       const long r_beg = (long)group * a.rows_per_group;
       const int rows = (int)(min((long)a.R, r_beg + a.rows_per_group) - r_beg);
       const int ns = (rows + 31) / 32;
       const int col0 = c0 + 4 * gu;
       const __amdgpu_buffer_rsrc_t rs = wbuf_rsrc((isx ? a.X.p : a.G) + r_beg * ld, (long)rows * ld * 4);
-      const unsigned vbase = col0 < (isx ? a.Ci : a.Co) ? (unsigned)(((16 * half + rpar) * ld + col0) * 4) : 0x7f000000u;
+      const unsigned vbase = (4 * gu < (isx ? BCI : BCO) && col0 < (isx ? a.Ci : a.Co)) ? (unsigned)(((16 * half + rpar) * ld + col0) * 4) : 0x7f000000u;
       WF32_ISSUE(0)
       if (ns > 1) {
         WF32_ISSUE(1)
@@ -1148,22 +1152,24 @@ __global__ __launch_bounds__(512, 1) void wgrad_f32_ws_kernel(WtArgs a) {
   const int l31 = lane & 31, hf = lane >> 5;
   const int wco = wave >> 1, wci = wave & 1;
   // float f of a row sits at byte ((f >> 2) ^ (8 * row parity)) * 16 + (f & 3) * 4; this lane reads rows of parity hf
-  const int fg = 64 * wco + l31, fx = 64 * wci + l31;
-  const int og0 = hf * 512 + (((fg >> 2) ^ (hf << 3)) << 4) + ((fg & 3) << 2), og1 = hf * 512 + ((((fg + 32) >> 2) ^ (hf << 3)) << 4) + ((fg & 3) << 2);
-  const int ox0 = OPB + hf * 512 + (((fx >> 2) ^ (hf << 3)) << 4) + ((fx & 3) << 2), ox1 = OPB + hf * 512 + ((((fx + 32) >> 2) ^ (hf << 3)) << 4) + ((fx & 3) << 2);
+  int og[E], ox[F];
+#pragma unroll
+  for (int e = 0; e < E; ++e) { const int f_ = 32 * E * wco + 32 * e + l31; og[e] = hf * 512 + (((f_ >> 2) ^ (hf << 3)) << 4) + ((f_ & 3) << 2); }
+#pragma unroll
+  for (int f = 0; f < F; ++f) { const int f_ = 32 * F * wci + 32 * f + l31; ox[f] = OPB + hf * 512 + (((f_ >> 2) ^ (hf << 3)) << 4) + ((f_ & 3) << 2); }
   for (int it = 0;; ++it) {
     const int item = (xcd + 8 * it) * chunk + slot;
     if (item >= items) break;
     const int group = item / tiles, tile = item - group * tiles;
-    const int co0 = (tile / a.tiles_ci) * 128, ci0 = (tile % a.tiles_ci) * 128;
+    const int co0 = (tile / a.tiles_ci) * BCO, ci0 = (tile % a.tiles_ci) * BCI;
     const long r_beg = (long)group * a.rows_per_group;
     const int rows = (int)(min((long)a.R, r_beg + a.rows_per_group) - r_beg);
     const int ns = (rows + 31) / 32;
-    wf32x16 acc[2][2], acc2[2][2];
+    wf32x16 acc[E][F], acc2[E][F];
 #pragma unroll
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < E; ++e)
 #pragma unroll
-      for (int f = 0; f < 2; ++f)
+      for (int f = 0; f < F; ++f)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[e][f][r] = 0.f;
     bool flushed = false;
@@ -1173,29 +1179,35 @@ __global__ __launch_bounds__(512, 1) void wgrad_f32_ws_kernel(WtArgs a) {
     for (int s = 0; s < ns; ++s) {
       if (s == flush_at) {                       // one fp32 accumulation chain is at most 1568 rows (as in the split kernel)
 #pragma unroll
-        for (int e = 0; e < 2; ++e)
+        for (int e = 0; e < E; ++e)
 #pragma unroll
-          for (int f = 0; f < 2; ++f)
+          for (int f = 0; f < F; ++f)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc2[e][f][r] = flushed ? acc2[e][f][r] + acc[e][f][r] : acc[e][f][r]; acc[e][f][r] = 0.f; }
         flushed = true;
         flush_at += WWS_CHAIN;
       }
       const unsigned char* st_ = wf_smem + (s % NST) * STAGE;
-      float g0 = *reinterpret_cast<const float*>(st_ + og0), g1 = *reinterpret_cast<const float*>(st_ + og1);
-      float x0 = *reinterpret_cast<const float*>(st_ + ox0), x1 = *reinterpret_cast<const float*>(st_ + ox1);
+      float gv[E], xv[F];
+#pragma unroll
+      for (int e = 0; e < E; ++e) gv[e] = *reinterpret_cast<const float*>(st_ + og[e]);
+#pragma unroll
+      for (int f = 0; f < F; ++f) xv[f] = *reinterpret_cast<const float*>(st_ + ox[f]);
 #pragma unroll
       for (int kk = 0; kk < 16; ++kk) {
-        float ng0 = 0.f, ng1 = 0.f, nx0 = 0.f, nx1 = 0.f;
-        if (kk < 15) {                           // the next two rows' fragments, under this step's MFMAs
-          ng0 = *reinterpret_cast<const float*>(st_ + og0 + (kk + 1) * 1024); ng1 = *reinterpret_cast<const float*>(st_ + og1 + (kk + 1) * 1024);
-          nx0 = *reinterpret_cast<const float*>(st_ + ox0 + (kk + 1) * 1024); nx1 = *reinterpret_cast<const float*>(st_ + ox1 + (kk + 1) * 1024);
-        }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x0, acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g0, x1, acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x0, acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(g1, x1, acc[1][1], 0, 0, 0);
-        g0 = ng0; g1 = ng1; x0 = nx0; x1 = nx1;
+        float ng[E], nx[F];
+#pragma unroll
+        for (int e = 0; e < E; ++e) ng[e] = kk < 15 ? *reinterpret_cast<const float*>(st_ + og[e] + (kk + 1) * 1024) : 0.f;      // the next two rows' fragments,
+#pragma unroll
+        for (int f = 0; f < F; ++f) nx[f] = kk < 15 ? *reinterpret_cast<const float*>(st_ + ox[f] + (kk + 1) * 1024) : 0.f;      // under this step's MFMAs
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+#pragma unroll
+          for (int f = 0; f < F; ++f) acc[e][f] = __builtin_amdgcn_mfma_f32_32x32x2f32(gv[e], xv[f], acc[e][f], 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < E; ++e) gv[e] = ng[e];
+#pragma unroll
+        for (int f = 0; f < F; ++f) xv[f] = nx[f];
       }
       __builtin_amdgcn_s_waitcnt(0xc07f);        // every LDS read of this stage has returned
       __builtin_amdgcn_s_barrier();
@@ -1203,36 +1215,38 @@ __global__ __launch_bounds__(512, 1) void wgrad_f32_ws_kernel(WtArgs a) {
     }
     if (flushed) {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < E; ++e)
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < F; ++f)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[e][f][r] = acc2[e][f][r] + acc[e][f][r];
     }
-    // acc[e][f][4 g + r] = dW[co0 + 64 wco + 32 e + 8 g + 4 hf + r][ci0 + 64 wci + 32 f + l31]  (the layout of every 32 x 32 MFMA result)
+    // acc[e][f][4 g + r] = dW[co0 + 32 E wco + 32 e + 8 g + 4 hf + r][ci0 + 32 F wci + 32 f + l31]  (the layout of every 32 x 32 MFMA result)
     if (!a.accumulate) {
       const __amdgpu_buffer_rsrc_t ro = wbuf_rsrc(a.part + (long)group * a.Co * a.Ci, (long)a.Co * a.Ci * 4);
-      const int cib = ci0 + 64 * wci + l31;
-      const unsigned rowo = (unsigned)(((co0 + 64 * wco + 4 * hf) * a.Ci) * 4);
-      const unsigned vo[2] = {cib < a.Ci ? rowo + (unsigned)cib * 4u : 0x7f000000u, cib + 32 < a.Ci ? rowo + (unsigned)(cib + 32) * 4u : 0x7f000000u};
+      const int cib = ci0 + 32 * F * wci + l31;
+      const unsigned rowo = (unsigned)(((co0 + 32 * E * wco + 4 * hf) * a.Ci) * 4);
+      unsigned vo[F];
+#pragma unroll
+      for (int f = 0; f < F; ++f) vo[f] = cib + 32 * f < a.Ci ? rowo + (unsigned)(cib + 32 * f) * 4u : 0x7f000000u;
       const unsigned rstep = (unsigned)(a.Ci * 4);
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < E; ++e)
 #pragma unroll
-        for (int f = 0; f < 2; ++f)
+        for (int f = 0; f < F; ++f)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[e][f][r]), ro, vo[f], (unsigned)(32 * e + 8 * (r >> 2) + (r & 3)) * rstep, 0);
     } else {
 #pragma unroll
-      for (int e = 0; e < 2; ++e)
+      for (int e = 0; e < E; ++e)
 #pragma unroll
-        for (int f = 0; f < 2; ++f) {
-          const int ci = ci0 + 64 * wci + 32 * f + l31;
+        for (int f = 0; f < F; ++f) {
+          const int ci = ci0 + 32 * F * wci + 32 * f + l31;
           if (ci >= a.Ci) continue;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int co = co0 + 64 * wco + 32 * e + 8 * (r >> 2) + 4 * hf + (r & 3);
+            const int co = co0 + 32 * E * wco + 32 * e + 8 * (r >> 2) + 4 * hf + (r & 3);
             if (co >= a.Co) continue;
             float* o = a.part + (long)co * a.Ci + ci;
             *o = *o + acc[e][f][r];
@@ -1353,7 +1367,16 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
   // exact-fp32 arithmetic (mx_set_gemm_mode(0)), 128 x 128 tiles, plain operands: wgrad_f32_ws_kernel - one persistent workgroup per CU, so
   // the row groups come from the same 256-slot model as the split kernel's (2.15 us per 32-row slab: 64 MFMAs of 64 cycles per wave at the
   // clock the chip holds; 3.4 us per item; chains of 1568 rows flushed inside the kernel)
-  if (g_wgrad_f32ws && mx_get_gemm_mode() == 0 && p->te == 4 && p->tf == 4 && x_mode == MX_PLAIN && g_wgrad_groups <= 0) {
+  if (g_wgrad_f32ws && mx_get_gemm_mode() == 0 && x_mode == MX_PLAIN && g_wgrad_groups <= 0) {
+    // tile of the wave-specialised fp32 kernel: 128 x 128, or 128 x 64 / 64 x 128 where that pads less MFMA work (960 x 160, 480 x 80 and mirrors)
+    int be = 2, bf = 2;
+    long bw = (long)cdiv(Co, 128) * cdiv(Ci, 128) * 4;
+    if ((long)cdiv(Co, 128) * cdiv(Ci, 64) * 2 < bw) { bw = (long)cdiv(Co, 128) * cdiv(Ci, 64) * 2; be = 2; bf = 1; }
+    if ((long)cdiv(Co, 64) * cdiv(Ci, 128) * 2 < bw) { bw = (long)cdiv(Co, 64) * cdiv(Ci, 128) * 2; be = 1; bf = 2; }
+    p->te = 2 * be; p->tf = 2 * bf;
+    p->tiles_co = cdiv(Co, 64 * be); p->tiles_ci = cdiv(Ci, 64 * bf);
+    const int tiles = p->tiles_co * p->tiles_ci;
+    const double slab_us = 0.55 * be * bf;                   // 16 K steps x E x F MFMAs of 64 cycles per wave and slab, at the clock the chip holds
     const int maxg = R / 128 > 0 ? R / 128 : 1;
     int gmin = cdiv(R, 1568 * 3);
     if (gmin > maxg) gmin = maxg;
@@ -1362,7 +1385,7 @@ static bool wt_plan(int R, int Co, int Ci, int x_mode, WtPlan* p) {
     for (int g = gmin; g <= maxg; ++g) {
       const int rpg = cdiv(cdiv(R, g), 32) * 32, ga = cdiv(R, rpg);
       if (ga != g) continue;
-      const double t = cdiv(tiles * g, 256) * (rpg / 32 * 2.15 + 3.4) + g * ((double)Co * Ci * 4.0 / 4e6);
+      const double t = cdiv(tiles * g, 256) * (rpg / 32 * slab_us + 3.4) + g * ((double)Co * Ci * 4.0 / 4e6);
       if (t < best_t - 1e-9) { best_t = t; best_g = g; }
     }
     p->rows_per_group = cdiv(cdiv(R, best_g), 32) * 32;
@@ -1600,10 +1623,22 @@ static int wgrad_tile_impl(const float* G, const float* G2, const float* gcoef, 
     else if (a.X.mode == MX_BNACT) hipLaunchKernelGGL((wgrad_split_kernel<MX_BNACT, false>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((wgrad_split_kernel<MX_AFFINE, false>), grid, dim3(256), 0, st, a);
   } else if (p.f32ws && ((long)a.rows_per_group + 96) * (a.ldg > a.ldx ? a.ldg : a.ldx) * 4 < (1l << 30) && (long)a.Co * a.Ci * 4 < (1l << 30)) {
-    static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_ws_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, WF32_NST * 2 * 32 * 512), 0);
-    (void)once;
     const int items = a.groups * a.tiles_co * a.tiles_ci;
-    hipLaunchKernelGGL(wgrad_f32_ws_kernel, dim3(items < 256 ? 8 * cdiv(items, 8) : 256), dim3(512), WF32_NST * 2 * 32 * 512, st, a);
+    const dim3 grid(items < 256 ? 8 * cdiv(items, 8) : 256);
+    constexpr int lds = WF32_NST * 2 * 32 * 512;
+    if (p.te == 4 && p.tf == 4) {
+      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_ws_kernel<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), 0);
+      (void)once;
+      hipLaunchKernelGGL((wgrad_f32_ws_kernel<2, 2>), grid, dim3(512), lds, st, a);
+    } else if (p.te == 4) {
+      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_ws_kernel<2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), 0);
+      (void)once;
+      hipLaunchKernelGGL((wgrad_f32_ws_kernel<2, 1>), grid, dim3(512), lds, st, a);
+    } else {
+      static const int once = (hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_f32_ws_kernel<1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds), 0);
+      (void)once;
+      hipLaunchKernelGGL((wgrad_f32_ws_kernel<1, 2>), grid, dim3(512), lds, st, a);
+    }
   } else if (p.te == 4 && p.tf == 4) wt_launch<4, 4>(a, st);
   else if (p.te == 4) wt_launch<4, 2>(a, st);
   else if (p.tf == 4) wt_launch<2, 4>(a, st);
